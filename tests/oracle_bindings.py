@@ -1,0 +1,269 @@
+"""ctypes bindings for the TEST-ONLY checkers:
+
+* ``Oracle``  -> oracle/liboracle.so   (C restatement of the CompV hot path, oracle/compv_oracle.c)
+* ``RefShim`` -> oracle/_ref/libcompv_refshim.so (the real CompV library compiled from /root/reference by
+  oracle/build_ref.sh; present in the build container and, as a prebuilt .so, on the GPU box)
+
+Nothing in compv_amd/ imports this module.
+"""
+import ctypes as C
+import hashlib
+import os
+import subprocess
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ORACLE_DIR = os.path.join(ROOT, "oracle")
+
+
+def synth_frame(W, H, seed=12345):
+    """SURVEY.md 8(d) synthetic frame, vectorised (LCG jump-ahead by doubling). Bit-identical to
+    orc_synth_frame() in oracle/compv_oracle.c (checked by tests/test_oracle.py)."""
+    n = W * H
+    M = np.uint64(0xFFFFFFFF)
+    a = np.uint64(1664525)
+    c = np.uint64(1013904223)
+    ap = np.array([1], dtype=np.uint64)  # a^k
+    cp = np.array([0], dtype=np.uint64)  # c_k with s_k = a^k s_0 + c_k
+    while len(ap) <= n:
+        aL = (ap[-1] * a) & M
+        cL = (cp[-1] * a + c) & M
+        ap, cp = np.concatenate([ap, (ap * aL) & M]), np.concatenate([cp, (ap * cL + cp) & M])
+    s = ((ap[1:n + 1] * np.uint64(seed & 0xFFFFFFFF)) + cp[1:n + 1]) & M
+    s = s.astype(np.uint32).reshape(H, W)
+    i = np.arange(W, dtype=np.int64)[None, :]
+    j = np.arange(H, dtype=np.int64)[:, None]
+    v = 40 + (((i // 64 + j // 64) & 1) * 150) + (s >> 28).astype(np.int64)
+    v = np.where(((i + 2 * j) % 257) < 3, 255, v)
+    return v.astype(np.uint8)
+
+
+def md5_rows(a):
+    """MD5 over the valid bytes of each row (the reference's compv_tests_md5 convention,
+    tests/tests_common.cxx:98-117)."""
+    return hashlib.md5(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class OrcLine(C.Structure):
+    _fields_ = [("rho", C.c_float), ("theta", C.c_float), ("strength", C.c_int64), ("row", C.c_int32), ("col", C.c_int32)]
+
+
+class RefLine(C.Structure):
+    _fields_ = [("rho", C.c_float), ("theta", C.c_float), ("strength", C.c_longlong)]
+
+
+def build_oracle():
+    src = os.path.join(ORACLE_DIR, "compv_oracle.c")
+    out = os.path.join(ORACLE_DIR, "liboracle.so")
+    if (not os.path.exists(out)) or os.path.getmtime(out) < os.path.getmtime(src) \
+            or os.path.getmtime(out) < os.path.getmtime(os.path.join(ORACLE_DIR, "compv_oracle.h")):
+        subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-std=c11", "-o", out, src, "-lm"])
+    return out
+
+
+class Oracle:
+    def __init__(self):
+        self.lib = C.CDLL(build_oracle())
+        L = self.lib
+        sz = C.c_size_t
+        L.orc_synth_frame.argtypes = [C.c_void_p, sz, sz, sz, C.c_uint32]
+        L.orc_synth_frame.restype = None
+        L.orc_convlt1_8u16s16s.argtypes = [C.c_void_p, sz, sz, sz, C.c_void_p, C.c_void_p, sz, C.c_void_p]
+        L.orc_convlt1_16s16s16s.argtypes = [C.c_void_p, sz, sz, sz, C.c_void_p, C.c_void_p, sz, C.c_void_p]
+        L.orc_gradient.argtypes = [C.c_void_p, sz, sz, sz, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_edge_dete.argtypes = [C.c_void_p, sz, sz, sz, C.c_int, C.c_void_p, sz, C.c_void_p]
+        L.orc_canny_thresholds.argtypes = [C.c_float, C.c_float, C.c_int, C.c_uint32, sz, sz, C.c_void_p, C.c_void_p]
+        L.orc_canny_coverage.argtypes = [sz, C.c_void_p, C.c_void_p]
+        L.orc_canny_coverage.restype = None
+        L.orc_canny.argtypes = [C.c_void_p, sz, sz, sz, C.c_float, C.c_float, C.c_int, C.c_int, C.c_void_p, sz, C.c_void_p]
+        L.orc_sht_dims.argtypes = [sz, sz, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.orc_sht_tables.argtypes = [C.c_float, sz, C.c_void_p, C.c_void_p]
+        L.orc_sht_acc.argtypes = [C.c_void_p, sz, sz, sz, C.c_void_p, C.c_void_p, sz, C.c_void_p, sz]
+        L.orc_sht_lines.argtypes = [C.c_void_p, sz, sz, sz, C.c_int32, C.c_int32, C.c_float, C.c_int, C.c_void_p, sz, C.c_void_p]
+        L.orc_sht.argtypes = [C.c_void_p, sz, sz, sz, C.c_float, C.c_int32, C.c_int, C.c_void_p, sz, C.c_void_p]
+
+    def synth(self, W, H, seed=12345):
+        out = np.zeros((H, W), np.uint8)
+        self.lib.orc_synth_frame(_p(out), W, H, W, seed)
+        return out
+
+    def convlt_8u(self, img, vt, hz):
+        H, W = img.shape
+        vt = np.ascontiguousarray(vt, np.int16); hz = np.ascontiguousarray(hz, np.int16)
+        out = np.zeros((H, img.strides[0]), np.int16)
+        r = self.lib.orc_convlt1_8u16s16s(_p(img), W, H, img.strides[0], _p(vt), _p(hz), len(vt), _p(out))
+        return r, out[:, :W]
+
+    def convlt_16s(self, img, vt, hz):
+        H, W = img.shape
+        vt = np.ascontiguousarray(vt, np.int16); hz = np.ascontiguousarray(hz, np.int16)
+        out = np.zeros((H, img.strides[0] // 2), np.int16)
+        r = self.lib.orc_convlt1_16s16s16s(_p(img), W, H, img.strides[0] // 2, _p(vt), _p(hz), len(vt), _p(out))
+        return r, out[:, :W]
+
+    def gradient(self, img, op=0):
+        H, W = img.shape
+        S = img.strides[0]
+        gx = np.zeros((H, S), np.int16); gy = np.zeros((H, S), np.int16); g = np.zeros((H, S), np.uint16)
+        r = self.lib.orc_gradient(_p(img), W, H, S, op, _p(gx), _p(gy), _p(g))
+        assert r == 0, r
+        return gx[:, :W], gy[:, :W], g[:, :W]
+
+    def edge_dete(self, img, op=0):
+        H, W = img.shape
+        out = np.zeros((H, W), np.uint8)
+        gmax = C.c_uint16(0)
+        r = self.lib.orc_edge_dete(_p(img), W, H, img.strides[0], op, _p(out), W, C.byref(gmax))
+        assert r == 0, r
+        return out, gmax.value
+
+    def canny_thresholds(self, fLow, fHigh, typ=0, total=0, W=1, H=1):
+        lo = C.c_uint16(0); hi = C.c_uint16(0)
+        r = self.lib.orc_canny_thresholds(fLow, fHigh, typ, total, W, H, C.byref(lo), C.byref(hi))
+        return r, lo.value, hi.value
+
+    def canny_coverage(self, W):
+        a = C.c_size_t(0); b = C.c_size_t(0)
+        self.lib.orc_canny_coverage(W, C.byref(a), C.byref(b))
+        return a.value, b.value
+
+    def canny(self, img, fLow, fHigh, ksize=3, typ=0, want_gnms=False):
+        H, W = img.shape
+        out = np.zeros((H, W), np.uint8)
+        gn = np.zeros((H, img.strides[0]), np.uint16) if want_gnms else None
+        r = self.lib.orc_canny(_p(img), W, H, img.strides[0], fLow, fHigh, ksize, typ, _p(out), W, _p(gn) if want_gnms else None)
+        if want_gnms:
+            return r, out, gn[:, :W]
+        return r, out
+
+    def sht_dims(self, W, H, theta_deg=1.0):
+        R = C.c_size_t(0); T = C.c_size_t(0); th = C.c_float(0)
+        r = self.lib.orc_sht_dims(W, H, theta_deg, C.byref(R), C.byref(T), C.byref(th))
+        assert r == 0
+        return R.value, T.value, th.value
+
+    def sht_tables(self, theta_deg, T):
+        s = np.zeros(T, np.int32); c = np.zeros(T, np.int32)
+        self.lib.orc_sht_tables(theta_deg, T, _p(s), _p(c))
+        return s, c
+
+    def sht_acc(self, edges, theta_deg=1.0):
+        H, W = edges.shape
+        R, T, _ = self.sht_dims(W, H, theta_deg)
+        s, c = self.sht_tables(theta_deg, T)
+        acc = np.zeros((R, T), np.int32)
+        self.lib.orc_sht_acc(_p(edges), W, H, edges.strides[0], _p(s), _p(c), T, _p(acc), T)
+        return acc
+
+    def sht_lines_from_acc(self, acc, W, H, theta_deg, threshold, max_lines=0):
+        R, T = acc.shape
+        _, _, th = self.sht_dims(W, H, theta_deg)
+        cap = max(1, int((acc > threshold).sum()))
+        buf = (OrcLine * cap)()
+        n = C.c_size_t(0)
+        r = self.lib.orc_sht_lines(_p(acc), R, T, acc.strides[0] // 4, threshold, W + H, th, max_lines, buf, cap, C.byref(n))
+        assert r == 0, r
+        return [(buf[i].rho, buf[i].theta, buf[i].strength, buf[i].row, buf[i].col) for i in range(min(n.value, cap))]
+
+    def sht(self, edges, theta_deg=1.0, threshold=100, max_lines=0):
+        acc = self.sht_acc(edges, theta_deg)
+        H, W = edges.shape
+        return self.sht_lines_from_acc(acc, W, H, theta_deg, threshold, max_lines)
+
+
+def refshim_path():
+    return os.path.join(ORACLE_DIR, "_ref", "libcompv_refshim.so")
+
+
+def have_refshim():
+    return os.path.exists(refshim_path())
+
+
+class RefShim:
+    """The real CompV CPU library (intrinsics path). threads: 1 or -1 (all cores)."""
+
+    def __init__(self, threads=1):
+        self.lib = C.CDLL(refshim_path())
+        L = self.lib
+        sz = C.c_size_t
+        L.refshim_init.argtypes = [C.c_int]
+        L.refshim_sobel.argtypes = [C.c_void_p, sz, sz, sz, C.c_void_p, sz]
+        L.refshim_canny.argtypes = [C.c_void_p, sz, sz, sz, C.c_float, C.c_float, C.c_int, C.c_int, C.c_void_p, sz]
+        L.refshim_sht.argtypes = [C.c_void_p, sz, sz, sz, C.c_float, sz, C.c_int, C.c_void_p, sz, C.c_void_p]
+        L.refshim_kht.argtypes = [C.c_void_p, sz, sz, sz, C.c_float, C.c_float, sz, C.c_int, C.c_void_p, sz, C.c_void_p, C.c_void_p]
+        L.refshim_sht_acc.argtypes = [C.c_void_p, sz, sz, sz, C.c_void_p, C.c_void_p, sz, C.c_void_p, sz]
+        L.refshim_convlt1_8u16s16s.argtypes = [C.c_void_p, sz, sz, sz, C.c_void_p, C.c_void_p, sz, C.c_void_p]
+        L.refshim_convlt1_16s16s16s.argtypes = [C.c_void_p, sz, sz, sz, C.c_void_p, C.c_void_p, sz, C.c_void_p]
+        L.refshim_bench_pipeline.argtypes = [C.c_void_p, sz, sz, sz, sz, C.c_float, C.c_float, C.c_float, sz, C.c_int, C.c_void_p, C.c_void_p]
+        L.refshim_bench_pipeline.restype = C.c_double
+        assert L.refshim_init(threads) == 0
+        self.threads = L.refshim_threads()
+        self.avx2 = bool(L.refshim_has_avx2())
+
+    def reinit(self, threads):
+        assert self.lib.refshim_init(threads) == 0
+        self.threads = self.lib.refshim_threads()
+
+    def sobel(self, img):
+        H, W = img.shape
+        out = np.zeros((H, W), np.uint8)
+        assert self.lib.refshim_sobel(_p(img), W, H, img.strides[0], _p(out), W) == 0
+        return out
+
+    def canny(self, img, fLow, fHigh, ksize=3, typ=0):
+        H, W = img.shape
+        out = np.zeros((H, W), np.uint8)
+        r = self.lib.refshim_canny(_p(img), W, H, img.strides[0], fLow, fHigh, ksize, typ, _p(out), W)
+        return r, out
+
+    def _lines(self, buf, n):
+        return [(buf[i].rho, buf[i].theta, buf[i].strength) for i in range(n)]
+
+    def sht(self, edges, theta_deg=1.0, threshold=100, max_lines=0, cap=1 << 20):
+        H, W = edges.shape
+        buf = (RefLine * cap)(); n = C.c_size_t(0)
+        r = self.lib.refshim_sht(_p(edges), W, H, edges.strides[0], theta_deg, threshold, max_lines, buf, cap, C.byref(n))
+        assert r == 0, r
+        assert n.value <= cap
+        return self._lines(buf, n.value)
+
+    def kht(self, edges, rho=1.0, theta_deg=1.0, threshold=1, max_lines=0, cap=1 << 18):
+        H, W = edges.shape
+        buf = (RefLine * cap)(); n = C.c_size_t(0); gs = C.c_double(0)
+        r = self.lib.refshim_kht(_p(edges), W, H, edges.strides[0], rho, theta_deg, threshold, max_lines, buf, cap, C.byref(n), C.byref(gs))
+        assert r == 0, r
+        return self._lines(buf, min(n.value, cap)), gs.value
+
+    def sht_acc(self, edges, sinQ, cosQ, R):
+        H, W = edges.shape
+        T = len(sinQ)
+        stride = (T + 15) & ~15
+        acc = np.zeros((R, stride), np.int32)
+        r = self.lib.refshim_sht_acc(_p(edges), W, H, edges.strides[0], _p(sinQ), _p(cosQ), T, _p(acc), stride)
+        assert r == 0, r
+        return acc[:, :T].copy()
+
+    def convlt_8u(self, img, vt, hz, S=None):
+        H, W = img.shape
+        vt = np.ascontiguousarray(vt, np.int16); hz = np.ascontiguousarray(hz, np.int16)
+        out = np.zeros((H, img.strides[0]), np.int16)
+        r = self.lib.refshim_convlt1_8u16s16s(_p(img), W, H, img.strides[0], _p(vt), _p(hz), len(vt), _p(out))
+        return r, out[:, :W]
+
+    def convlt_16s(self, img, vt, hz):
+        H, W = img.shape
+        vt = np.ascontiguousarray(vt, np.int16); hz = np.ascontiguousarray(hz, np.int16)
+        out = np.zeros((H, img.strides[0] // 2), np.int16)
+        r = self.lib.refshim_convlt1_16s16s16s(_p(img), W, H, img.strides[0] // 2, _p(vt), _p(hz), len(vt), _p(out))
+        return r, out[:, :W]
+
+    def bench_pipeline(self, frames, fLow, fHigh, theta_deg, threshold, stages=3):
+        n, H, W = frames.shape
+        e = C.c_longlong(0); l = C.c_longlong(0)
+        ms = self.lib.refshim_bench_pipeline(_p(frames), W, H, W, n, fLow, fHigh, theta_deg, threshold, stages, C.byref(e), C.byref(l))
+        return ms, e.value, l.value
