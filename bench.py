@@ -1,0 +1,193 @@
+#!/usr/bin/env python
+"""bench.py -- Mpixels/s of Sobel -> Canny -> HoughSHT on batches of synthetic 4K uint8 frames (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+One "step" = one pass of the whole hot path (compvhip_plan_pipeline: fused Sobel+NMS+tile hysteresis, cross-tile
+resolve, edge compaction, Hough voting, Hough NMS, line sort/decode) over a batch of FRAMES_PER_GPU frames that are
+already resident in HBM.  Frames are independent units: ranks process disjoint frame shards, no data-path collective
+(weak scaling: per-GPU batch fixed).  Timing: barrier + synchronize, K steps, synchronize + barrier, MAX over ranks.
+
+Extra objects on the JSON line:
+  roofline      dominant kernel (by measured time): algorithmic bytes / average launch duration, durations measured
+                with HIP events recorded by the library on the stream the kernels run on, during the timed steps
+  roofline_canny  the fused Sobel->Canny tile kernel on the same basis (north_star's 40 % target is quoted on it)
+  cpu_baseline  the REAL CompV CPU library (oracle/_ref, AVX2 intrinsics path, all host cores) -- or the C port --
+                timed on a bounded sample of the same workload on rank 0 at N=1
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+T_LOW, T_HIGH = 59.0, 119.0
+THETA_DEG, SHT_THRESHOLD = 1.0, 100
+
+
+def synth_batch(n, W, H, first_seed):
+    from oracle_bindings import synth_frame
+    return np.stack([synth_frame(W, H, first_seed + f) for f in range(n)])
+
+
+def cpu_baseline(W, H, budget_s=20.0):
+    """CompV's own CPU path (or the C port) on a bounded sample of the same workload."""
+    from oracle_bindings import Oracle, RefShim, have_refshim, synth_frame
+    cores = os.cpu_count() or 1
+    if have_refshim():
+        ref = RefShim(-1)   # all host cores (CompVBase::init(-1))
+        probe = synth_batch(1, W, H, 12345)
+        ms, _, _ = ref.bench_pipeline(probe, T_LOW, T_HIGH, THETA_DEG, SHT_THRESHOLD)
+        n = int(max(2, min(64, budget_s * 1000.0 / max(ms, 1e-3))))
+        frames = synth_batch(n, W, H, 12345)
+        ms, edges, lines = ref.bench_pipeline(frames, T_LOW, T_HIGH, THETA_DEG, SHT_THRESHOLD)
+        return {"value": round(n * W * H / (ms * 1e-3) / 1e6, 2), "unit": "Mpixels/s", "cores": ref.threads, "host_cpus": cores,
+                "kind": "reference",
+                "sample": "%d frames %dx%d, CompV AVX2 intrinsics path (COMPV_ASM=0), %d threads, Canny(59,119)+SHT(1deg,100)" % (n, W, H, ref.threads),
+                "ms_per_frame": round(ms / n, 3)}
+    orc = Oracle()
+    img = synth_frame(W, H, 12345)
+    t0 = time.time()
+    n = 0
+    while time.time() - t0 < budget_s or n < 1:
+        rc, e = orc.canny(img, T_LOW, T_HIGH)
+        orc.sht(e, THETA_DEG, SHT_THRESHOLD)
+        n += 1
+    dt = time.time() - t0
+    return {"value": round(n * W * H / dt / 1e6, 2), "unit": "Mpixels/s", "cores": 1, "host_cpus": cores, "kind": "port",
+            "sample": "%d frames %dx%d, scalar C restatement (oracle/compv_oracle.c)" % (n, W, H), "ms_per_frame": round(dt / n * 1e3, 3)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames-per-gpu", type=int, default=32)   # BASELINE config 4: 256 frames over 8 GPUs
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    from compv_amd import capi
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    dist_on = world > 1
+    if dist_on:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local_rank if dist_on else 0)
+
+    W, H, F = args.width, args.height, args.frames_per_gpu
+    # frame f of the global batch uses seed 12345+f; rank r owns frames [r*F, (r+1)*F)
+    frames = synth_batch(F, W, H, 12345 + rank * F)
+    d_in = torch.from_numpy(frames).to(dev)
+    d_edges = torch.empty_like(d_in)
+    line_cap = 1 << 16
+    d_lines = torch.zeros((F, line_cap, 5), dtype=torch.int32, device=dev)
+    d_counts = torch.zeros(F, dtype=torch.int32, device=dev)
+
+    ctx = capi.Context(local_rank if dist_on else 0)
+    plan = capi.Plan(ctx, W, H, W, F, THETA_DEG)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    def step():
+        plan.pipeline(d_in.data_ptr(), T_LOW, T_HIGH, SHT_THRESHOLD, 0, d_edges.data_ptr(), d_lines.data_ptr(), line_cap,
+                      d_counts.data_ptr(), stream)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+
+    plan.set_timing(True)       # HIP events around every kernel, on the launch stream, during the timed steps
+    per_kernel = {}
+    if dist_on:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+        # the pipeline call ends with a stream sync (hysteresis convergence check); collect this step's events
+        for name, ms in plan.get_timing():
+            a = per_kernel.setdefault(name, [0.0, 0])
+            a[0] += ms
+            a[1] += 1
+    torch.cuda.synchronize()
+    if dist_on:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist_on:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    plan.set_timing(False)
+
+    counts = d_counts.cpu().numpy()
+    total_px = world * F * W * H * args.steps
+    value = total_px / elapsed / 1e6
+
+    if rank == 0:
+        R = 2 * (W + H) + 1
+        T = 180
+        kern = {k: {"ms_per_launch": v[0] / v[1], "launches_per_step": v[1] / args.steps, "ms_per_step": v[0] / args.steps}
+                for k, v in per_kernel.items()}
+        dom = max(kern.items(), key=lambda kv: kv[1]["ms_per_step"])[0] if kern else None
+        # algorithmic bytes per frame: Sobel->Canny 1 B/px read (+1 B/px write reported separately);
+        # SHT: W*H edge read + R*T*4 accumulator written once
+        alg = {
+            "canny_tile_kernel": F * W * H * 1.0,
+            "sht_vote_kernel": F * (W * H + R * T * 4.0),
+        }
+
+        def roof(name, nbytes):
+            if name not in kern:
+                return None
+            ms = kern[name]["ms_per_launch"]
+            ach = nbytes / (ms * 1e-3) / 1e9
+            return {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "ms_per_launch": round(ms, 4),
+                    "algorithmic_bytes_per_launch": int(nbytes)}
+        roofline = roof(dom, alg.get(dom, F * W * H * 1.0)) if dom else None
+        rc = roof("canny_tile_kernel", alg["canny_tile_kernel"])
+        if rc:
+            rc["frac_read_plus_write"] = round(2 * rc["frac"], 4)
+        out = {
+            "metric": "Mpixels/s Sobel->Canny->HoughSHT on 4K uint8",
+            "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "config": {"workload": "batched %dx%d uint8 frames, Sobel3x3 -> Canny(59,119) -> HoughSHT(rho=1, theta=1deg, thr=100)" % (W, H),
+                       "frames_per_gpu": F, "global_frames": world * F,
+                       "parallelism": "frames sharded across %d GPU(s), no data-path collective" % world},
+            "roofline": roofline, "roofline_canny": rc,
+            "kernels_ms_per_step": {k: round(v["ms_per_step"], 4) for k, v in sorted(kern.items())},
+            "lines_frame0": int(counts[0]),
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(W, H)
+            except Exception as e:  # the baseline is reporting only; never let it hide the GPU number
+                out["cpu_baseline"] = {"error": str(e)}
+        print(json.dumps(out))
+    plan.close()
+    ctx.close()
+    if dist_on:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

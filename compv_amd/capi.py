@@ -1,0 +1,214 @@
+"""ctypes binding of the C ABI in include/compv_hip.h (compv_amd/lib/libcompv_hip.so).
+
+This is plumbing for tests and bench.py: the product is the shared library itself, which a CompV build binds
+directly from C++.  There is NO CPU fallback: importing works without a GPU (so that the
+symbol-export test can run), but creating a context without a GPU, or loading without the built library, fails loudly.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libcompv_hip.so")
+
+OK = 0
+E_NOT_IMPLEMENTED = -1
+E_NOT_INITIALIZED = -2
+E_INVALID_STATE = -3
+E_INVALID_PARAMETER = -4
+E_OUT_OF_MEMORY = -5
+E_OUT_OF_BOUND = -6
+E_HIP = -7
+
+OP_SOBEL, OP_SCHARR, OP_PREWITT = 0, 2, 3
+THRESHOLD_COMPARE_TO_GRADIENT, THRESHOLD_PERCENT_OF_MEAN = 0, 1
+
+# every symbol include/compv_hip.h declares (checked by tests/test_abi.py)
+EXPORTS = [
+    "compvhip_device_count", "compvhip_ctx_create", "compvhip_ctx_destroy", "compvhip_last_error",
+    "compvhip_live_allocations", "compvhip_edge_dete_u8", "compvhip_canny_u8", "compvhip_houghsht_u8",
+    "compvhip_houghsht_dims", "compvhip_plan_create", "compvhip_plan_destroy", "compvhip_plan_canny",
+    "compvhip_plan_houghsht", "compvhip_plan_pipeline", "compvhip_plan_acc", "compvhip_plan_edge_counts",
+    "compvhip_plan_set_timing", "compvhip_plan_get_timing",
+]
+
+
+class Line(C.Structure):
+    _fields_ = [("rho", C.c_float), ("theta", C.c_float), ("strength", C.c_int32), ("row", C.c_int32), ("col", C.c_int32)]
+
+
+LINE_DTYPE = np.dtype([("rho", "<f4"), ("theta", "<f4"), ("strength", "<i4"), ("row", "<i4"), ("col", "<i4")])
+
+
+class CompvHipError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("compvhip error %d: %s" % (code, msg))
+        self.code = code
+
+
+_lib = None
+
+
+def load():
+    """Load the HIP library; raises if it was not built (no silent fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError("compv_amd: %s is missing -- run `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(the HIP extension is mandatory; there is no CPU fallback)" % LIB_PATH)
+    L = C.CDLL(LIB_PATH)
+    sz, vp, i32 = C.c_size_t, C.c_void_p, C.c_int
+    L.compvhip_device_count.restype = i32
+    L.compvhip_ctx_create.argtypes = [C.POINTER(vp), i32]
+    L.compvhip_ctx_destroy.argtypes = [vp]
+    L.compvhip_ctx_destroy.restype = None
+    L.compvhip_last_error.argtypes = [vp]
+    L.compvhip_last_error.restype = C.c_char_p
+    L.compvhip_live_allocations.argtypes = [vp]
+    L.compvhip_live_allocations.restype = C.c_long
+    L.compvhip_edge_dete_u8.argtypes = [vp, vp, sz, sz, sz, i32, vp, sz]
+    L.compvhip_canny_u8.argtypes = [vp, vp, sz, sz, sz, C.c_float, C.c_float, i32, i32, vp, sz]
+    L.compvhip_houghsht_u8.argtypes = [vp, vp, sz, sz, sz, C.c_float, C.c_float, i32, i32, vp, sz, C.POINTER(sz), vp, sz]
+    L.compvhip_houghsht_dims.argtypes = [sz, sz, C.c_float, C.POINTER(sz), C.POINTER(sz), C.POINTER(C.c_float)]
+    L.compvhip_plan_create.argtypes = [vp, sz, sz, sz, sz, C.c_float, C.POINTER(vp)]
+    L.compvhip_plan_destroy.argtypes = [vp]
+    L.compvhip_plan_destroy.restype = None
+    L.compvhip_plan_canny.argtypes = [vp, vp, C.c_float, C.c_float, i32, i32, vp, vp]
+    L.compvhip_plan_houghsht.argtypes = [vp, vp, i32, i32, vp, sz, vp, vp]
+    L.compvhip_plan_pipeline.argtypes = [vp, vp, C.c_float, C.c_float, i32, i32, vp, vp, sz, vp, vp]
+    L.compvhip_plan_acc.argtypes = [vp, sz, C.POINTER(vp), C.POINTER(sz), C.POINTER(sz), C.POINTER(sz)]
+    L.compvhip_plan_edge_counts.argtypes = [vp, C.POINTER(vp)]
+    L.compvhip_plan_set_timing.argtypes = [vp, i32]
+    L.compvhip_plan_get_timing.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_float), i32]
+    _lib = L
+    return L
+
+
+def _ptr(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+class Context:
+    """One GPU context (compvhip_ctx)."""
+
+    def __init__(self, device=-1):
+        self.lib = load()
+        h = C.c_void_p()
+        rc = self.lib.compvhip_ctx_create(C.byref(h), device)
+        if rc != OK:
+            raise CompvHipError(rc, "compvhip_ctx_create failed (no usable GPU? the HIP path is mandatory)")
+        self.h = h
+
+    def close(self):
+        if self.h:
+            self.lib.compvhip_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def last_error(self):
+        return self.lib.compvhip_last_error(self.h).decode()
+
+    def live_allocations(self):
+        return self.lib.compvhip_live_allocations(self.h)
+
+    def _chk(self, rc):
+        if rc != OK:
+            raise CompvHipError(rc, self.last_error())
+
+    # ---- host entry points (numpy in / numpy out) ----
+    def edge_dete(self, img, op=OP_SOBEL):
+        H, W = img.shape
+        out = np.empty((H, W), np.uint8)
+        self._chk(self.lib.compvhip_edge_dete_u8(self.h, _ptr(img), W, H, img.strides[0], op, _ptr(out), W))
+        return out
+
+    def canny(self, img, tLow, tHigh, ksize=3, threshold_type=THRESHOLD_COMPARE_TO_GRADIENT, out=None):
+        H, W = img.shape
+        if out is None:
+            out = np.empty((H, W), np.uint8)
+        self._chk(self.lib.compvhip_canny_u8(self.h, _ptr(img), W, H, img.strides[0], tLow, tHigh, ksize, threshold_type,
+                                             _ptr(out), out.strides[0]))
+        return out
+
+    def houghsht_dims(self, W, H, theta_deg=1.0):
+        R, T, st = C.c_size_t(), C.c_size_t(), C.c_float()
+        rc = self.lib.compvhip_houghsht_dims(W, H, theta_deg, C.byref(R), C.byref(T), C.byref(st))
+        self._chk(rc)
+        return R.value, T.value, st.value
+
+    def houghsht(self, edges, theta_deg=1.0, threshold=100, max_lines=0, rho=1.0, cap=1 << 16, want_acc=False):
+        H, W = edges.shape
+        lines = np.zeros(cap, LINE_DTYPE)
+        n = C.c_size_t(0)
+        acc = None
+        accp, accs = None, 0
+        if want_acc:
+            R, T, _ = self.houghsht_dims(W, H, theta_deg)
+            acc = np.zeros((R, T), np.int32)
+            accp, accs = _ptr(acc), T
+        rc = self.lib.compvhip_houghsht_u8(self.h, _ptr(edges), W, H, edges.strides[0], rho, theta_deg, threshold, max_lines,
+                                           _ptr(lines), cap, C.byref(n), accp, accs)
+        if rc == E_OUT_OF_BOUND and n.value > cap:
+            return self.houghsht(edges, theta_deg, threshold, max_lines, rho, cap=n.value, want_acc=want_acc)
+        self._chk(rc)
+        lines = lines[:n.value]
+        return (lines, acc) if want_acc else lines
+
+
+class Plan:
+    """Batched device-resident pipeline (compvhip_plan). Pointers are raw device addresses (e.g. torch .data_ptr())."""
+
+    def __init__(self, ctx, W, H, S, frames, theta_deg=1.0):
+        self.ctx = ctx
+        self.lib = ctx.lib
+        h = C.c_void_p()
+        ctx._chk(self.lib.compvhip_plan_create(ctx.h, W, H, S, frames, theta_deg, C.byref(h)))
+        self.h = h
+        self.W, self.H, self.S, self.frames = W, H, S, frames
+
+    def close(self):
+        if self.h:
+            self.lib.compvhip_plan_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def canny(self, d_in, tLow, tHigh, d_edges, ksize=3, threshold_type=THRESHOLD_COMPARE_TO_GRADIENT, stream=0):
+        self.ctx._chk(self.lib.compvhip_plan_canny(self.h, d_in, tLow, tHigh, ksize, threshold_type, d_edges, stream))
+
+    def houghsht(self, d_edges, threshold, max_lines, d_lines, line_cap, d_counts, stream=0):
+        self.ctx._chk(self.lib.compvhip_plan_houghsht(self.h, d_edges, threshold, max_lines, d_lines, line_cap, d_counts, stream))
+
+    def pipeline(self, d_in, tLow, tHigh, threshold, max_lines, d_edges, d_lines, line_cap, d_counts, stream=0):
+        self.ctx._chk(self.lib.compvhip_plan_pipeline(self.h, d_in, tLow, tHigh, threshold, max_lines, d_edges, d_lines, line_cap,
+                                                      d_counts, stream))
+
+    def acc(self, frame):
+        p, R, T, pitch = C.c_void_p(), C.c_size_t(), C.c_size_t(), C.c_size_t()
+        self.ctx._chk(self.lib.compvhip_plan_acc(self.h, frame, C.byref(p), C.byref(R), C.byref(T), C.byref(pitch)))
+        return p.value, R.value, T.value, pitch.value
+
+    def edge_counts_ptr(self):
+        p = C.c_void_p()
+        self.ctx._chk(self.lib.compvhip_plan_edge_counts(self.h, C.byref(p)))
+        return p.value
+
+    def set_timing(self, on=True):
+        self.ctx._chk(self.lib.compvhip_plan_set_timing(self.h, 1 if on else 0))
+
+    def get_timing(self, cap=256):
+        names = (C.c_char_p * cap)()
+        ms = (C.c_float * cap)()
+        n = self.lib.compvhip_plan_get_timing(self.h, names, ms, cap)
+        return [(names[i].decode(), ms[i]) for i in range(max(n, 0))]

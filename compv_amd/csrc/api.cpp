@@ -1,0 +1,685 @@
+// api.cpp -- host side of the C ABI declared in include/compv_hip.h (compiled with hipcc, no torch types).
+//
+// Host-pointer entry points mirror the reference's process() contract (synchronous, results in host memory):
+//   compvhip_canny_u8     <- CompVEdgeDeteCanny::process   core/features/edges/compv_core_feature_canny_dete.cxx:123-331
+//   compvhip_edge_dete_u8 <- CompVCornerDeteEdgeBase::process core/features/edges/compv_core_feature_edge_dete.cxx:55-206
+//   compvhip_houghsht_u8  <- CompVHoughSht::process        core/features/hough/compv_core_feature_houghsht.cxx:96-262
+// Device-pointer ("plan") entry points run the same kernels on batches of frames resident in HBM.
+#include "../../include/compv_hip.h"
+#include "kernels.hpp"
+
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+using namespace compvhip;
+
+namespace {
+constexpr int kMaxRounds = 4096;       // hysteresis resolve rounds before giving up (one per 64-row band crossed)
+constexpr int kSpecRounds = 3;         // rounds enqueued speculatively between two convergence checks
+constexpr size_t kDefaultLineCap = 1u << 18;
+} // namespace
+
+struct compvhip_ctx {
+	int device = 0;
+	std::string err;
+	long live = 0;
+	hipStream_t stream = nullptr;      // stream of the host entry points
+	compvhip_plan* hostPlan = nullptr; // single-frame plan cached for the host entry points
+	uint8_t* dIn = nullptr;            // device staging of the host entry points
+	uint8_t* dOut = nullptr;
+	size_t dInBytes = 0, dOutBytes = 0;
+	compvhip_line* dLines = nullptr; size_t dLinesCap = 0;
+	int32_t* dCounts = nullptr;
+	int32_t* dAccOut = nullptr; size_t dAccOutElems = 0;
+};
+
+struct TimingEntry { const char* name; hipEvent_t a, b; };
+
+struct compvhip_plan {
+	compvhip_ctx* ctx = nullptr;
+	size_t W = 0, H = 0, S = 0, frames = 0;
+	float thetaDeg = 1.f;
+	// canny
+	int tilesX = 0, tilesY = 0, wb = 0;
+	size_t bitsFrameStride = 0;
+	uint32_t* ebits = nullptr; uint32_t* ubits = nullptr;
+	int* flags = nullptr; int* hFlags = nullptr; // device / pinned host
+	int roundsUsed = 0;
+	int2* thrDev = nullptr; unsigned int* sums = nullptr;
+	uint8_t* tmpOut = nullptr; // aliasing (in == out) scratch
+	bool bitsValid = false;
+	// sht
+	bool shtReady = false;
+	size_t R = 0, T = 0; float thetaStep = 0.f; int accPitch = 0;
+	int32_t* sinQ = nullptr; int32_t* cosQ = nullptr;
+	uint32_t* edges = nullptr; size_t edgeCap = 0; int* edgeCounts = nullptr;
+	int32_t* acc = nullptr; size_t accFrameStride = 0;
+	uint64_t* keysA = nullptr; uint64_t* keysB = nullptr; size_t lineCap = 0; int* lineCounts = nullptr;
+	unsigned int* segBeg = nullptr; unsigned int* segEnd = nullptr;
+	void* sortTemp = nullptr; size_t sortTempBytes = 0;
+	int shards = 1;
+	// timing
+	bool timing = false;
+	std::vector<TimingEntry> timeline;
+	std::vector<std::string> timingNames; std::vector<float> timingMs;
+};
+
+namespace {
+
+int fail(compvhip_ctx* ctx, int code, const char* what, hipError_t e = hipSuccess)
+{
+	if (ctx) {
+		ctx->err = what ? what : "";
+		if (e != hipSuccess) { ctx->err += ": "; ctx->err += hipGetErrorString(e); }
+	}
+	return code;
+}
+
+#define HIPCHK(ctx, call) do { hipError_t e__ = (call); if (e__ != hipSuccess) return fail((ctx), COMPVHIP_E_HIP, #call, e__); } while (0)
+
+template <typename T>
+hipError_t dmalloc(compvhip_ctx* ctx, T** p, size_t count)
+{
+	*p = nullptr;
+	if (!count) return hipSuccess;
+	hipError_t e = hipMalloc(reinterpret_cast<void**>(p), count * sizeof(T));
+	if (e == hipSuccess && ctx) ctx->live++;
+	return e;
+}
+template <typename T>
+void dfree(compvhip_ctx* ctx, T*& p)
+{
+	if (p) { (void)hipFree(p); if (ctx) ctx->live--; p = nullptr; }
+}
+
+size_t alignUp(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+// ---- thresholds: core/features/edges/compv_core_feature_canny_dete.cxx:251-266 (COMPARE_TO_GRADIENT branch) ----
+void gradientThresholds(float fLow, float fHigh, int* tLow, int* tHigh)
+{
+	const float l = fLow < 1.f ? 1.f : (fLow > 65535.f ? 65535.f : fLow);
+	const float h = fHigh < 1.f ? 1.f : (fHigh > 65535.f ? 65535.f : fHigh);
+	uint16_t lo = static_cast<uint16_t>(l), hi = static_cast<uint16_t>(h);
+	lo = static_cast<uint16_t>(std::max<int>(1, lo));
+	hi = static_cast<uint16_t>(std::max<int>(lo + 2, hi));
+	*tLow = lo; *tHigh = hi;
+}
+
+// ---- column coverage of the reference's SIMD + scalar-remainder dispatch (quirk Q3) ----
+// ...canny_dete.cxx:362-412 (nms_gather) and :483-527 (hysteresis): the row leaves cover col = 1, 1+mpw, ... while
+// col < (W-1)-(mpw-1); the scalar remainder restarts at (W-1) & -(mpw-1).
+void cannyCoverage(size_t W, int* simdEnd, int* cStart)
+{
+	const size_t maxCols = W - 1;
+	size_t mpw = 1;
+	if (maxCols >= 16) mpw = 16; else if (maxCols >= 8) mpw = 8;
+	if (mpw == 1) { *simdEnd = 1; *cStart = 1; return; }
+	size_t col = 1;
+	while (col + (mpw - 1) < maxCols) col += mpw;
+	*simdEnd = static_cast<int>(col);
+	*cStart = static_cast<int>(maxCols & static_cast<size_t>(-static_cast<ptrdiff_t>(mpw - 1)));
+}
+
+// ---- SHT geometry/tables: core/features/hough/compv_core_feature_houghsht.cxx:42-52,318-348 ----
+const float kPiF = 3.1415926535897932384626433f;   // kfMathTrigPi (base/math/compv_math.cxx:27)
+float piOver180() { return kPiF / 180.f; }         // kfMathTrigPiOver180 (:30)
+
+int shtDims(size_t W, size_t H, float thetaDeg, size_t* R, size_t* T, float* step)
+{
+	if (!W || !H || !(thetaDeg > 0.f)) return COMPVHIP_E_INVALID_PARAMETER;
+	const float fTheta = thetaDeg * piOver180();
+	const float fRho = 1.f;
+	*R = static_cast<size_t>((static_cast<float>(((W + H) << 1) + 1) / fRho) + 0.5);
+	*T = static_cast<size_t>((kPiF / fTheta) + 0.5);
+	if (step) *step = fTheta;
+	return COMPVHIP_OK;
+}
+
+void shtTables(float thetaDeg, size_t T, std::vector<int32_t>& sinQ, std::vector<int32_t>& cosQ)
+{
+	// float32 running angle and libm sinf/cosf on the HOST, exactly as initCoords (:335-339); never device sinf.
+	const float fTheta = thetaDeg * piOver180();
+	const float fRho = 1.f;
+	sinQ.resize(T); cosQ.resize(T);
+	float tt = 0.f;
+	for (size_t t = 0; t < T; ++t, tt += fTheta) {
+		sinQ[t] = static_cast<int32_t>((std::sin(tt) * fRho) * 65535.f);
+		cosQ[t] = static_cast<int32_t>((std::cos(tt) * fRho) * 65535.f);
+	}
+}
+
+struct Stamp {
+	compvhip_plan* p; hipStream_t s; size_t idx; bool on;
+	Stamp(compvhip_plan* plan, hipStream_t stream, const char* name) : p(plan), s(stream), idx(0), on(plan->timing)
+	{
+		if (!on) return;
+		TimingEntry t; t.name = name;
+		if (hipEventCreate(&t.a) != hipSuccess || hipEventCreate(&t.b) != hipSuccess) { on = false; return; }
+		(void)hipEventRecord(t.a, s);
+		p->timeline.push_back(t);
+		idx = p->timeline.size() - 1;
+	}
+	~Stamp() { if (on) (void)hipEventRecord(p->timeline[idx].b, s); }
+};
+
+void timelineClear(compvhip_plan* p)
+{
+	for (auto& t : p->timeline) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
+	p->timeline.clear();
+}
+
+void timelineCollect(compvhip_plan* p)
+{
+	p->timingNames.clear(); p->timingMs.clear();
+	for (auto& t : p->timeline) {
+		float ms = 0.f;
+		if (hipEventElapsedTime(&ms, t.a, t.b) != hipSuccess) ms = -1.f;
+		p->timingNames.push_back(t.name); p->timingMs.push_back(ms);
+	}
+	timelineClear(p);
+}
+
+int ensureSht(compvhip_plan* p)
+{
+	if (p->shtReady) return COMPVHIP_OK;
+	compvhip_ctx* ctx = p->ctx;
+	size_t R, T; float step;
+	int rc = shtDims(p->W, p->H, p->thetaDeg, &R, &T, &step);
+	if (rc) return fail(ctx, rc, "invalid SHT geometry");
+	if (T < 5) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "theta step too large (fewer than 5 theta bins)");
+	if (p->W + p->H >= 65536) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "W+H must be < 65536 (u16 LDS vote counters)");
+	if (sht_vote_lds_bytes(static_cast<int>(R)) > 160 * 1024) return fail(ctx, COMPVHIP_E_NOT_IMPLEMENTED, "rho range does not fit the LDS histogram");
+	p->R = R; p->T = T; p->thetaStep = step;
+	p->accPitch = static_cast<int>(alignUp(R, 64));
+	p->accFrameStride = static_cast<size_t>(p->accPitch) * T;
+	std::vector<int32_t> s, c;
+	shtTables(p->thetaDeg, T, s, c);
+	HIPCHK(ctx, dmalloc(ctx, &p->sinQ, T));
+	HIPCHK(ctx, dmalloc(ctx, &p->cosQ, T));
+	HIPCHK(ctx, hipMemcpy(p->sinQ, s.data(), T * sizeof(int32_t), hipMemcpyHostToDevice));
+	HIPCHK(ctx, hipMemcpy(p->cosQ, c.data(), T * sizeof(int32_t), hipMemcpyHostToDevice));
+	p->edgeCap = p->W * p->H;
+	HIPCHK(ctx, dmalloc(ctx, &p->edges, p->edgeCap * p->frames));
+	HIPCHK(ctx, dmalloc(ctx, &p->edgeCounts, p->frames));
+	HIPCHK(ctx, hipMemset(p->edgeCounts, 0, sizeof(int) * p->frames));
+	HIPCHK(ctx, dmalloc(ctx, &p->acc, p->accFrameStride * p->frames));
+	HIPCHK(ctx, dmalloc(ctx, &p->lineCounts, p->frames));
+	HIPCHK(ctx, dmalloc(ctx, &p->segBeg, p->frames));
+	HIPCHK(ctx, dmalloc(ctx, &p->segEnd, p->frames));
+	p->shtReady = true;
+	return COMPVHIP_OK;
+}
+
+int ensureLineCap(compvhip_plan* p, size_t cap)
+{
+	compvhip_ctx* ctx = p->ctx;
+	cap = std::min(cap, p->R * p->T);
+	if (cap <= p->lineCap) return COMPVHIP_OK;
+	dfree(ctx, p->keysA); dfree(ctx, p->keysB); dfree(ctx, p->sortTemp);
+	p->lineCap = 0;
+	HIPCHK(ctx, dmalloc(ctx, &p->keysA, cap * p->frames));
+	HIPCHK(ctx, dmalloc(ctx, &p->keysB, cap * p->frames));
+	size_t tb = 0;
+	hipError_t e = sht_sort_keys(nullptr, tb, p->keysA, p->keysB, cap, static_cast<int>(p->frames), p->lineCounts, p->segBeg, p->segEnd, nullptr);
+	if (e != hipSuccess) return fail(ctx, COMPVHIP_E_HIP, "segmented sort size query", e);
+	p->sortTempBytes = tb;
+	uint8_t* tmp = nullptr;
+	HIPCHK(ctx, dmalloc(ctx, &tmp, std::max<size_t>(tb, 16)));
+	p->sortTemp = tmp;
+	p->lineCap = cap;
+	return COMPVHIP_OK;
+}
+
+ShtArgs shtArgs(compvhip_plan* p, int threshold)
+{
+	ShtArgs a;
+	a.ebits = p->ebits; a.edges = p->edges; a.edgeCounts = p->edgeCounts; a.acc = p->acc;
+	a.sinQ = p->sinQ; a.cosQ = p->cosQ; a.lineKeys = p->keysA; a.lineCounts = p->lineCounts;
+	a.bitsFrameStride = p->bitsFrameStride; a.edgeCap = p->edgeCap; a.accFrameStride = p->accFrameStride; a.lineCap = p->lineCap;
+	a.W = static_cast<int>(p->W); a.H = static_cast<int>(p->H); a.wb = p->wb;
+	a.R = static_cast<int>(p->R); a.T = static_cast<int>(p->T); a.accPitch = p->accPitch; a.barrier = static_cast<int>(p->W + p->H);
+	a.threshold = threshold;
+	a.nmsLastCol = static_cast<int>((p->T - 1) & ~static_cast<size_t>(3)); // quirk Q2: NMS covers theta columns [1, (T-1)&~3]
+	a.shards = p->shards;
+	return a;
+}
+
+// Enqueue canny tiles + `rounds` speculative resolve rounds starting at p->roundsUsed.
+int enqueueCanny(compvhip_plan* p, const uint8_t* d_in, uint8_t* d_out, int tLow, int tHigh, bool meanMode, float fLow, float fHigh, hipStream_t st)
+{
+	compvhip_ctx* ctx = p->ctx;
+	CannyArgs a;
+	a.in = d_in; a.out = d_out; a.ebits = p->ebits; a.ubits = p->ubits; a.thrDev = meanMode ? p->thrDev : nullptr;
+	a.inFrameStride = p->S * p->H; a.outFrameStride = p->S * p->H; a.bitsFrameStride = p->bitsFrameStride;
+	a.W = static_cast<int>(p->W); a.H = static_cast<int>(p->H); a.S = static_cast<int>(p->S); a.So = static_cast<int>(p->S);
+	a.wb = p->wb; a.tilesX = p->tilesX; a.tilesY = p->tilesY; a.tLow = tLow; a.tHigh = tHigh;
+	cannyCoverage(p->W, &a.simdEnd, &a.cStart);
+	// coverage [1,simdEnd) U [cStart,W-1) equals the whole interior unless the two pieces leave a hole (W = 1 mod 16 ...)
+	const bool gap = !((a.simdEnd >= a.W - 1) || (a.cStart <= a.simdEnd));
+	if (meanMode) {
+		Stamp s(p, st, "canny_mean_thresholds");
+		HIPCHK(ctx, launch_mean_thresholds(d_in, a.W, a.H, a.S, a.inFrameStride, static_cast<int>(p->frames), fLow, fHigh, p->sums, p->thrDev, st));
+	}
+	HIPCHK(ctx, hipMemsetAsync(p->flags, 0, sizeof(int) * kMaxRounds, st));
+	p->roundsUsed = 0;
+	{
+		Stamp s(p, st, "canny_tile_kernel");
+		HIPCHK(ctx, launch_canny_tiles(a, static_cast<int>(p->frames), gap, st));
+	}
+	return COMPVHIP_OK;
+}
+
+int enqueueResolve(compvhip_plan* p, uint8_t* d_out, int rounds, hipStream_t st)
+{
+	compvhip_ctx* ctx = p->ctx;
+	ResolveArgs r;
+	r.ebits = p->ebits; r.ubits = p->ubits; r.out = d_out; r.flags = p->flags;
+	r.outFrameStride = p->S * p->H; r.bitsFrameStride = p->bitsFrameStride;
+	r.H = static_cast<int>(p->H); r.So = static_cast<int>(p->S); r.wb = p->wb;
+	for (int i = 0; i < rounds; ++i) {
+		if (p->roundsUsed >= kMaxRounds) return fail(ctx, COMPVHIP_E_INVALID_STATE, "hysteresis did not converge");
+		r.round = p->roundsUsed++;
+		Stamp s(p, st, "canny_resolve_kernel");
+		HIPCHK(ctx, launch_canny_resolve(r, static_cast<int>(p->frames), st));
+	}
+	return COMPVHIP_OK;
+}
+
+// true when the last enqueued round changed nothing (fixed point reached). Synchronises the stream.
+int resolveConverged(compvhip_plan* p, hipStream_t st, bool* done)
+{
+	compvhip_ctx* ctx = p->ctx;
+	const int last = p->roundsUsed - 1;
+	HIPCHK(ctx, hipMemcpyAsync(p->hFlags, p->flags + last, sizeof(int), hipMemcpyDeviceToHost, st));
+	HIPCHK(ctx, hipStreamSynchronize(st));
+	*done = (p->hFlags[0] == 0);
+	return COMPVHIP_OK;
+}
+
+int validateCannyParams(compvhip_ctx* ctx, float tLow, float tHigh, int ksize, int type, int* lo, int* hi)
+{
+	if (ksize != 3 && ksize != 5) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "kernel size must be 3 or 5"); // canny_dete.cxx:101
+	if (type != COMPVHIP_CANNY_THRESHOLD_COMPARE_TO_GRADIENT && type != COMPVHIP_CANNY_THRESHOLD_PERCENT_OF_MEAN)
+		return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "invalid threshold type"); // :83
+	if (tLow >= tHigh) return fail(ctx, COMPVHIP_E_INVALID_STATE, "tLow >= tHigh"); // :126
+	if (ksize == 5) return fail(ctx, COMPVHIP_E_NOT_IMPLEMENTED, "5x5 Sobel in Canny: next scope row (SURVEY 8f-3)");
+	*lo = 0; *hi = 0;
+	if (type == COMPVHIP_CANNY_THRESHOLD_COMPARE_TO_GRADIENT) {
+		gradientThresholds(tLow, tHigh, lo, hi);
+		// the reference's SIMD leaves compare as signed int16 (intrin_avx2.cxx:144-147): thresholds above 32767 are an
+		// artefact regime (g <= 24480) that this implementation rejects instead of reproducing
+		if (*hi > 32767) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "thresholds above 32767 are not supported");
+	}
+	else if (!(tHigh * 255.f < 32767.f)) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "thresholds above 32767 are not supported");
+	return COMPVHIP_OK;
+}
+
+} // namespace
+
+// ==================================================================================================================
+extern "C" {
+
+int compvhip_device_count(void)
+{
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+	return n;
+}
+
+int compvhip_ctx_create(compvhip_ctx** out, int device)
+{
+	if (!out) return COMPVHIP_E_INVALID_PARAMETER;
+	*out = nullptr;
+	int n = 0;
+	if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return COMPVHIP_E_NOT_INITIALIZED; // no GPU: fail loudly, no CPU fallback
+	if (device < 0) { if (hipGetDevice(&device) != hipSuccess) return COMPVHIP_E_HIP; }
+	if (device >= n) return COMPVHIP_E_INVALID_PARAMETER;
+	if (hipSetDevice(device) != hipSuccess) return COMPVHIP_E_HIP;
+	compvhip_ctx* ctx = new (std::nothrow) compvhip_ctx();
+	if (!ctx) return COMPVHIP_E_OUT_OF_MEMORY;
+	ctx->device = device;
+	if (hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess) { delete ctx; return COMPVHIP_E_HIP; }
+	*out = ctx;
+	return COMPVHIP_OK;
+}
+
+void compvhip_ctx_destroy(compvhip_ctx* ctx)
+{
+	if (!ctx) return;
+	(void)hipSetDevice(ctx->device);
+	if (ctx->hostPlan) compvhip_plan_destroy(ctx->hostPlan);
+	dfree(ctx, ctx->dIn); dfree(ctx, ctx->dOut); dfree(ctx, ctx->dLines); dfree(ctx, ctx->dCounts); dfree(ctx, ctx->dAccOut);
+	if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+	delete ctx;
+}
+
+const char* compvhip_last_error(const compvhip_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+long compvhip_live_allocations(const compvhip_ctx* ctx) { return ctx ? ctx->live : 0; }
+
+int compvhip_houghsht_dims(size_t W, size_t H, float thetaDeg, size_t* R, size_t* T, float* step)
+{
+	if (!R || !T) return COMPVHIP_E_INVALID_PARAMETER;
+	return shtDims(W, H, thetaDeg, R, T, step);
+}
+
+// ---- plans -------------------------------------------------------------------------------------------------------
+int compvhip_plan_create(compvhip_ctx* ctx, size_t W, size_t H, size_t S, size_t frames, float thetaDeg, compvhip_plan** out)
+{
+	if (!ctx || !out) return COMPVHIP_E_INVALID_PARAMETER;
+	*out = nullptr;
+	// W,H >= 3: the convolution rejects images smaller than the kernel (compv_math_convlt.h:100); int16 coordinates in
+	// the reference's hysteresis stack bound W,H <= 32767 (canny_dete.cxx:617-621)
+	if (W < 3 || H < 3 || W > 32767 || H > 32767 || S < W || (S & 7) || !frames || !(thetaDeg > 0.f))
+		return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "plan geometry (need 3 <= W,H <= 32767, S >= W, S % 8 == 0, frames > 0)");
+	HIPCHK(ctx, hipSetDevice(ctx->device));
+	compvhip_plan* p = new (std::nothrow) compvhip_plan();
+	if (!p) return fail(ctx, COMPVHIP_E_OUT_OF_MEMORY, "plan");
+	p->ctx = ctx; p->W = W; p->H = H; p->S = S; p->frames = frames; p->thetaDeg = thetaDeg;
+	p->tilesX = static_cast<int>((W + 511) / 512);
+	p->tilesY = static_cast<int>((H + 63) / 64);
+	p->wb = p->tilesX * 16;
+	p->bitsFrameStride = static_cast<size_t>(p->wb) * H;
+	int rc = COMPVHIP_OK;
+	do {
+		if (dmalloc(ctx, &p->ebits, p->bitsFrameStride * frames) != hipSuccess) { rc = COMPVHIP_E_OUT_OF_MEMORY; break; }
+		if (dmalloc(ctx, &p->ubits, p->bitsFrameStride * frames) != hipSuccess) { rc = COMPVHIP_E_OUT_OF_MEMORY; break; }
+		if (dmalloc(ctx, &p->flags, kMaxRounds) != hipSuccess) { rc = COMPVHIP_E_OUT_OF_MEMORY; break; }
+		if (dmalloc(ctx, &p->thrDev, frames) != hipSuccess) { rc = COMPVHIP_E_OUT_OF_MEMORY; break; }
+		if (dmalloc(ctx, &p->sums, frames) != hipSuccess) { rc = COMPVHIP_E_OUT_OF_MEMORY; break; }
+		if (hipHostMalloc(reinterpret_cast<void**>(&p->hFlags), sizeof(int) * 4) != hipSuccess) { rc = COMPVHIP_E_OUT_OF_MEMORY; break; }
+	} while (0);
+	if (rc) { compvhip_plan_destroy(p); return fail(ctx, rc, "plan allocation"); }
+	*out = p;
+	return COMPVHIP_OK;
+}
+
+void compvhip_plan_destroy(compvhip_plan* p)
+{
+	if (!p) return;
+	compvhip_ctx* ctx = p->ctx;
+	(void)hipSetDevice(ctx->device);
+	timelineClear(p);
+	dfree(ctx, p->ebits); dfree(ctx, p->ubits); dfree(ctx, p->flags); dfree(ctx, p->thrDev); dfree(ctx, p->sums); dfree(ctx, p->tmpOut);
+	if (p->hFlags) (void)hipHostFree(p->hFlags);
+	dfree(ctx, p->sinQ); dfree(ctx, p->cosQ); dfree(ctx, p->edges); dfree(ctx, p->edgeCounts); dfree(ctx, p->acc);
+	dfree(ctx, p->keysA); dfree(ctx, p->keysB); dfree(ctx, p->lineCounts); dfree(ctx, p->segBeg); dfree(ctx, p->segEnd);
+	dfree(ctx, p->sortTemp);
+	delete p;
+}
+
+int compvhip_plan_set_timing(compvhip_plan* p, int enabled)
+{
+	if (!p) return COMPVHIP_E_INVALID_PARAMETER;
+	p->timing = enabled != 0;
+	return COMPVHIP_OK;
+}
+
+int compvhip_plan_get_timing(compvhip_plan* p, const char** names, float* ms, int cap)
+{
+	if (!p) return COMPVHIP_E_INVALID_PARAMETER;
+	if (!p->timeline.empty()) { (void)hipDeviceSynchronize(); timelineCollect(p); }
+	const int n = std::min<int>(cap, static_cast<int>(p->timingMs.size()));
+	for (int i = 0; i < n; ++i) { if (names) names[i] = p->timingNames[i].c_str(); if (ms) ms[i] = p->timingMs[i]; }
+	return n;
+}
+
+static int planCannyImpl(compvhip_plan* p, const uint8_t* d_in, float tLow, float tHigh, int ksize, int type, uint8_t* d_edges, hipStream_t st,
+                         bool waitConverged)
+{
+	compvhip_ctx* ctx = p->ctx;
+	if (!d_in || !d_edges) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "null frame pointer");
+	int lo, hi;
+	int rc = validateCannyParams(ctx, tLow, tHigh, ksize, type, &lo, &hi);
+	if (rc) return rc;
+	HIPCHK(ctx, hipSetDevice(ctx->device));
+	if (p->timing) timelineClear(p);
+	uint8_t* out = d_edges;
+	const size_t bytes = p->S * p->H * p->frames;
+	const bool alias = (d_in < d_edges + bytes) && (d_edges < d_in + bytes);
+	if (alias) {
+		// the tile kernel reads a 2-row halo that a neighbouring tile may already have overwritten: go through scratch
+		if (!p->tmpOut) HIPCHK(ctx, dmalloc(ctx, &p->tmpOut, bytes));
+		out = p->tmpOut;
+	}
+	const bool mean = (type == COMPVHIP_CANNY_THRESHOLD_PERCENT_OF_MEAN);
+	rc = enqueueCanny(p, d_in, out, lo, hi, mean, tLow, tHigh, st);
+	if (rc) return rc;
+	rc = enqueueResolve(p, out, kSpecRounds, st);
+	if (rc) return rc;
+	if (waitConverged) {
+		for (;;) {
+			bool done = false;
+			rc = resolveConverged(p, st, &done);
+			if (rc) return rc;
+			if (done) break;
+			rc = enqueueResolve(p, out, kSpecRounds, st);
+			if (rc) return rc;
+		}
+	}
+	if (alias) HIPCHK(ctx, hipMemcpyAsync(d_edges, out, bytes, hipMemcpyDeviceToDevice, st));
+	p->bitsValid = true;
+	return COMPVHIP_OK;
+}
+
+int compvhip_plan_canny(compvhip_plan* p, const uint8_t* d_in, float tLow, float tHigh, int ksize, int type, uint8_t* d_edges, void* stream)
+{
+	if (!p) return COMPVHIP_E_INVALID_PARAMETER;
+	return planCannyImpl(p, d_in, tLow, tHigh, ksize, type, d_edges, static_cast<hipStream_t>(stream), true);
+}
+
+static int planShtImpl(compvhip_plan* p, const uint8_t* d_edges, int threshold, int maxLines, compvhip_line* d_lines, size_t lineCap, int32_t* d_counts,
+                       hipStream_t st, bool clearTimeline)
+{
+	compvhip_ctx* ctx = p->ctx;
+	if (threshold <= 0) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "threshold must be > 0"); // houghsht.cxx:82
+	if (!d_edges && !p->bitsValid) return fail(ctx, COMPVHIP_E_INVALID_STATE, "no edge masks: run compvhip_plan_canny first or pass d_edges");
+	HIPCHK(ctx, hipSetDevice(ctx->device));
+	int rc = ensureSht(p);
+	if (rc) return rc;
+	rc = ensureLineCap(p, std::max(lineCap, kDefaultLineCap));
+	if (rc) return rc;
+	if (p->timing && clearTimeline) timelineClear(p);
+	const int frames = static_cast<int>(p->frames);
+	if (d_edges) {
+		Stamp s(p, st, "bytes_to_bits_kernel");
+		HIPCHK(ctx, launch_bytes_to_bits(d_edges, static_cast<int>(p->W), static_cast<int>(p->H), static_cast<int>(p->S), p->S * p->H, p->ebits, p->wb,
+		                                 p->bitsFrameStride, frames, st));
+		p->bitsValid = false; // U masks no longer match
+	}
+	ShtArgs a = shtArgs(p, threshold);
+	{ Stamp s(p, st, "sht_compact_kernel"); HIPCHK(ctx, launch_sht_compact(a, frames, st)); }
+	{ Stamp s(p, st, "sht_vote_kernel"); HIPCHK(ctx, launch_sht_vote(a, frames, st)); }
+	{ Stamp s(p, st, "sht_nms_kernel"); HIPCHK(ctx, launch_sht_nms(a, frames, st)); }
+	{
+		Stamp s(p, st, "sht_sort_lines");
+		size_t tb = p->sortTempBytes;
+		hipError_t e = sht_sort_keys(p->sortTemp, tb, p->keysA, p->keysB, p->lineCap, frames, p->lineCounts, p->segBeg, p->segEnd, st);
+		if (e != hipSuccess) return fail(ctx, COMPVHIP_E_HIP, "segmented sort", e);
+	}
+	if (d_lines && lineCap) {
+		Stamp s(p, st, "sht_decode_kernel");
+		HIPCHK(ctx, launch_sht_decode(p->keysB, p->lineCounts, p->lineCap, frames, static_cast<int>(p->T), static_cast<int>(p->W + p->H), p->thetaStep, maxLines,
+		                              d_lines, lineCap, st));
+	}
+	if (d_counts) HIPCHK(ctx, hipMemcpyAsync(d_counts, p->lineCounts, sizeof(int32_t) * frames, hipMemcpyDeviceToDevice, st));
+	return COMPVHIP_OK;
+}
+
+int compvhip_plan_houghsht(compvhip_plan* p, const uint8_t* d_edges, int threshold, int maxLines, compvhip_line* d_lines, size_t lineCap,
+                           int32_t* d_counts, void* stream)
+{
+	if (!p) return COMPVHIP_E_INVALID_PARAMETER;
+	return planShtImpl(p, d_edges, threshold, maxLines, d_lines, lineCap, d_counts, static_cast<hipStream_t>(stream), true);
+}
+
+int compvhip_plan_pipeline(compvhip_plan* p, const uint8_t* d_in, float tLow, float tHigh, int threshold, int maxLines, uint8_t* d_edges,
+                           compvhip_line* d_lines, size_t lineCap, int32_t* d_counts, void* stream)
+{
+	if (!p) return COMPVHIP_E_INVALID_PARAMETER;
+	compvhip_ctx* ctx = p->ctx;
+	hipStream_t st = static_cast<hipStream_t>(stream);
+	// Everything is enqueued back to back (speculative resolve rounds included); the convergence flag is checked once at
+	// the end and, in the rare case the hysteresis needed more rounds, the tail is replayed.
+	int rc = planCannyImpl(p, d_in, tLow, tHigh, 3, COMPVHIP_CANNY_THRESHOLD_COMPARE_TO_GRADIENT, d_edges, st, false);
+	if (rc) return rc;
+	const size_t bytes = p->S * p->H * p->frames;
+	const bool alias = (d_in < d_edges + bytes) && (d_edges < d_in + bytes);
+	uint8_t* out = alias ? p->tmpOut : d_edges;
+	for (;;) {
+		rc = planShtImpl(p, nullptr, threshold, maxLines, d_lines, lineCap, d_counts, st, false);
+		if (rc) return rc;
+		bool done = false;
+		rc = resolveConverged(p, st, &done);
+		if (rc) return rc;
+		if (done) break;
+		do {
+			rc = enqueueResolve(p, out, kSpecRounds, st);
+			if (rc) return rc;
+			rc = resolveConverged(p, st, &done);
+			if (rc) return rc;
+		} while (!done);
+		if (alias) HIPCHK(ctx, hipMemcpyAsync(d_edges, out, bytes, hipMemcpyDeviceToDevice, st));
+	}
+	return COMPVHIP_OK;
+}
+
+int compvhip_plan_acc(compvhip_plan* p, size_t frame, const int32_t** d_acc, size_t* R, size_t* T, size_t* accPitch)
+{
+	if (!p || !p->shtReady || frame >= p->frames) return COMPVHIP_E_INVALID_PARAMETER;
+	if (d_acc) *d_acc = p->acc + frame * p->accFrameStride;
+	if (R) *R = p->R;
+	if (T) *T = p->T;
+	if (accPitch) *accPitch = static_cast<size_t>(p->accPitch);
+	return COMPVHIP_OK;
+}
+
+int compvhip_plan_edge_counts(compvhip_plan* p, const int32_t** d_edge_counts)
+{
+	if (!p || !p->shtReady || !d_edge_counts) return COMPVHIP_E_INVALID_PARAMETER;
+	*d_edge_counts = p->edgeCounts;
+	return COMPVHIP_OK;
+}
+
+// ---- host entry points -------------------------------------------------------------------------------------------
+static int hostPlan(compvhip_ctx* ctx, size_t W, size_t H, float thetaDeg, compvhip_plan** out)
+{
+	const size_t S = alignUp(W, 64);
+	compvhip_plan* p = ctx->hostPlan;
+	if (p && (p->W != W || p->H != H || p->thetaDeg != thetaDeg)) { compvhip_plan_destroy(p); ctx->hostPlan = p = nullptr; }
+	if (!p) {
+		int rc = compvhip_plan_create(ctx, W, H, S, 1, thetaDeg, &p);
+		if (rc) return rc;
+		ctx->hostPlan = p;
+	}
+	const size_t bytes = S * H;
+	if (ctx->dInBytes < bytes) { dfree(ctx, ctx->dIn); HIPCHK(ctx, dmalloc(ctx, &ctx->dIn, bytes)); ctx->dInBytes = bytes; }
+	if (ctx->dOutBytes < bytes) { dfree(ctx, ctx->dOut); HIPCHK(ctx, dmalloc(ctx, &ctx->dOut, bytes)); ctx->dOutBytes = bytes; }
+	*out = p;
+	return COMPVHIP_OK;
+}
+
+static int checkImage(compvhip_ctx* ctx, const uint8_t* in, size_t W, size_t H, size_t S, const void* out, size_t So)
+{
+	if (!ctx) return COMPVHIP_E_INVALID_PARAMETER;
+	if (!in || !out || S < W || So < W) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "null image or stride < width");
+	if (W < 3 || H < 3 || W > 32767 || H > 32767) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "image size out of range (3..32767)");
+	return COMPVHIP_OK;
+}
+
+int compvhip_canny_u8(compvhip_ctx* ctx, const uint8_t* in, size_t W, size_t H, size_t S, float tLow, float tHigh, int ksize, int type,
+                      uint8_t* out, size_t So)
+{
+	int rc = checkImage(ctx, in, W, H, S, out, So);
+	if (rc) return rc;
+	int lo, hi;
+	rc = validateCannyParams(ctx, tLow, tHigh, ksize, type, &lo, &hi);
+	if (rc) return rc;
+	HIPCHK(ctx, hipSetDevice(ctx->device));
+	compvhip_plan* p = nullptr;
+	rc = hostPlan(ctx, W, H, ctx->hostPlan ? ctx->hostPlan->thetaDeg : 1.f, &p);
+	if (rc) return rc;
+	HIPCHK(ctx, hipMemcpy2DAsync(ctx->dIn, p->S, in, S, W, H, hipMemcpyHostToDevice, ctx->stream));
+	rc = compvhip_plan_canny(p, ctx->dIn, tLow, tHigh, ksize, type, ctx->dOut, ctx->stream);
+	if (rc) return rc;
+	HIPCHK(ctx, hipMemcpy2DAsync(out, So, ctx->dOut, p->S, W, H, hipMemcpyDeviceToHost, ctx->stream));
+	HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+	return COMPVHIP_OK;
+}
+
+int compvhip_edge_dete_u8(compvhip_ctx* ctx, const uint8_t* in, size_t W, size_t H, size_t S, int op, uint8_t* out, size_t So)
+{
+	int rc = checkImage(ctx, in, W, H, S, out, So);
+	if (rc) return rc;
+	if (op != COMPVHIP_OP_SOBEL && op != COMPVHIP_OP_SCHARR && op != COMPVHIP_OP_PREWITT)
+		return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "invalid detector id"); // edge_dete.cxx:246
+	HIPCHK(ctx, hipSetDevice(ctx->device));
+	compvhip_plan* p = nullptr;
+	rc = hostPlan(ctx, W, H, ctx->hostPlan ? ctx->hostPlan->thetaDeg : 1.f, &p);
+	if (rc) return rc;
+	HIPCHK(ctx, hipMemcpy2DAsync(ctx->dIn, p->S, in, S, W, H, hipMemcpyHostToDevice, ctx->stream));
+	EdgeDeteArgs a;
+	a.in = ctx->dIn; a.out = ctx->dOut; a.gmax = p->sums;
+	a.inFrameStride = p->S * H; a.outFrameStride = p->S * H;
+	a.W = static_cast<int>(W); a.H = static_cast<int>(H); a.S = static_cast<int>(p->S); a.So = static_cast<int>(p->S);
+	a.tilesX = p->tilesX; a.tilesY = p->tilesY;
+	HIPCHK(ctx, launch_edge_dete(a, op, 1, ctx->stream));
+	HIPCHK(ctx, hipMemcpy2DAsync(out, So, ctx->dOut, p->S, W, H, hipMemcpyDeviceToHost, ctx->stream));
+	HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+	return COMPVHIP_OK;
+}
+
+int compvhip_houghsht_u8(compvhip_ctx* ctx, const uint8_t* edges, size_t W, size_t H, size_t S, float rho, float thetaDeg, int threshold, int maxLines,
+                         compvhip_line* lines, size_t cap, size_t* n, int32_t* acc, size_t accStride)
+{
+	if (!ctx) return COMPVHIP_E_INVALID_PARAMETER;
+	if (!edges || !n || (cap && !lines) || S < W || !W || !H) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "null/invalid argument"); // houghsht.cxx:98
+	if (rho != 1.f) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "SHT requires rho == 1 (use KHT for fractional rho)"); // :306-316
+	if (!(thetaDeg > 0.f) || threshold <= 0) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "theta and threshold must be > 0");
+	if (W < 3 || H < 3 || W > 32767 || H > 32767) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "image size out of range (3..32767)");
+	*n = 0;
+	HIPCHK(ctx, hipSetDevice(ctx->device));
+	compvhip_plan* p = nullptr;
+	int rc = hostPlan(ctx, W, H, thetaDeg, &p);
+	if (rc) return rc;
+	rc = ensureSht(p);
+	if (rc) return rc;
+	if (acc && accStride < p->T) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "accStride < theta bins");
+	HIPCHK(ctx, hipMemcpy2DAsync(ctx->dIn, p->S, edges, S, W, H, hipMemcpyHostToDevice, ctx->stream));
+	if (!ctx->dCounts) HIPCHK(ctx, dmalloc(ctx, &ctx->dCounts, 1));
+	size_t want = std::max<size_t>(cap, 1);
+	int32_t count = 0;
+	for (int attempt = 0; attempt < 2; ++attempt) {
+		if (ctx->dLinesCap < want) { dfree(ctx, ctx->dLines); HIPCHK(ctx, dmalloc(ctx, &ctx->dLines, want)); ctx->dLinesCap = want; }
+		rc = compvhip_plan_houghsht(p, ctx->dIn, threshold, maxLines, ctx->dLines, want, ctx->dCounts, ctx->stream);
+		if (rc) return rc;
+		HIPCHK(ctx, hipMemcpyAsync(&count, ctx->dCounts, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+		HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+		if (static_cast<size_t>(count) <= p->lineCap) break;
+		// more candidate lines than the device key buffer holds: grow it and redo the line stage
+		rc = ensureLineCap(p, static_cast<size_t>(count));
+		if (rc) return rc;
+	}
+	size_t found = static_cast<size_t>(count);
+	if (maxLines > 0 && found > static_cast<size_t>(maxLines)) found = static_cast<size_t>(maxLines);
+	*n = found;
+	const size_t ncopy = std::min(found, cap);
+	if (ncopy) HIPCHK(ctx, hipMemcpy(lines, ctx->dLines, ncopy * sizeof(compvhip_line), hipMemcpyDeviceToHost));
+	if (acc) {
+		const size_t elems = p->R * p->T;
+		if (ctx->dAccOutElems < elems) { dfree(ctx, ctx->dAccOut); HIPCHK(ctx, dmalloc(ctx, &ctx->dAccOut, elems)); ctx->dAccOutElems = elems; }
+		HIPCHK(ctx, launch_sht_acc_transpose(p->acc, static_cast<int>(p->R), static_cast<int>(p->T), p->accPitch, ctx->dAccOut, p->T, ctx->stream));
+		HIPCHK(ctx, hipMemcpy2DAsync(acc, accStride * sizeof(int32_t), ctx->dAccOut, p->T * sizeof(int32_t), p->T * sizeof(int32_t), p->R,
+		                             hipMemcpyDeviceToHost, ctx->stream));
+		HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+	}
+	if (found > cap) return fail(ctx, COMPVHIP_E_OUT_OF_BOUND, "line buffer too small");
+	return COMPVHIP_OK;
+}
+
+} // extern "C"

@@ -1,0 +1,464 @@
+// canny_kernels.hip -- Canny (Sobel gradient -> NMS -> hysteresis) for gfx950, hand-written HIP.
+//
+// Replaces, behind compvhip_canny_u8 / compvhip_plan_canny (include/compv_hip.h):
+//   CompVEdgeDeteCanny::process            core/features/edges/compv_core_feature_canny_dete.cxx:123-331
+//   nms_gather / nms_apply / hysteresis    ...canny_dete.cxx:334-528 and the row leaves :566-680,
+//   CompVCannyNMSGatherRow_16mpw_Intrin_AVX2 / CompVCannyHysteresisRow_16mpw_Intrin_SSE2 (intrin/x86/*)
+//
+// HBM layout per frame:  in  u8 [H][S]                 (read once, 1 B/px)
+//                        out u8 [H][So]  {0,0xff}      (written once, 1 B/px)
+//                        E,U bitmasks u32 [H][wb]      (1 bit/px each: E = edge so far, U = weak but unresolved)
+//
+// Kernel 1 (canny_tile_kernel): one wave per 512x64 tile.  Streams rows through registers (stencil.hpp), applies the
+//   NMS rule to the *unsuppressed* g (gather/apply split of the reference), classifies weak (g_nms > tLow) / strong
+//   (g_nms > tHigh) per pixel, collects the per-row lane masks with v_writelane into a lane==row layout, and then
+//   floods strong -> weak inside the tile to a fixed point with 512-bit carry-propagate adds (horizontal runs in one
+//   step) + cross-lane row exchange (vertical/diagonal steps).  Pixels resolved inside the tile are final; weak
+//   pixels the tile cannot resolve go to the U mask.
+// Kernel 2 (canny_resolve_kernel): works on the 1-bit masks only (0.25 B/px): one workgroup per 64-row band floods
+//   E into U across tile borders; repeated (device flag, no data-dependent host work) until no band changes.  The
+//   fixed point "all pixels with g_nms > tLow 8-connected to a pixel with g_nms > tHigh" is unique, hence
+//   bit-exact whatever the propagation order (the reference's own multithreaded bands race the same way).
+#include "stencil.hpp"
+#include "kernels.hpp"
+
+namespace compvhip {
+
+// ---------------------------------------------------------------------------------------------------------------
+// helpers for the lane==row 512-bit masks
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t spread4(uint32_t nib)
+{
+	// bit j of the nibble -> bit 8*j
+	return __umul24(nib, 0x00204081u) & 0x01010101u;
+}
+
+// planes (bit i of lo[p]/hi[p] = pixel 8*i+p / 8*(i+32)+p of this lane's row) -> 8 x u64 in pixel order
+__device__ __forceinline__ void planes_to_row(const uint32_t (&lo)[8], const uint32_t (&hi)[8], uint64_t (&row)[8])
+{
+#pragma unroll
+	for (int k = 0; k < 16; ++k) {
+		uint32_t d = 0;
+#pragma unroll
+		for (int p = 0; p < 8; ++p) {
+			const uint32_t src = (k < 8) ? lo[p] : hi[p];
+			const uint32_t nib = (src >> (4 * (k & 7))) & 0xfu;
+			d |= spread4(nib) << p;
+		}
+		if (k & 1) row[k >> 1] |= (uint64_t)d << 32; else row[k >> 1] = d;
+	}
+}
+
+// S |= every run of W that contains a bit of S, towards higher bit positions (512-bit carry chain)
+__device__ __forceinline__ void flood_up(const uint64_t (&W)[8], uint64_t (&S)[8])
+{
+	uint64_t carry = 0;
+#pragma unroll
+	for (int m = 0; m < 8; ++m) {
+		const uint64_t a = W[m];
+		const uint64_t b = S[m] & a;
+		const uint64_t t = a + b;
+		const uint64_t c1 = t < a;
+		const uint64_t t2 = t + carry;
+		const uint64_t c2 = t2 < t;
+		carry = c1 | c2;
+		S[m] |= a & ~t2;
+	}
+}
+
+__device__ __forceinline__ void flood_down(const uint64_t (&W)[8], uint64_t (&S)[8])
+{
+	uint64_t carry = 0;
+#pragma unroll
+	for (int m = 7; m >= 0; --m) {
+		const uint64_t a = __brevll(W[m]);
+		const uint64_t b = __brevll(S[m]) & a;
+		const uint64_t t = a + b;
+		const uint64_t c1 = t < a;
+		const uint64_t t2 = t + carry;
+		const uint64_t c2 = t2 < t;
+		carry = c1 | c2;
+		S[m] |= __brevll(a & ~t2);
+	}
+}
+
+// Deposit the four 32-bit halves of the weak / strong lane masks of tile row `row` into lane `row` of the four
+// accumulators (v_writelane_b32; gfx9 allows one SGPR on the constant bus, so the lane select travels in M0).
+__device__ __forceinline__ void deposit_masks(uint64_t wm, uint64_t sm, int row, uint32_t& wlo, uint32_t& whi, uint32_t& slo, uint32_t& shi)
+{
+	asm volatile(
+		"s_mov_b32 m0, %8\n\t"
+		"v_writelane_b32 %0, %4, m0\n\t"
+		"v_writelane_b32 %1, %5, m0\n\t"
+		"v_writelane_b32 %2, %6, m0\n\t"
+		"v_writelane_b32 %3, %7, m0"
+		: "+v"(wlo), "+v"(whi), "+v"(slo), "+v"(shi)
+		: "s"((uint32_t)wm), "s"((uint32_t)(wm >> 32)), "s"((uint32_t)sm), "s"((uint32_t)(sm >> 32)), "s"(row)
+		: "m0");
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Kernel 1
+// ---------------------------------------------------------------------------------------------------------------
+template <bool GAP>
+__global__ __launch_bounds__(kCannyWaves * 64) void canny_tile_kernel(CannyArgs a)
+{
+	__shared__ uint32_t lds_rows[kCannyWaves][kTileH][17];
+
+	const int lane = threadIdx.x & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const int tileX = blockIdx.x;
+	const int tileY = blockIdx.y * kCannyWaves + wave;
+	const int frame = blockIdx.z;
+	if (tileY >= a.tilesY) return; // whole wave
+
+	const int W = a.W, H = a.H, S = a.S;
+	const int x0 = tileX * kTileW + lane * kLanePx;
+	const int y0 = tileY * kTileH;
+	const uint8_t* __restrict__ in = a.in + (size_t)frame * a.inFrameStride;
+
+	int tLow = a.tLow, tHigh = a.tHigh;
+	if (a.thrDev) { const int2 t = a.thrDev[frame]; tLow = t.x; tHigh = t.y; }
+
+	// columns gi = 0..9 <-> x = x0-1+gi: g is forced to 0 outside [1, W-2] (zero OUTPUT border of the convolution,
+	// compv_math_convlt.h:181-209) -- only tiles touching column 0 or W-1.. need the per-column test.
+	const bool edgeTile = (tileX == 0) || ((tileX + 1) * kTileW + 1 >= W - 1);
+	uint32_t colok = 0x3ffu;
+	if (edgeTile) {
+		colok = 0;
+#pragma unroll
+		for (int gi = 0; gi < 10; ++gi) {
+			const int x = x0 - 1 + gi;
+			if (x >= 1 && x <= W - 2) colok |= 1u << gi;
+		}
+	}
+	// quirk Q3 column coverage of the NMS and of the seed scan: [1,simdEnd) U [cStart,W-1)
+	uint32_t cov = 0xffu;
+	if (GAP) {
+		cov = 0;
+#pragma unroll
+		for (int p = 0; p < 8; ++p) {
+			const int x = x0 + p;
+			if ((x >= 1 && x < a.simdEnd) || (x >= a.cStart && x < W - 1)) cov |= 1u << p;
+		}
+	}
+
+	Grad3State<1, 2> st;
+	st.reset();
+	int gU[10], gC[10];
+	bool c1[8], c2[8], ngc[8];
+#pragma unroll
+	for (int i = 0; i < 10; ++i) { gU[i] = 0; gC[i] = 0; }
+#pragma unroll
+	for (int p = 0; p < 8; ++p) { c1[p] = false; c2[p] = false; ngc[p] = false; }
+
+	uint32_t wlo[8], whi[8], slo[8], shi[8];
+#pragma unroll
+	for (int p = 0; p < 8; ++p) { wlo[p] = whi[p] = slo[p] = shi[p] = 0u; }
+
+	// input rows y0-2 .. y0+kTileH+1; the gradient of row yc = yin-1 appears when row yin is pushed, the NMS of row
+	// yc-1 one step later.
+	for (int it = 0; it < kTileH + 4; ++it) {
+		const int yin = y0 - 2 + it;
+		const int yl = min(max(yin, 0), H - 1);
+		const RowBytes rb = load_row(in + (size_t)yl * S, x0, S);
+		int v[12];
+		unpack12(rb, v);
+		GradRow gr;
+		st.push(v, gr);
+
+		const int yc = yin - 1;
+		int gD[10];
+		const bool rowok = (yc >= 1) && (yc <= H - 2);
+#pragma unroll
+		for (int gi = 0; gi < 10; ++gi) gD[gi] = rowok ? (gr.ax[gi] + gr.ay[gi]) : 0;
+		if (edgeTile) {
+#pragma unroll
+			for (int gi = 0; gi < 10; ++gi) gD[gi] = ((colok >> gi) & 1u) ? gD[gi] : 0;
+		}
+
+		// NMS + classification of row yo = yc-1 (rows gU = yo-1, gC = yo, gD = yo+1)
+		const int yo = yc - 1;
+		const int rr = yo - y0;
+		if (rr >= 0 && rr < kTileH) {
+#pragma unroll
+			for (int p = 0; p < 8; ++p) {
+				const int gi = p + 1;
+				const int g = gC[gi];
+				const int mh = max(gC[gi - 1], gC[gi + 1]);
+				const int mv = max(gU[gi], gD[gi]);
+				const int md1 = max(gU[gi - 1], gD[gi + 1]);
+				const int md2 = max(gD[gi - 1], gU[gi + 1]);
+				int m = c1[p] ? mh : (c2[p] ? (ngc[p] ? md2 : md1) : mv);
+				bool seedok = true;
+				if (GAP) {
+					seedok = (cov >> p) & 1u;
+					m = seedok ? m : 0;
+				}
+				const bool weak = (g > tLow) && (g >= m);
+				const bool strong = weak && (g > tHigh) && seedok;
+				const uint64_t wm = __builtin_amdgcn_ballot_w64(weak);
+				const uint64_t sm = __builtin_amdgcn_ballot_w64(strong);
+				deposit_masks(wm, sm, rr, wlo[p], whi[p], slo[p], shi[p]);
+			}
+		}
+
+		// roll: direction class of the new centre row (constants canny_dete.h:58-61: tan(pi/8), tan(3pi/8) in Q16)
+#pragma unroll
+		for (int gi = 0; gi < 10; ++gi) { gU[gi] = gC[gi]; gC[gi] = gD[gi]; }
+#pragma unroll
+		for (int p = 0; p < 8; ++p) {
+			const uint32_t ax = (uint32_t)gr.ax[p + 1], ay = (uint32_t)gr.ay[p + 1];
+			const uint32_t ays = ay << 16;
+			c1[p] = ays < __umul24(ax, 27145u);
+			c2[p] = ays < __umul24(ax, 158217u);
+			ngc[p] = gr.ng[p + 1];
+		}
+	}
+
+	// ---- lane == row: flood strong into weak inside the tile ----
+	uint64_t Wm[8], Em[8];
+	planes_to_row(wlo, whi, Wm);
+	planes_to_row(slo, shi, Em);
+	for (;;) {
+		flood_up(Wm, Em);
+		flood_down(Wm, Em);
+		bool changed = false;
+		uint64_t nb[8];
+#pragma unroll
+		for (int m = 0; m < 8; ++m) {
+			uint64_t up = __shfl_up(Em[m], 1);
+			uint64_t dn = __shfl_down(Em[m], 1);
+			if (lane == 0) up = 0;
+			if (lane == 63) dn = 0;
+			nb[m] = up | dn;
+		}
+#pragma unroll
+		for (int m = 0; m < 8; ++m) {
+			uint64_t n3 = nb[m] | (nb[m] << 1) | (nb[m] >> 1);
+			if (m > 0) n3 |= nb[m - 1] >> 63;
+			if (m < 7) n3 |= nb[m + 1] << 63;
+			const uint64_t add = Wm[m] & n3 & ~Em[m];
+			Em[m] |= add;
+			changed |= (add != 0);
+		}
+		if (!__any(changed)) break;
+	}
+
+	// ---- outputs ----
+	const int yrow = y0 + lane;
+	if (yrow < H) {
+		uint32_t* __restrict__ eb = a.ebits + (size_t)frame * a.bitsFrameStride + (size_t)yrow * a.wb + tileX * 16;
+		uint32_t* __restrict__ ub = a.ubits + (size_t)frame * a.bitsFrameStride + (size_t)yrow * a.wb + tileX * 16;
+#pragma unroll
+		for (int q = 0; q < 4; ++q) {
+			uint4 e, u;
+			e.x = (uint32_t)Em[2 * q]; e.y = (uint32_t)(Em[2 * q] >> 32);
+			e.z = (uint32_t)Em[2 * q + 1]; e.w = (uint32_t)(Em[2 * q + 1] >> 32);
+			const uint64_t u0 = Wm[2 * q] & ~Em[2 * q], u1 = Wm[2 * q + 1] & ~Em[2 * q + 1];
+			u.x = (uint32_t)u0; u.y = (uint32_t)(u0 >> 32); u.z = (uint32_t)u1; u.w = (uint32_t)(u1 >> 32);
+			reinterpret_cast<uint4*>(eb)[q] = e;
+			reinterpret_cast<uint4*>(ub)[q] = u;
+		}
+	}
+	// bytes: transpose back to lane == 8-pixel column group through LDS (wave-private rows, no barrier needed
+	// beyond the wave's own program order)
+#pragma unroll
+	for (int m = 0; m < 8; ++m) {
+		lds_rows[wave][lane][2 * m] = (uint32_t)Em[m];
+		lds_rows[wave][lane][2 * m + 1] = (uint32_t)(Em[m] >> 32);
+	}
+	__builtin_amdgcn_wave_barrier();
+	__builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): LDS writes of this wave have landed
+	uint8_t* __restrict__ out = a.out + (size_t)frame * a.outFrameStride;
+	const uint8_t* lb = reinterpret_cast<const uint8_t*>(&lds_rows[wave][0][0]);
+	if (x0 + 8 <= a.So) {
+		const int rows = min(kTileH, H - y0);
+		for (int r = 0; r < rows; ++r) {
+			const uint32_t b = lb[r * 17 * 4 + lane];
+			uint2 o;
+			o.x = spread4(b & 0xfu) * 0xffu;
+			o.y = spread4(b >> 4) * 0xffu;
+			*reinterpret_cast<uint2*>(out + (size_t)(y0 + r) * a.So + x0) = o;
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Kernel 2: cross-tile hysteresis on the bit masks.  One workgroup = one band of kBandH rows x up to kBandWords
+// 32-px words.  E rows carry a one-row / one-word halo (read-only context owned by neighbouring bands).
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(kResolveThreads) void canny_resolve_kernel(ResolveArgs a)
+{
+	extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+	// round r only runs if round r-1 changed something (rounds are enqueued speculatively, see host code)
+	if (a.round > 0 && a.flags[a.round - 1] == 0) return;
+
+	const int frame = blockIdx.z;
+	const int band = blockIdx.y;
+	const int chunk = blockIdx.x;
+	const int wb = a.wb;
+	const int w0 = chunk * kBandWords;               // first word of this chunk
+	const int cw = min(kBandWords, wb - w0);          // words in this chunk
+	const int y0 = band * kBandH;
+	const int rows = min(kBandH, a.H - y0);
+	const int ew = cw + 2;                            // E row pitch in LDS (halo word each side)
+	uint32_t* sE = smem;                              // (rows+2) x ew
+	uint32_t* sU = smem + (kBandH + 2) * (kBandWords + 2); // rows x cw
+
+	uint32_t* __restrict__ gE = a.ebits + (size_t)frame * a.bitsFrameStride;
+	uint32_t* __restrict__ gU = a.ubits + (size_t)frame * a.bitsFrameStride;
+	const int tid = threadIdx.x;
+
+	// load U; bail out early when the band has nothing unresolved
+	int haveU = 0;
+	for (int i = tid; i < rows * cw; i += kResolveThreads) {
+		const int r = i / cw, k = i - r * cw;
+		const uint32_t u = gU[(size_t)(y0 + r) * wb + w0 + k];
+		sU[r * cw + k] = u;
+		haveU |= (u != 0);
+	}
+	if (!__syncthreads_or(haveU)) return;
+	for (int i = tid; i < (rows + 2) * ew; i += kResolveThreads) {
+		const int r = i / ew, k = i - r * ew;
+		const int y = y0 - 1 + r, w = w0 - 1 + k;
+		uint32_t e = 0;
+		if (y >= 0 && y < a.H && w >= 0 && w < wb) e = gE[(size_t)y * wb + w];
+		sE[i] = e;
+	}
+	__syncthreads();
+
+	for (;;) {
+		int changed = 0;
+		for (int i = tid; i < rows * cw; i += kResolveThreads) {
+			const int r = i / cw, k = i - r * cw;
+			const uint32_t cand = sU[i] & ~sE[(r + 1) * ew + k + 1];
+			if (!cand) continue;
+			uint32_t nb = 0;
+#pragma unroll
+			for (int dr = 0; dr < 3; ++dr) {
+				const uint32_t* row = sE + (r + dr) * ew + k;
+				const uint32_t c = row[1];
+				nb |= c | (c << 1) | (c >> 1) | (row[0] >> 31) | (row[2] << 31);
+			}
+			uint32_t add = cand & nb;
+			if (add) {
+				// extend along horizontal runs of candidates inside the word (both directions)
+				const uint32_t up = cand & ~(cand + add);
+				const uint32_t rc = __brev(cand), ra = __brev(add);
+				const uint32_t dn = __brev(rc & ~(rc + ra));
+				add |= up | dn;
+				sE[(r + 1) * ew + k + 1] |= add; // single owner per word; neighbours may read old or new (monotone)
+				changed = 1;
+			}
+		}
+		if (!__syncthreads_or(changed)) break;
+	}
+
+	// write back: promoted = E_new & U_old
+	int wrote = 0;
+	uint8_t* __restrict__ out = a.out + (size_t)frame * a.outFrameStride;
+	for (int i = tid; i < rows * cw; i += kResolveThreads) {
+		const int r = i / cw, k = i - r * cw;
+		const uint32_t u = sU[i];
+		if (!u) continue;
+		uint32_t p = u & sE[(r + 1) * ew + k + 1];
+		if (!p) continue;
+		const size_t gi = (size_t)(y0 + r) * wb + w0 + k;
+		gE[gi] = sE[(r + 1) * ew + k + 1];
+		gU[gi] = u & ~p;
+		wrote = 1;
+		uint8_t* orow = out + (size_t)(y0 + r) * a.So + (size_t)(w0 + k) * 32;
+		while (p) {
+			const int b = __ffs(p) - 1;
+			p &= p - 1;
+			orow[b] = 0xff;
+		}
+	}
+	if (__syncthreads_or(wrote)) {
+		if (tid == 0) a.flags[a.round] = 1; // benign race: every writer stores 1
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// PERCENT_OF_MEAN thresholds: sum of pixels per frame (CompVMathUtils::sum<u8,u32>, canny_dete.cxx:243), then
+// mean/thresholds exactly as :252-266.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void frame_sum_kernel(const uint8_t* __restrict__ in, int W, int H, int S, size_t frameStride,
+                                                        unsigned int* __restrict__ sums)
+{
+	const int frame = blockIdx.y;
+	const uint8_t* p = in + (size_t)frame * frameStride;
+	unsigned int acc = 0;
+	const int wq = W >> 2;
+	for (int y = blockIdx.x; y < H; y += gridDim.x) {
+		const uint8_t* row = p + (size_t)y * S;
+		for (int q = threadIdx.x; q < wq; q += blockDim.x) {
+			const uint32_t v = reinterpret_cast<const uint32_t*>(row)[q];
+			acc += (v & 0xff) + ((v >> 8) & 0xff) + ((v >> 16) & 0xff) + (v >> 24);
+		}
+		for (int x = (wq << 2) + threadIdx.x; x < W; x += blockDim.x) acc += row[x];
+	}
+	for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+	if ((threadIdx.x & 63) == 0) atomicAdd(&sums[frame], acc);
+}
+
+__global__ void mean_thresholds_kernel(const unsigned int* __restrict__ sums, int W, int H, float fLow, float fHigh, int2* __restrict__ thr, int frames)
+{
+	const int f = blockIdx.x * blockDim.x + threadIdx.x;
+	if (f >= frames) return;
+	unsigned int mean = (sums[f] / (unsigned int)(W * H)) & 0xffu; // static_cast<uint8_t>
+	mean = mean < 1u ? 1u : mean;
+	unsigned int lo = (unsigned int)(int)__fmul_rn((float)mean, fLow) & 0xffffu;   // static_cast<uint16_t>(mean * f)
+	unsigned int hi = (unsigned int)(int)__fmul_rn((float)mean, fHigh) & 0xffffu;
+	lo = lo < 1u ? 1u : lo;
+	const unsigned int t = lo + 2u;
+	hi = (t > hi ? t : hi) & 0xffffu;
+	thr[f] = make_int2((int)lo, (int)hi);
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// launchers
+// ---------------------------------------------------------------------------------------------------------------
+hipError_t launch_canny_tiles(const CannyArgs& a, int frames, bool gap, hipStream_t stream)
+{
+	dim3 grid(a.tilesX, (a.tilesY + kCannyWaves - 1) / kCannyWaves, frames);
+	dim3 block(kCannyWaves * 64);
+	if (gap) hipLaunchKernelGGL(canny_tile_kernel<true>, grid, block, 0, stream, a);
+	else hipLaunchKernelGGL(canny_tile_kernel<false>, grid, block, 0, stream, a);
+	return hipGetLastError();
+}
+
+size_t resolve_lds_bytes()
+{
+	return ((size_t)(kBandH + 2) * (kBandWords + 2) + (size_t)kBandH * kBandWords) * sizeof(uint32_t);
+}
+
+hipError_t launch_canny_resolve(const ResolveArgs& a, int frames, hipStream_t stream)
+{
+	static bool attr_set = false;
+	const size_t lds = resolve_lds_bytes();
+	if (!attr_set) {
+		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(canny_resolve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+		if (e != hipSuccess) return e;
+		attr_set = true;
+	}
+	const int bands = (a.H + kBandH - 1) / kBandH;
+	const int chunks = (a.wb + kBandWords - 1) / kBandWords;
+	dim3 grid(chunks, bands, frames);
+	hipLaunchKernelGGL(canny_resolve_kernel, grid, dim3(kResolveThreads), lds, stream, a);
+	return hipGetLastError();
+}
+
+hipError_t launch_mean_thresholds(const uint8_t* in, int W, int H, int S, size_t frameStride, int frames, float fLow, float fHigh,
+                                  unsigned int* sums, int2* thr, hipStream_t stream)
+{
+	hipError_t e = hipMemsetAsync(sums, 0, sizeof(unsigned int) * frames, stream);
+	if (e != hipSuccess) return e;
+	dim3 grid(min(H, 64), frames);
+	hipLaunchKernelGGL(frame_sum_kernel, grid, dim3(256), 0, stream, in, W, H, S, frameStride, sums);
+	hipLaunchKernelGGL(mean_thresholds_kernel, dim3((frames + 63) / 64), dim3(64), 0, stream, sums, W, H, fLow, fHigh, thr, frames);
+	return hipGetLastError();
+}
+
+} // namespace compvhip

@@ -1,0 +1,88 @@
+// kernels.hpp -- argument blocks and launchers shared between the .hip kernel files and the C-ABI host code (api.cpp).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace compvhip {
+
+// ---- Canny ------------------------------------------------------------------------------------------------
+constexpr int kCannyWaves = 4;        // waves (= 512x64 tiles, stacked vertically) per workgroup
+constexpr int kBandH = 64;            // rows per resolve band
+constexpr int kBandWords = 128;       // 32-px words per resolve chunk (4096 columns)
+constexpr int kResolveThreads = 512;
+
+struct CannyArgs {
+	const uint8_t* in;
+	uint8_t* out;
+	uint32_t* ebits;
+	uint32_t* ubits;
+	const int2* thrDev;       // per-frame {tLow,tHigh} (PERCENT_OF_MEAN) or nullptr
+	size_t inFrameStride, outFrameStride, bitsFrameStride; // elements
+	int W, H, S, So;
+	int wb;                   // words per bitmask row (= tilesX*16)
+	int tilesX, tilesY;
+	int tLow, tHigh;
+	int simdEnd, cStart;      // quirk Q3 coverage: [1,simdEnd) U [cStart,W-1)
+};
+
+struct ResolveArgs {
+	uint32_t* ebits;
+	uint32_t* ubits;
+	uint8_t* out;
+	int* flags;               // flags[round] = 1 when round changed something
+	size_t outFrameStride, bitsFrameStride;
+	int H, So, wb;
+	int round;
+};
+
+hipError_t launch_canny_tiles(const CannyArgs& a, int frames, bool gap, hipStream_t stream);
+hipError_t launch_canny_resolve(const ResolveArgs& a, int frames, hipStream_t stream);
+hipError_t launch_mean_thresholds(const uint8_t* in, int W, int H, int S, size_t frameStride, int frames, float fLow, float fHigh,
+                                  unsigned int* sums, int2* thr, hipStream_t stream);
+
+// ---- Sobel / Scharr / Prewitt detector -------------------------------------------------------------------
+struct EdgeDeteArgs {
+	const uint8_t* in;
+	uint8_t* out;
+	unsigned int* gmax;       // per frame
+	size_t inFrameStride, outFrameStride;
+	int W, H, S, So;
+	int tilesX, tilesY;
+};
+hipError_t launch_edge_dete(const EdgeDeteArgs& a, int op, int frames, hipStream_t stream);
+
+// ---- Hough SHT ---------------------------------------------------------------------------------------------
+constexpr int kShtThetaPerGroup = 4;  // theta bins per vote workgroup (2 packed u16 pairs per rho row)
+constexpr int kShtVoteThreads = 1024;
+
+struct ShtArgs {
+	const uint32_t* ebits;    // edge bit masks [frames][H][wb]
+	uint32_t* edges;          // compacted edge list per frame: (y << 16) | x, capacity edgeCap
+	int* edgeCounts;          // per frame
+	int32_t* acc;             // [frames][T][accPitch]
+	const int32_t* sinQ;      // [T]
+	const int32_t* cosQ;      // [T]
+	uint64_t* lineKeys;       // [frames][lineCap] sort keys: strength<<32 | ~(row*T+col)
+	int* lineCounts;          // per frame
+	size_t bitsFrameStride, edgeCap, accFrameStride, lineCap;
+	int W, H, wb;
+	int R, T, accPitch, barrier;
+	int threshold, nmsLastCol;
+	int shards;               // vote workgroups per (frame, theta group)
+};
+hipError_t launch_bytes_to_bits(const uint8_t* edges, int W, int H, int S, size_t frameStride, uint32_t* ebits, int wb, size_t bitsFrameStride,
+                                int frames, hipStream_t stream);
+hipError_t launch_sht_compact(const ShtArgs& a, int frames, hipStream_t stream);
+hipError_t launch_sht_vote(const ShtArgs& a, int frames, hipStream_t stream);
+hipError_t launch_sht_nms(const ShtArgs& a, int frames, hipStream_t stream);
+hipError_t launch_sht_decode(const uint64_t* keys, const int* counts, size_t lineCap, int frames, int T, int barrier, float thetaStep,
+                             int maxLines, void* lines /*compvhip_line*/, size_t outCap, hipStream_t stream);
+// acc [T][pitch] -> reference layout [R][stride]
+hipError_t launch_sht_acc_transpose(const int32_t* accT, int R, int T, int accPitch, int32_t* out, size_t outStride, hipStream_t stream);
+size_t sht_vote_lds_bytes(int R);
+// descending segmented sort (one segment per frame) of the unique 64-bit line keys; temp == nullptr queries tempBytes
+hipError_t sht_sort_keys(void* temp, size_t& tempBytes, const uint64_t* keysIn, uint64_t* keysOut, size_t lineCap, int frames,
+                         const int* counts, unsigned int* segBeg, unsigned int* segEnd, hipStream_t stream);
+
+} // namespace compvhip

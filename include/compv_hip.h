@@ -1,0 +1,151 @@
+/* compv_hip.h -- C ABI of the MI355X (gfx950) implementation of CompV's Sobel -> Canny -> Hough hot path.
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++ types, no ownership transfer.  It is what a
+ * CompV maintainer binds from the replacement factories registered with CompVFeature::addFactory()
+ * (reference: base/include/compv/base/compv_features.h:36-44 registry, base/compv_features.cxx:30-40 replace-by-id);
+ * the reference-side binding is shown in INTEGRATION.md and implemented in compv_amd/host/.
+ * Precedent for a function-pointer GPU hook in the reference: gpu/include/compv/gpu/base/math/compv_gpu_math_convlt.h.
+ *
+ * All file:line citations are relative to the CompV source tree.
+ *
+ * Conventions
+ *   - return value: 0 = success (COMPV_ERROR_CODE_S_OK), negative = COMPVHIP_E_* (mapping to COMPV_ERROR_CODE in
+ *     INTEGRATION.md).  No exceptions cross this boundary.
+ *   - W,H = columns/rows, S = row stride in elements (bytes for u8).  Images are single-plane uint8.
+ *   - "host" entry points take HOST pointers, are synchronous and leave results valid in host memory on return
+ *     (what CompVEdgeDete::process / CompVHough::process promise their callers).
+ *   - "dev" entry points take DEVICE pointers to frames resident in HBM and enqueue work on a HIP stream.
+ *   - an instance (ctx / plan) is not re-entrant, exactly like a CompVEdgeDeteCanny / CompVHoughSht object
+ *     (persistent scratch sized on first use: core/features/edges/compv_core_feature_canny_dete.cxx:133-147).
+ */
+#ifndef COMPV_HIP_H
+#define COMPV_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#	define COMPVHIP_API __attribute__((visibility("default")))
+#else
+#	define COMPVHIP_API
+#endif
+
+/* ---- error codes (negative) ------------------------------------------------------------------------------- */
+enum {
+	COMPVHIP_OK = 0,
+	COMPVHIP_E_NOT_IMPLEMENTED = -1,    /* COMPV_ERROR_CODE_E_NOT_IMPLEMENTED */
+	COMPVHIP_E_NOT_INITIALIZED = -2,    /* COMPV_ERROR_CODE_E_NOT_INITIALIZED */
+	COMPVHIP_E_INVALID_STATE = -3,      /* COMPV_ERROR_CODE_E_INVALID_STATE   (tLow >= tHigh, canny_dete.cxx:126) */
+	COMPVHIP_E_INVALID_PARAMETER = -4,  /* COMPV_ERROR_CODE_E_INVALID_PARAMETER */
+	COMPVHIP_E_OUT_OF_MEMORY = -5,      /* COMPV_ERROR_CODE_E_OUT_OF_MEMORY */
+	COMPVHIP_E_OUT_OF_BOUND = -6,       /* COMPV_ERROR_CODE_E_OUT_OF_BOUND    (caller's line buffer too small) */
+	COMPVHIP_E_HIP = -7                 /* a hipError_t; class of COMPV_ERROR_CODE_E_CUDA / _E_OPENCL (compv_common.h:265-266) */
+};
+
+/* ---- operator / mode ids ---------------------------------------------------------------------------------- */
+enum { /* gradient operator of the edge detector; ids mirror COMPV_SOBEL_ID / _SCHARR_ID / _PREWITT_ID
+          (compv_features.h:84-90), kernels compv_features.h:124-133 */
+	COMPVHIP_OP_SOBEL = 0,
+	COMPVHIP_OP_SCHARR = 2,
+	COMPVHIP_OP_PREWITT = 3
+};
+enum { /* COMPV_CANNY_THRESHOLD_TYPE_* (compv_features.h:80-81) */
+	COMPVHIP_CANNY_THRESHOLD_COMPARE_TO_GRADIENT = 0,
+	COMPVHIP_CANNY_THRESHOLD_PERCENT_OF_MEAN = 1
+};
+
+/* One Hough line.  rho/theta/strength are CompVHoughLine's fields (compv_common.h:686-693); row/col are the
+ * accumulator cell (rho = barrier - row, theta = col * thetaStepRad) and define the canonical tie order. */
+typedef struct compvhip_line {
+	float rho;
+	float theta;
+	int32_t strength;
+	int32_t row;
+	int32_t col;
+} compvhip_line;
+
+typedef struct compvhip_ctx compvhip_ctx;     /* one GPU + its scratch; one per host thread / CompV object */
+typedef struct compvhip_plan compvhip_plan;   /* batched device-resident pipeline for a fixed geometry */
+
+/* ---- life cycle -------------------------------------------------------------------------------------------- */
+COMPVHIP_API int compvhip_device_count(void);
+/* device < 0: use the current HIP device. Replaces nothing in CompV: it is what CompVGpu::init() would call
+ * (gpu/compv_gpu.cxx:53-58). */
+COMPVHIP_API int compvhip_ctx_create(compvhip_ctx** ctx, int device);
+COMPVHIP_API void compvhip_ctx_destroy(compvhip_ctx* ctx);
+/* text of the last failure on this ctx (HIP error string included); never NULL */
+COMPVHIP_API const char* compvhip_last_error(const compvhip_ctx* ctx);
+/* hipMalloc/hipFree balance of this ctx -- the analogue of COMPV_DEBUG_CHECK_FOR_MEMORY_LEAKS (compv_api.h:148-155) */
+COMPVHIP_API long compvhip_live_allocations(const compvhip_ctx* ctx);
+
+/* ---- host entry points (drop-in for process()) ------------------------------------------------------------- */
+
+/* CompVCornerDeteEdgeBase::process (core/features/edges/compv_core_feature_edge_dete.cxx:55-206):
+ * out = sat_u8(trunc(float(|gx|+|gy|) * (255.f / gmax))).  in and out may alias. */
+COMPVHIP_API int compvhip_edge_dete_u8(compvhip_ctx* ctx, const uint8_t* in, size_t W, size_t H, size_t S, int op,
+                                       uint8_t* out, size_t So);
+
+/* CompVEdgeDeteCanny::process (core/features/edges/compv_core_feature_canny_dete.cxx:123-331).
+ * tLow/tHigh are the detector's float thresholds (resolved to uint16 exactly as :251-266), ksize 3 or 5,
+ * thresholdType COMPVHIP_CANNY_THRESHOLD_*.  out = {0,0xff}; in and out may alias (samples/edges_canny/main.cxx:72). */
+COMPVHIP_API int compvhip_canny_u8(compvhip_ctx* ctx, const uint8_t* in, size_t W, size_t H, size_t S,
+                                   float tLow, float tHigh, int ksize, int thresholdType, uint8_t* out, size_t So);
+
+/* CompVHoughSht::process (core/features/hough/compv_core_feature_houghsht.cxx:96-262).  rho must be 1 (:306-316),
+ * thetaDeg in degrees, threshold > 0 is the NMS/line threshold, maxLines <= 0 keeps every line.
+ * lines: caller-allocated, capacity cap; *n receives the number of lines found (after the maxLines cut); if *n > cap
+ * only cap lines are written and COMPVHIP_E_OUT_OF_BOUND is returned.  Lines are sorted by strength descending; equal
+ * strengths (order unspecified in the reference: unstable std::sort, :243-249) are ordered by (row, col) ascending.
+ * acc (optional): int32 accumulator in the reference layout, R rows of accStride elements, R = 2(W+H)+1. */
+COMPVHIP_API int compvhip_houghsht_u8(compvhip_ctx* ctx, const uint8_t* edges, size_t W, size_t H, size_t S,
+                                      float rho, float thetaDeg, int threshold, int maxLines,
+                                      compvhip_line* lines, size_t cap, size_t* n,
+                                      int32_t* acc, size_t accStride);
+
+/* Geometry helper: R (rho rows), T (theta bins) and the float32 theta step for a W x H image
+ * (initCoords, houghsht.cxx:318-348). */
+COMPVHIP_API int compvhip_houghsht_dims(size_t W, size_t H, float thetaDeg, size_t* R, size_t* T, float* thetaStepRad);
+
+/* ---- device-resident batched pipeline (frames already in HBM) ---------------------------------------------- */
+
+/* A plan owns every scratch buffer for `frames` frames of W x H (stride S, S % 8 == 0, frame stride S*H) and the
+ * Q16 sin/cos tables for thetaDeg.  Frames are independent units: one plan per GPU, shard frames across GPUs. */
+COMPVHIP_API int compvhip_plan_create(compvhip_ctx* ctx, size_t W, size_t H, size_t S, size_t frames, float thetaDeg,
+                                      compvhip_plan** plan);
+COMPVHIP_API void compvhip_plan_destroy(compvhip_plan* plan);
+
+/* Canny on `frames` device frames: d_in -> d_edges (both frames*S*H bytes, may alias).  Asynchronous on `stream`
+ * (a hipStream_t; NULL = default stream) except for the hysteresis convergence check, which polls a device flag. */
+COMPVHIP_API int compvhip_plan_canny(compvhip_plan* plan, const uint8_t* d_in, float tLow, float tHigh, int ksize,
+                                     int thresholdType, uint8_t* d_edges, void* stream);
+
+/* SHT on the edge maps produced by the last compvhip_plan_canny() of this plan (uses its 1-bit edge masks, no byte
+ * re-read) or, when d_edges != NULL, on arbitrary device edge maps.  Results stay on the device:
+ * d_lines: frames * lineCap compvhip_line (sorted as compvhip_houghsht_u8), d_counts: frames int32 (lines found,
+ * before clipping to lineCap). */
+COMPVHIP_API int compvhip_plan_houghsht(compvhip_plan* plan, const uint8_t* d_edges, int threshold, int maxLines,
+                                        compvhip_line* d_lines, size_t lineCap, int32_t* d_counts, void* stream);
+
+/* Sobel -> Canny -> HoughSHT in one call (the benchmark's "step"). */
+COMPVHIP_API int compvhip_plan_pipeline(compvhip_plan* plan, const uint8_t* d_in, float tLow, float tHigh,
+                                        int threshold, int maxLines, uint8_t* d_edges,
+                                        compvhip_line* d_lines, size_t lineCap, int32_t* d_counts, void* stream);
+
+/* Device accumulator of frame f after compvhip_plan_houghsht: int32, theta-major [T][accPitch] (pitch >= R). */
+COMPVHIP_API int compvhip_plan_acc(compvhip_plan* plan, size_t frame, const int32_t** d_acc, size_t* R, size_t* T, size_t* accPitch);
+/* Number of edge pixels per frame found by the last canny/houghsht of this plan (device int32[frames]). */
+COMPVHIP_API int compvhip_plan_edge_counts(compvhip_plan* plan, const int32_t** d_edge_counts);
+
+/* Per-kernel timing of the last plan call, measured with hipEvents on the stream the kernels were launched on.
+ * names/ms: caller arrays of capacity cap; returns the number of entries (<= cap). Enabled by compvhip_plan_set_timing. */
+COMPVHIP_API int compvhip_plan_set_timing(compvhip_plan* plan, int enabled);
+COMPVHIP_API int compvhip_plan_get_timing(compvhip_plan* plan, const char** names, float* ms, int cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* COMPV_HIP_H */

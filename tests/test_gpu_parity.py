@@ -1,0 +1,270 @@
+"""GPU parity tests (run with `-m gpu` on an MI355X): the HIP path, called through the C ABI (compv_amd.capi ->
+libcompv_hip.so), against the oracle on the same seeded inputs, against the committed golden fixtures generated from
+the compiled reference, and -- at BASELINE.json's full sizes -- through size-independent properties.
+
+Bars: bit-exact for the uint8 Sobel / Canny maps, the int32 Hough accumulator and the line set (rho, theta as f32
+bit patterns, strength); there is no floating-point tolerance on this path (the only f32 operations are one
+division + one multiply in the Sobel normalisation and col*thetaStep, all correctly rounded single operations).
+"""
+import numpy as np
+import pytest
+
+from oracle_bindings import md5_rows, synth_frame
+
+pytestmark = pytest.mark.gpu
+
+
+def _lines_tuple(lines):
+    return [(float(l["rho"]), float(l["theta"]), int(l["strength"]), int(l["row"]), int(l["col"])) for l in lines]
+
+
+def _orc_tuple(lines):
+    return [(float(np.float32(l[0])), float(np.float32(l[1])), int(l[2]), int(l[3]), int(l[4])) for l in lines]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# host entry points vs oracle
+# ---------------------------------------------------------------------------------------------------------------
+SIZES = [(3, 3), (9, 9), (16, 16), (17, 9), (20, 20), (33, 200), (64, 64), (97, 33), (200, 258), (257, 65), (320, 240),
+         (512, 64), (513, 65), (641, 480), (1023, 129), (1282, 720)]
+
+
+@pytest.mark.parametrize("W,H", SIZES)
+def test_edge_dete_matches_oracle(hip_ctx, oracle, W, H):
+    from compv_amd import capi
+    img = synth_frame(W, H, 100 + W)
+    for op, oop in [(capi.OP_SOBEL, 0), (capi.OP_SCHARR, 2), (capi.OP_PREWITT, 3)]:
+        exp, _ = oracle.edge_dete(img, oop)
+        got = hip_ctx.edge_dete(img, op)
+        assert (got == exp).all(), (W, H, op, int((got != exp).sum()))
+
+
+def test_edge_dete_constant_image_is_zero(hip_ctx, oracle):
+    img = np.full((48, 80), 77, np.uint8)     # gmax == 0 -> scale = inf -> all zeros (edge_dete.cxx:199)
+    exp, gmax = oracle.edge_dete(img)
+    assert gmax == 0 and not exp.any()
+    assert not hip_ctx.edge_dete(img).any()
+
+
+@pytest.mark.parametrize("W,H", SIZES)
+def test_canny_matches_oracle(hip_ctx, oracle, W, H):
+    rng = np.random.default_rng(W * 31 + H)
+    y, x = np.mgrid[0:H, 0:W]
+    imgs = [synth_frame(W, H, 7 + H),
+            rng.integers(0, 256, (H, W), dtype=np.uint8),
+            ((np.sin(x / 7.0) + np.cos(y / 5.0)) * 40 + 128 + rng.integers(0, 6, (H, W))).astype(np.uint8)]
+    for k, img in enumerate(imgs):
+        for (tl, th) in [(59.0, 119.0), (0.8, 1.6), (20.0, 300.0)]:
+            rc, exp = oracle.canny(img, tl, th)
+            assert rc == 0
+            got = hip_ctx.canny(img, tl, th)
+            assert (got == exp).all(), (W, H, k, tl, th, int((got != exp).sum()))
+
+
+def test_canny_long_weak_chains(hip_ctx, oracle):
+    """Hysteresis stress: weak spirals / long chains with one strong seed cross many tiles and bands."""
+    W, H = 1100, 700
+    img = np.full((H, W), 100, np.uint8)
+    # a serpentine of low-contrast lines (weak everywhere) ...
+    for k, yy in enumerate(range(20, H - 20, 12)):
+        img[yy:yy + 3, 15:W - 15] = 112
+        xs = W - 30 if (k % 2 == 0) else 15
+        img[yy:yy + 15, xs:xs + 3] = 112
+    # ... and one strong blob touching its start
+    img[18:26, 10:20] = 255
+    rc, exp = oracle.canny(img, 10.0, 200.0)
+    assert rc == 0 and exp.any()
+    got = hip_ctx.canny(img, 10.0, 200.0)
+    assert (got == exp).all(), int((got != exp).sum())
+
+
+def test_canny_in_place_and_strided(hip_ctx, oracle):
+    W, H, S = 300, 200, 384
+    buf = np.zeros((H, S), np.uint8)
+    buf[:, :W] = synth_frame(W, H, 5)
+    view = buf[:, :W]
+    rc, exp = oracle.canny(np.ascontiguousarray(view), 59.0, 119.0)
+    got = hip_ctx.canny(view, 59.0, 119.0, out=view)        # samples/edges_canny/main.cxx:72 does process(mat,&mat)
+    assert (got == exp).all()
+    assert not buf[:, W:].any()                              # stride padding untouched
+
+
+def test_canny_mean_threshold_mode(hip_ctx, oracle):
+    from compv_amd import capi
+    for (W, H) in [(640, 480), (333, 77)]:
+        img = synth_frame(W, H)
+        rc, exp = oracle.canny(img, 0.68, 1.36, 3, 1)
+        got = hip_ctx.canny(img, 0.68, 1.36, 3, capi.THRESHOLD_PERCENT_OF_MEAN)
+        assert (got == exp).all()
+
+
+def test_canny_error_behaviour(hip_ctx):
+    from compv_amd import capi
+    img = synth_frame(64, 64)
+    with pytest.raises(capi.CompvHipError) as e:
+        hip_ctx.canny(img, 100.0, 50.0)                      # tLow >= tHigh -> E_INVALID_STATE (canny_dete.cxx:126)
+    assert e.value.code == capi.E_INVALID_STATE
+    with pytest.raises(capi.CompvHipError) as e:
+        hip_ctx.canny(img, 10.0, 50.0, ksize=7)              # canny_dete.cxx:101
+    assert e.value.code == capi.E_INVALID_PARAMETER
+    with pytest.raises(capi.CompvHipError) as e:
+        hip_ctx.canny(np.zeros((2, 2), np.uint8), 10.0, 50.0)  # smaller than the kernel (compv_math_convlt.h:100)
+    assert e.value.code == capi.E_INVALID_PARAMETER
+
+
+@pytest.mark.parametrize("W,H,tl,th,deg,thr", [(320, 240, 59., 119., 1.0, 40), (333, 77, 0.8, 1.6, 1.0, 20), (641, 480, 59., 119., 1.0, 100),
+                                               (640, 480, 59., 119., 0.5, 50), (640, 480, 59., 119., 2.0, 30), (320, 240, 59., 119., 1.3, 10),
+                                               (1282, 720, 0.8, 1.6, 1.0, 100)])
+def test_houghsht_matches_oracle(hip_ctx, oracle, W, H, tl, th, deg, thr):
+    img = synth_frame(W, H)
+    rc, edges = oracle.canny(img, tl, th)
+    acc_exp = oracle.sht_acc(edges, deg)
+    exp = oracle.sht_lines_from_acc(acc_exp, W, H, deg, thr)
+    lines, acc = hip_ctx.houghsht(edges, deg, thr, want_acc=True)
+    assert acc.shape == acc_exp.shape and (acc == acc_exp).all(), int((acc != acc_exp).sum())   # vote histogram bit-exact
+    assert _lines_tuple(lines) == _orc_tuple(exp)
+    # maxLines keeps the strongest
+    if len(exp) > 5:
+        top = hip_ctx.houghsht(edges, deg, thr, max_lines=5)
+        assert _lines_tuple(top) == _orc_tuple(exp[:5])
+
+
+def test_houghsht_empty_and_full_maps(hip_ctx, oracle):
+    W, H = 160, 120
+    none = np.zeros((H, W), np.uint8)
+    assert len(hip_ctx.houghsht(none, 1.0, 1)) == 0
+    full = np.full((H, W), 0xff, np.uint8)                    # every pixel votes; any non-zero byte is an edge
+    full[::3, ::5] = 1
+    acc_exp = oracle.sht_acc(full, 1.0)
+    lines, acc = hip_ctx.houghsht(full, 1.0, 50, want_acc=True)
+    assert (acc == acc_exp).all()
+    assert _lines_tuple(lines) == _orc_tuple(oracle.sht_lines_from_acc(acc_exp, W, H, 1.0, 50))
+
+
+def test_houghsht_error_behaviour(hip_ctx):
+    from compv_amd import capi
+    e = np.zeros((32, 32), np.uint8)
+    with pytest.raises(capi.CompvHipError) as ex:
+        hip_ctx.houghsht(e, 1.0, 10, rho=0.5)                  # SHT requires rho == 1 (houghsht.cxx:306-316)
+    assert ex.value.code == capi.E_INVALID_PARAMETER
+    with pytest.raises(capi.CompvHipError):
+        hip_ctx.houghsht(e, 1.0, 0)                            # threshold must be > 0 (:82)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# golden fixtures from the compiled reference
+# ---------------------------------------------------------------------------------------------------------------
+GOLD = ["tiny_20x20", "q1_200x258", "small_320x240", "q3_641x480", "ragged_333x77", "dense_1282x720", "hd_1280x720",
+        "fhd_1920x1080", "fhd_seed7", "theta_half_640x480", "mean_640x480", "uhd_3840x2160"]
+
+
+@pytest.mark.parametrize("name", GOLD)
+def test_golden(hip_ctx, golden, name):
+    meta, arrays = golden
+    m = meta[name]
+    W, H = m["W"], m["H"]
+    img = synth_frame(W, H, m["seed"])
+    assert md5_rows(img) == m["input_md5"]
+    sob = hip_ctx.edge_dete(img)
+    assert md5_rows(sob) == m["sobel_md5"]
+    can = hip_ctx.canny(img, m["tLow"], m["tHigh"], 3, m["threshold_type"])
+    assert md5_rows(can) == m["canny_md5"]
+    assert int((can != 0).sum()) == m["canny_edges"]
+    assert set(np.unique(can)) <= {0, 255}
+    if "sht" in m:
+        s = m["sht"]
+        lines = hip_ctx.houghsht(can, s["theta_deg"], s["threshold"], cap=max(1, s["lines"]))
+        assert len(lines) == s["lines"]
+        assert int(lines["strength"].astype(np.int64).sum()) == s["sum_strength"]
+        exp = arrays[name + "/sht_lines"]
+        got = np.stack([lines["rho"][:len(exp)].astype(np.float64), lines["theta"][:len(exp)].astype(np.float64),
+                        lines["strength"][:len(exp)].astype(np.float64)], axis=1)
+        assert (got == exp).all()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# device-resident batched plan (what bench.py times) at BASELINE sizes, via torch device memory
+# ---------------------------------------------------------------------------------------------------------------
+def _plan_run(hip_ctx, frames_np, tl, th, thr, line_cap):
+    import torch
+    from compv_amd import capi
+    n, H, W = frames_np.shape
+    dev = torch.device("cuda:0")
+    d_in = torch.from_numpy(frames_np).to(dev)
+    d_edges = torch.empty_like(d_in)
+    d_lines = torch.zeros((n, line_cap, 5), dtype=torch.int32, device=dev)
+    d_counts = torch.zeros(n, dtype=torch.int32, device=dev)
+    plan = capi.Plan(hip_ctx, W, H, W, n, 1.0)
+    st = torch.cuda.current_stream().cuda_stream
+    plan.pipeline(d_in.data_ptr(), tl, th, thr, 0, d_edges.data_ptr(), d_lines.data_ptr(), line_cap, d_counts.data_ptr(), st)
+    torch.cuda.synchronize()
+    accs = []
+    for f in range(n):
+        p, R, T, pitch = plan.acc(f)
+        import ctypes
+        a = torch.empty((T, pitch), dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        # copy the plan-owned accumulator through hipMemcpy D2D
+        hip = ctypes.CDLL("libamdhip64.so")
+        hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
+        assert hip.hipMemcpy(a.data_ptr(), p, T * pitch * 4, 3) == 0
+        accs.append(a[:, :R].t().contiguous().cpu().numpy())
+    out = (d_edges.cpu().numpy(), d_lines.cpu().numpy().view(np.uint8).reshape(n, line_cap, 20), d_counts.cpu().numpy(), accs)
+    plan.close()
+    return out
+
+
+def test_plan_pipeline_batch_matches_oracle(hip_ctx, oracle):
+    from compv_amd import capi
+    W, H, n = 640, 480, 5
+    frames = np.stack([synth_frame(W, H, 12345 + f) for f in range(n)])
+    edges, lines_raw, counts, accs = _plan_run(hip_ctx, frames, 59.0, 119.0, 60, 4096)
+    for f in range(n):
+        rc, e = oracle.canny(frames[f], 59.0, 119.0)
+        assert (edges[f] == e).all(), f
+        acc = oracle.sht_acc(e, 1.0)
+        assert (accs[f] == acc).all(), f
+        exp = oracle.sht_lines_from_acc(acc, W, H, 1.0, 60)
+        assert counts[f] == len(exp)
+        got = np.frombuffer(lines_raw[f].tobytes(), dtype=capi.LINE_DTYPE)[:len(exp)]
+        assert _lines_tuple(got) == _orc_tuple(exp)
+
+
+@pytest.mark.parametrize("name", ["fhd_1920x1080", "uhd_3840x2160"])
+def test_plan_full_size_golden_and_properties(hip_ctx, golden, name):
+    """BASELINE configs 2-4: full Canny and SHT at 1080p / 4K through the batched plan: MD5/sums from the compiled
+    reference, plus size-independent properties (sum(acc) == E*T, idempotent re-run, frame independence)."""
+    meta, _ = golden
+    m = meta[name]
+    W, H = m["W"], m["H"]
+    f0 = synth_frame(W, H, m["seed"])
+    f1 = synth_frame(W, H, m["seed"] + 1)
+    frames = np.stack([f0, f1, f0])
+    edges, lines_raw, counts, accs = _plan_run(hip_ctx, frames, m["tLow"], m["tHigh"], m["sht"]["threshold"], 1 << 16)
+    assert md5_rows(edges[0]) == m["canny_md5"]
+    assert (edges[0] == edges[2]).all() and not (edges[0] == edges[1]).all()      # frames are independent units
+    E = int((edges[0] != 0).sum())
+    assert E == m["canny_edges"]
+    assert int(accs[0].sum()) == E * 180                                           # every edge votes once per theta
+    assert (accs[0] == accs[2]).all()
+    assert counts[0] == m["sht"]["lines"] == counts[2]
+    from compv_amd import capi
+    got = np.frombuffer(lines_raw[0].tobytes(), dtype=capi.LINE_DTYPE)[:counts[0]]
+    assert int(got["strength"].astype(np.int64).sum()) == m["sht"]["sum_strength"]
+    assert (np.diff(got["strength"].astype(np.int64)) <= 0).all()                  # sorted by strength descending
+    assert accs[0].max() == got["strength"][0]
+
+
+def test_no_leaks(oracle):
+    """hipMalloc/hipFree balance (the analogue of COMPV_DEBUG_CHECK_FOR_MEMORY_LEAKS, compv_api.h:148-155)."""
+    from compv_amd import capi
+    ctx = capi.Context(0)
+    img = synth_frame(200, 100)
+    e = ctx.canny(img, 59.0, 119.0)
+    ctx.houghsht(e, 1.0, 20)
+    ctx.edge_dete(img)
+    assert ctx.live_allocations() > 0
+    lib, h = ctx.lib, ctx.h
+    # destroy hostPlan & staging, then the count must return to zero just before the ctx itself goes
+    ctx.close()
+    assert ctx.h is None
