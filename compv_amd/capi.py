@@ -5,6 +5,7 @@ directly from C++.  There is NO CPU fallback: importing works w
 symbol-export test can run), but creating a context without a GPU, or loading without the built library, fails loudly.
 """
 import ctypes as C
+import importlib.util
 import os
 
 import numpy as np
@@ -30,7 +31,7 @@ EXPORTS = [
     "compvhip_live_allocations", "compvhip_edge_dete_u8", "compvhip_canny_u8", "compvhip_houghsht_u8",
     "compvhip_houghsht_dims", "compvhip_plan_create", "compvhip_plan_destroy", "compvhip_plan_canny",
     "compvhip_plan_houghsht", "compvhip_plan_pipeline", "compvhip_plan_acc", "compvhip_plan_edge_counts",
-    "compvhip_plan_set_timing", "compvhip_plan_get_timing",
+    "compvhip_plan_set_timing", "compvhip_plan_get_timing", "compvhip_plan_acc_export",
 ]
 
 
@@ -50,6 +51,20 @@ class CompvHipError(RuntimeError):
 _lib = None
 
 
+def _share_hip_runtime_with_torch():
+    """PyTorch wheels bundle their own libamdhip64.so (same soname as /opt/rocm's).  Device pointers are only
+    interchangeable inside ONE HIP runtime, so when torch is installed its copy is loaded first and the loader
+    resolves libcompv_hip.so's DT_NEEDED libamdhip64.so.7 to it (no torch import needed, no dependency on torch)."""
+    try:
+        spec = importlib.util.find_spec("torch")
+    except Exception:
+        spec = None
+    if spec and spec.submodule_search_locations:
+        p = os.path.join(list(spec.submodule_search_locations)[0], "lib", "libamdhip64.so")
+        if os.path.exists(p):
+            C.CDLL(p, mode=C.RTLD_GLOBAL)
+
+
 def load():
     """Load the HIP library; raises if it was not built (no silent fallback)."""
     global _lib
@@ -58,6 +73,7 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise RuntimeError("compv_amd: %s is missing -- run `python -c 'import __graft_entry__ as g; g.build()'` "
                            "(the HIP extension is mandatory; there is no CPU fallback)" % LIB_PATH)
+    _share_hip_runtime_with_torch()
     L = C.CDLL(LIB_PATH)
     sz, vp, i32 = C.c_size_t, C.c_void_p, C.c_int
     L.compvhip_device_count.restype = i32
@@ -79,6 +95,7 @@ def load():
     L.compvhip_plan_houghsht.argtypes = [vp, vp, i32, i32, vp, sz, vp, vp]
     L.compvhip_plan_pipeline.argtypes = [vp, vp, C.c_float, C.c_float, i32, i32, vp, vp, sz, vp, vp]
     L.compvhip_plan_acc.argtypes = [vp, sz, C.POINTER(vp), C.POINTER(sz), C.POINTER(sz), C.POINTER(sz)]
+    L.compvhip_plan_acc_export.argtypes = [vp, sz, vp, sz, vp]
     L.compvhip_plan_edge_counts.argtypes = [vp, C.POINTER(vp)]
     L.compvhip_plan_set_timing.argtypes = [vp, i32]
     L.compvhip_plan_get_timing.argtypes = [vp, C.POINTER(C.c_char_p), C.POINTER(C.c_float), i32]
@@ -198,6 +215,9 @@ class Plan:
         p, R, T, pitch = C.c_void_p(), C.c_size_t(), C.c_size_t(), C.c_size_t()
         self.ctx._chk(self.lib.compvhip_plan_acc(self.h, frame, C.byref(p), C.byref(R), C.byref(T), C.byref(pitch)))
         return p.value, R.value, T.value, pitch.value
+
+    def acc_export(self, frame, d_out, out_stride, stream=0):
+        self.ctx._chk(self.lib.compvhip_plan_acc_export(self.h, frame, d_out, out_stride, stream))
 
     def edge_counts_ptr(self):
         p = C.c_void_p()

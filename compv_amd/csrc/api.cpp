@@ -22,7 +22,7 @@ using namespace compvhip;
 namespace {
 constexpr int kMaxRounds = 4096;       // hysteresis resolve rounds before giving up (one per 64-row band crossed)
 constexpr int kSpecRounds = 3;         // rounds enqueued speculatively between two convergence checks
-constexpr size_t kDefaultLineCap = 1u << 18;
+constexpr size_t kMinLineCap = 1u << 10;  // per-frame line-key slots are sized by the caller's lineCap (grown on demand)
 } // namespace
 
 struct compvhip_ctx {
@@ -61,8 +61,8 @@ struct compvhip_plan {
 	uint32_t* edges = nullptr; size_t edgeCap = 0; int* edgeCounts = nullptr;
 	int32_t* acc = nullptr; size_t accFrameStride = 0;
 	uint64_t* keysA = nullptr; uint64_t* keysB = nullptr; size_t lineCap = 0; int* lineCounts = nullptr;
-	unsigned int* segBeg = nullptr; unsigned int* segEnd = nullptr;
 	void* sortTemp = nullptr; size_t sortTempBytes = 0;
+	int cellBits = 0, keyBits = 0;
 	int shards = 1;
 	// timing
 	bool timing = false;
@@ -210,8 +210,13 @@ int ensureSht(compvhip_plan* p)
 	HIPCHK(ctx, hipMemset(p->edgeCounts, 0, sizeof(int) * p->frames));
 	HIPCHK(ctx, dmalloc(ctx, &p->acc, p->accFrameStride * p->frames));
 	HIPCHK(ctx, dmalloc(ctx, &p->lineCounts, p->frames));
-	HIPCHK(ctx, dmalloc(ctx, &p->segBeg, p->frames));
-	HIPCHK(ctx, dmalloc(ctx, &p->segEnd, p->frames));
+	// line key = frameTag | strength (16 bits) | cell index (cellBits): see sht_nms_kernel
+	p->cellBits = 1;
+	while ((static_cast<size_t>(1) << p->cellBits) <= R * T) p->cellBits++;
+	int frameBits = 0;
+	while ((static_cast<size_t>(1) << frameBits) < p->frames) frameBits++;
+	p->keyBits = frameBits + 16 + p->cellBits;
+	if (p->keyBits > 64) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "too many frames x accumulator cells for a 64-bit line key");
 	p->shtReady = true;
 	return COMPVHIP_OK;
 }
@@ -226,8 +231,8 @@ int ensureLineCap(compvhip_plan* p, size_t cap)
 	HIPCHK(ctx, dmalloc(ctx, &p->keysA, cap * p->frames));
 	HIPCHK(ctx, dmalloc(ctx, &p->keysB, cap * p->frames));
 	size_t tb = 0;
-	hipError_t e = sht_sort_keys(nullptr, tb, p->keysA, p->keysB, cap, static_cast<int>(p->frames), p->lineCounts, p->segBeg, p->segEnd, nullptr);
-	if (e != hipSuccess) return fail(ctx, COMPVHIP_E_HIP, "segmented sort size query", e);
+	hipError_t e = sht_sort_keys(nullptr, tb, p->keysA, p->keysB, cap, static_cast<int>(p->frames), p->keyBits, nullptr);
+	if (e != hipSuccess) return fail(ctx, COMPVHIP_E_HIP, "radix sort size query", e);
 	p->sortTempBytes = tb;
 	uint8_t* tmp = nullptr;
 	HIPCHK(ctx, dmalloc(ctx, &tmp, std::max<size_t>(tb, 16)));
@@ -247,6 +252,8 @@ ShtArgs shtArgs(compvhip_plan* p, int threshold)
 	a.threshold = threshold;
 	a.nmsLastCol = static_cast<int>((p->T - 1) & ~static_cast<size_t>(3)); // quirk Q2: NMS covers theta columns [1, (T-1)&~3]
 	a.shards = p->shards;
+	a.frames = static_cast<int>(p->frames);
+	a.cellBits = p->cellBits;
 	return a;
 }
 
@@ -408,7 +415,7 @@ void compvhip_plan_destroy(compvhip_plan* p)
 	dfree(ctx, p->ebits); dfree(ctx, p->ubits); dfree(ctx, p->flags); dfree(ctx, p->thrDev); dfree(ctx, p->sums); dfree(ctx, p->tmpOut);
 	if (p->hFlags) (void)hipHostFree(p->hFlags);
 	dfree(ctx, p->sinQ); dfree(ctx, p->cosQ); dfree(ctx, p->edges); dfree(ctx, p->edgeCounts); dfree(ctx, p->acc);
-	dfree(ctx, p->keysA); dfree(ctx, p->keysB); dfree(ctx, p->lineCounts); dfree(ctx, p->segBeg); dfree(ctx, p->segEnd);
+	dfree(ctx, p->keysA); dfree(ctx, p->keysB); dfree(ctx, p->lineCounts);
 	dfree(ctx, p->sortTemp);
 	delete p;
 }
@@ -482,7 +489,7 @@ static int planShtImpl(compvhip_plan* p, const uint8_t* d_edges, int threshold, 
 	HIPCHK(ctx, hipSetDevice(ctx->device));
 	int rc = ensureSht(p);
 	if (rc) return rc;
-	rc = ensureLineCap(p, std::max(lineCap, kDefaultLineCap));
+	rc = ensureLineCap(p, std::max(lineCap, kMinLineCap));
 	if (rc) return rc;
 	if (p->timing && clearTimeline) timelineClear(p);
 	const int frames = static_cast<int>(p->frames);
@@ -499,13 +506,13 @@ static int planShtImpl(compvhip_plan* p, const uint8_t* d_edges, int threshold, 
 	{
 		Stamp s(p, st, "sht_sort_lines");
 		size_t tb = p->sortTempBytes;
-		hipError_t e = sht_sort_keys(p->sortTemp, tb, p->keysA, p->keysB, p->lineCap, frames, p->lineCounts, p->segBeg, p->segEnd, st);
-		if (e != hipSuccess) return fail(ctx, COMPVHIP_E_HIP, "segmented sort", e);
+		hipError_t e = sht_sort_keys(p->sortTemp, tb, p->keysA, p->keysB, p->lineCap, frames, p->keyBits, st);
+		if (e != hipSuccess) return fail(ctx, COMPVHIP_E_HIP, "radix sort", e);
 	}
 	if (d_lines && lineCap) {
 		Stamp s(p, st, "sht_decode_kernel");
 		HIPCHK(ctx, launch_sht_decode(p->keysB, p->lineCounts, p->lineCap, frames, static_cast<int>(p->T), static_cast<int>(p->W + p->H), p->thetaStep, maxLines,
-		                              d_lines, lineCap, st));
+		                              p->cellBits, d_lines, lineCap, st));
 	}
 	if (d_counts) HIPCHK(ctx, hipMemcpyAsync(d_counts, p->lineCounts, sizeof(int32_t) * frames, hipMemcpyDeviceToDevice, st));
 	return COMPVHIP_OK;
@@ -556,6 +563,15 @@ int compvhip_plan_acc(compvhip_plan* p, size_t frame, const int32_t** d_acc, siz
 	if (R) *R = p->R;
 	if (T) *T = p->T;
 	if (accPitch) *accPitch = static_cast<size_t>(p->accPitch);
+	return COMPVHIP_OK;
+}
+
+int compvhip_plan_acc_export(compvhip_plan* p, size_t frame, int32_t* d_out, size_t outStride, void* stream)
+{
+	if (!p || !p->shtReady || frame >= p->frames || !d_out || outStride < p->T) return COMPVHIP_E_INVALID_PARAMETER;
+	compvhip_ctx* ctx = p->ctx;
+	HIPCHK(ctx, launch_sht_acc_transpose(p->acc + frame * p->accFrameStride, static_cast<int>(p->R), static_cast<int>(p->T), p->accPitch, d_out, outStride,
+	                                     static_cast<hipStream_t>(stream)));
 	return COMPVHIP_OK;
 }
 

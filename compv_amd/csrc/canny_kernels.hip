@@ -158,10 +158,12 @@ __global__ __launch_bounds__(kCannyWaves * 64) void canny_tile_kernel(CannyArgs 
 
 	// input rows y0-2 .. y0+kTileH+1; the gradient of row yc = yin-1 appears when row yin is pushed, the NMS of row
 	// yc-1 one step later.
+	RowBytes nextRow = load_row(in + (size_t)min(max(y0 - 2, 0), H - 1) * S, x0, S);
 	for (int it = 0; it < kTileH + 4; ++it) {
 		const int yin = y0 - 2 + it;
-		const int yl = min(max(yin, 0), H - 1);
-		const RowBytes rb = load_row(in + (size_t)yl * S, x0, S);
+		const RowBytes rb = nextRow;
+		// software prefetch: the next row's loads are in flight while this row is processed
+		nextRow = load_row(in + (size_t)min(max(yin + 1, 0), H - 1) * S, x0, S);
 		int v[12];
 		unpack12(rb, v);
 		GradRow gr;

@@ -70,6 +70,8 @@ struct ShtArgs {
 	int R, T, accPitch, barrier;
 	int threshold, nmsLastCol;
 	int shards;               // vote workgroups per (frame, theta group)
+	int frames;
+	int cellBits;             // bits of the accumulator cell index in a line key (2^cellBits > R*T)
 };
 hipError_t launch_bytes_to_bits(const uint8_t* edges, int W, int H, int S, size_t frameStride, uint32_t* ebits, int wb, size_t bitsFrameStride,
                                 int frames, hipStream_t stream);
@@ -77,12 +79,12 @@ hipError_t launch_sht_compact(const ShtArgs& a, int frames, hipStream_t stream);
 hipError_t launch_sht_vote(const ShtArgs& a, int frames, hipStream_t stream);
 hipError_t launch_sht_nms(const ShtArgs& a, int frames, hipStream_t stream);
 hipError_t launch_sht_decode(const uint64_t* keys, const int* counts, size_t lineCap, int frames, int T, int barrier, float thetaStep,
-                             int maxLines, void* lines /*compvhip_line*/, size_t outCap, hipStream_t stream);
+                             int maxLines, int cellBits, void* lines /*compvhip_line*/, size_t outCap, hipStream_t stream);
 // acc [T][pitch] -> reference layout [R][stride]
 hipError_t launch_sht_acc_transpose(const int32_t* accT, int R, int T, int accPitch, int32_t* out, size_t outStride, hipStream_t stream);
 size_t sht_vote_lds_bytes(int R);
-// descending segmented sort (one segment per frame) of the unique 64-bit line keys; temp == nullptr queries tempBytes
-hipError_t sht_sort_keys(void* temp, size_t& tempBytes, const uint64_t* keysIn, uint64_t* keysOut, size_t lineCap, int frames,
-                         const int* counts, unsigned int* segBeg, unsigned int* segEnd, hipStream_t stream);
+// one descending radix sort over the (unique) 64-bit line keys of all frames; temp == nullptr queries tempBytes
+hipError_t sht_sort_keys(void* temp, size_t& tempBytes, const uint64_t* keysIn, uint64_t* keysOut, size_t lineCap, int frames, int keyBits,
+                         hipStream_t stream);
 
 } // namespace compvhip

@@ -24,7 +24,10 @@ constexpr int kTileH = 64;                 // output rows per wave tile (one per
 
 __device__ __forceinline__ int absdiff(int a, int b)
 {
-	return (int)__usad((unsigned)a, (unsigned)b, 0u); // v_sad_u32: |a-b| + 0
+	// v_sad_u32 d, a, b, 0 = |a-b|; written as asm because the compiler otherwise expands the intrinsic to sub/max/min
+	int d;
+	asm("v_sad_u32 %0, %1, %2, 0" : "=v"(d) : "v"(a), "v"(b));
+	return d;
 }
 
 // 16 input bytes around the lane's 8 pixels: columns x0-4 .. x0+11

@@ -137,6 +137,9 @@ COMPVHIP_API int compvhip_plan_pipeline(compvhip_plan* plan, const uint8_t* d_in
 
 /* Device accumulator of frame f after compvhip_plan_houghsht: int32, theta-major [T][accPitch] (pitch >= R). */
 COMPVHIP_API int compvhip_plan_acc(compvhip_plan* plan, size_t frame, const int32_t** d_acc, size_t* R, size_t* T, size_t* accPitch);
+/* Copies the accumulator of frame f into a caller DEVICE buffer in the reference layout: int32 [R][outStride]
+ * (outStride >= T), i.e. acc[(barrier - rho) * outStride + t] (houghsht.cxx:430-431). */
+COMPVHIP_API int compvhip_plan_acc_export(compvhip_plan* plan, size_t frame, int32_t* d_out, size_t outStride, void* stream);
 /* Number of edge pixels per frame found by the last canny/houghsht of this plan (device int32[frames]). */
 COMPVHIP_API int compvhip_plan_edge_counts(compvhip_plan* plan, const int32_t** d_edge_counts);
 

@@ -199,16 +199,12 @@ def _plan_run(hip_ctx, frames_np, tl, th, thr, line_cap):
     plan.pipeline(d_in.data_ptr(), tl, th, thr, 0, d_edges.data_ptr(), d_lines.data_ptr(), line_cap, d_counts.data_ptr(), st)
     torch.cuda.synchronize()
     accs = []
+    _, R, T, _ = plan.acc(0)
     for f in range(n):
-        p, R, T, pitch = plan.acc(f)
-        import ctypes
-        a = torch.empty((T, pitch), dtype=torch.int32, device=dev)
+        a = torch.zeros((R, T), dtype=torch.int32, device=dev)
+        plan.acc_export(f, a.data_ptr(), T, st)     # reference layout [R][T]
         torch.cuda.synchronize()
-        # copy the plan-owned accumulator through hipMemcpy D2D
-        hip = ctypes.CDLL("libamdhip64.so")
-        hip.hipMemcpy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int]
-        assert hip.hipMemcpy(a.data_ptr(), p, T * pitch * 4, 3) == 0
-        accs.append(a[:, :R].t().contiguous().cpu().numpy())
+        accs.append(a.cpu().numpy())
     out = (d_edges.cpu().numpy(), d_lines.cpu().numpy().view(np.uint8).reshape(n, line_cap, 20), d_counts.cpu().numpy(), accs)
     plan.close()
     return out
