@@ -22,6 +22,8 @@
 #include "stencil.hpp"
 #include "kernels.hpp"
 
+#include <type_traits>
+
 namespace compvhip {
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -82,20 +84,10 @@ __device__ __forceinline__ void flood_down(const uint64_t (&W)[8], uint64_t (&S)
 	}
 }
 
-// Deposit the four 32-bit halves of the weak / strong lane masks of tile row `row` into lane `row` of the four
-// accumulators (v_writelane_b32; gfx9 allows one SGPR on the constant bus, so the lane select travels in M0).
-__device__ __forceinline__ void deposit_masks(uint64_t wm, uint64_t sm, int row, uint32_t& wlo, uint32_t& whi, uint32_t& slo, uint32_t& shi)
-{
-	asm volatile(
-		"s_mov_b32 m0, %8\n\t"
-		"v_writelane_b32 %0, %4, m0\n\t"
-		"v_writelane_b32 %1, %5, m0\n\t"
-		"v_writelane_b32 %2, %6, m0\n\t"
-		"v_writelane_b32 %3, %7, m0"
-		: "+v"(wlo), "+v"(whi), "+v"(slo), "+v"(shi)
-		: "s"((uint32_t)wm), "s"((uint32_t)(wm >> 32)), "s"((uint32_t)sm), "s"((uint32_t)(sm >> 32)), "s"(row)
-		: "m0");
-}
+// The 8 weak + 8 strong lane masks (64 bit each) of one tile row are gathered into lanes 0..31 of ONE VGPR with
+// v_writelane_b32 (constant lane selects), then stored with a single ds_write_b32: row r of the wave's LDS slab holds
+// dwords [wlo0 whi0 wlo1 whi1 ... | slo0 shi0 ...].  After the row loop every lane reads back "its" row (lane == row).
+#define COMPV_WRITELANE(vdst, sval, LANE) asm volatile("v_writelane_b32 %0, %1, " #LANE : "+v"(vdst) : "s"(sval))
 
 // ---------------------------------------------------------------------------------------------------------------
 // Kernel 1
@@ -103,7 +95,8 @@ __device__ __forceinline__ void deposit_masks(uint64_t wm, uint64_t sm, int row,
 template <bool GAP>
 __global__ __launch_bounds__(kCannyWaves * 64) void canny_tile_kernel(CannyArgs a)
 {
-	__shared__ uint32_t lds_rows[kCannyWaves][kTileH][17];
+	constexpr int kMaskPitch = 33; // 32 mask dwords per row + 1: lane==row reads are bank-conflict free
+	__shared__ uint32_t lds_masks[kCannyWaves][kTileH][kMaskPitch];
 
 	const int lane = threadIdx.x & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -119,6 +112,8 @@ __global__ __launch_bounds__(kCannyWaves * 64) void canny_tile_kernel(CannyArgs 
 
 	int tLow = a.tLow, tHigh = a.tHigh;
 	if (a.thrDev) { const int2 t = a.thrDev[frame]; tLow = t.x; tHigh = t.y; }
+	tHigh = __builtin_amdgcn_readfirstlane(tHigh);
+	const int tLow1 = __builtin_amdgcn_readfirstlane(tLow) + 1;
 
 	// columns gi = 0..9 <-> x = x0-1+gi: g is forced to 0 outside [1, W-2] (zero OUTPUT border of the convolution,
 	// compv_math_convlt.h:181-209) -- only tiles touching column 0 or W-1.. need the per-column test.
@@ -143,78 +138,115 @@ __global__ __launch_bounds__(kCannyWaves * 64) void canny_tile_kernel(CannyArgs 
 		}
 	}
 
-	Grad3State<1, 2> st;
+	// tiles whose first/last gradient rows fall on the image border rows (g forced to 0 there)
+	const bool vEdgeTile = (tileY == 0) || (y0 + kTileH + 1 >= H - 1);
+
+	Grad3Ring<1, 2> st;
 	st.reset();
-	int gU[10], gC[10];
-	bool c1[8], c2[8], ngc[8];
+	int gr[3][10];           // ring of the last three gradient-magnitude rows
+	int axr[2][8];           // ring of |gx| of the last two gradient rows (direction class is evaluated at NMS time)
+	bool ngr[2][8];          // ring of sign(gx^gy)
 #pragma unroll
-	for (int i = 0; i < 10; ++i) { gU[i] = 0; gC[i] = 0; }
+	for (int i = 0; i < 10; ++i) { gr[0][i] = 0; gr[1][i] = 0; gr[2][i] = 0; }
 #pragma unroll
-	for (int p = 0; p < 8; ++p) { c1[p] = false; c2[p] = false; ngc[p] = false; }
+	for (int p = 0; p < 8; ++p) { axr[0][p] = axr[1][p] = 0; ngr[0][p] = ngr[1][p] = false; }
 
-	uint32_t wlo[8], whi[8], slo[8], shi[8];
-#pragma unroll
-	for (int p = 0; p < 8; ++p) { wlo[p] = whi[p] = slo[p] = shi[p] = 0u; }
+	uint32_t* maskRows = &lds_masks[wave][0][0];
 
-	// input rows y0-2 .. y0+kTileH+1; the gradient of row yc = yin-1 appears when row yin is pushed, the NMS of row
-	// yc-1 one step later.
 	RowBytes nextRow = load_row(in + (size_t)min(max(y0 - 2, 0), H - 1) * S, x0, S);
-	for (int it = 0; it < kTileH + 4; ++it) {
+
+	// One row step.  Input rows y0-2 .. y0+kTileH+1 are pushed; pushing row yin yields the gradient of row yc = yin-1
+	// and allows the NMS of row yo = yc-1.  PH = it mod 6 selects the ring slots at compile time.
+	auto step = [&](auto phase, int it) {
+		constexpr int PH = decltype(phase)::value;
+		constexpr int gNew = PH % 3, gMid = (PH + 2) % 3, gOld = (PH + 1) % 3;
+		constexpr int aNew = PH % 2, aMid = (PH + 1) % 2;
 		const int yin = y0 - 2 + it;
 		const RowBytes rb = nextRow;
 		// software prefetch: the next row's loads are in flight while this row is processed
 		nextRow = load_row(in + (size_t)min(max(yin + 1, 0), H - 1) * S, x0, S);
-		int v[12];
-		unpack12(rb, v);
-		GradRow gr;
-		st.push(v, gr);
+		int (&gD)[10] = gr[gNew];
+		const int (&gC)[10] = gr[gMid];
+		const int (&gU)[10] = gr[gOld];
+		st.template push<PH & 1>(rb, gD, axr[aNew], ngr[aNew]);
 
 		const int yc = yin - 1;
-		int gD[10];
-		const bool rowok = (yc >= 1) && (yc <= H - 2);
+		if (vEdgeTile) {
+			if (!((yc >= 1) && (yc <= H - 2))) {
 #pragma unroll
-		for (int gi = 0; gi < 10; ++gi) gD[gi] = rowok ? (gr.ax[gi] + gr.ay[gi]) : 0;
+				for (int gi = 0; gi < 10; ++gi) gD[gi] = 0;
+			}
+		}
 		if (edgeTile) {
 #pragma unroll
 			for (int gi = 0; gi < 10; ++gi) gD[gi] = ((colok >> gi) & 1u) ? gD[gi] : 0;
 		}
 
 		// NMS + classification of row yo = yc-1 (rows gU = yo-1, gC = yo, gD = yo+1)
-		const int yo = yc - 1;
-		const int rr = yo - y0;
+		const int rr = yc - 1 - y0;
 		if (rr >= 0 && rr < kTileH) {
+			uint32_t rowv = 0;
 #pragma unroll
 			for (int p = 0; p < 8; ++p) {
 				const int gi = p + 1;
-				const int g = gC[gi];
+				const int gc = gC[gi];
+				// direction class (constants canny_dete.h:58-61: tan(pi/8), tan(3pi/8) in Q16; 158217 = 27145 + 2^17)
+				const uint32_t ax = (uint32_t)axr[aMid][p];
+				const uint32_t ays = ((uint32_t)gc - ax) << 16;               // |gy| << 16
+				const uint32_t t1 = __umul24(ax, 27145u);
+				const bool k1 = ays < t1;
+				const bool k2 = ays < t1 + (ax << 17);
 				const int mh = max(gC[gi - 1], gC[gi + 1]);
 				const int mv = max(gU[gi], gD[gi]);
 				const int md1 = max(gU[gi - 1], gD[gi + 1]);
 				const int md2 = max(gD[gi - 1], gU[gi + 1]);
-				int m = c1[p] ? mh : (c2[p] ? (ngc[p] ? md2 : md1) : mv);
+				int m = k1 ? mh : (k2 ? (ngr[aMid][p] ? md2 : md1) : mv);
 				bool seedok = true;
 				if (GAP) {
 					seedok = (cov >> p) & 1u;
 					m = seedok ? m : 0;
 				}
-				const bool weak = (g > tLow) && (g >= m);
-				const bool strong = weak && (g > tHigh) && seedok;
-				const uint64_t wm = __builtin_amdgcn_ballot_w64(weak);
-				const uint64_t sm = __builtin_amdgcn_ballot_w64(strong);
-				deposit_masks(wm, sm, rr, wlo[p], whi[p], slo[p], shi[p]);
+				// weak = g > tLow && g >= m  <=>  g >= max(m, tLow+1);  strong = weak && g > tHigh [&& covered]
+				const uint64_t wm = mask_ge_i32(gc, max(m, tLow1));
+				uint64_t sm = wm & mask_gt_i32_s(gc, tHigh);
+				if (GAP) sm &= __builtin_amdgcn_ballot_w64(seedok);
+				const uint32_t w0 = (uint32_t)wm, w1 = (uint32_t)(wm >> 32), s0 = (uint32_t)sm, s1 = (uint32_t)(sm >> 32);
+				switch (p) { // lane selects must be literal
+				case 0: COMPV_WRITELANE(rowv, w0, 0); COMPV_WRITELANE(rowv, w1, 1); COMPV_WRITELANE(rowv, s0, 16); COMPV_WRITELANE(rowv, s1, 17); break;
+				case 1: COMPV_WRITELANE(rowv, w0, 2); COMPV_WRITELANE(rowv, w1, 3); COMPV_WRITELANE(rowv, s0, 18); COMPV_WRITELANE(rowv, s1, 19); break;
+				case 2: COMPV_WRITELANE(rowv, w0, 4); COMPV_WRITELANE(rowv, w1, 5); COMPV_WRITELANE(rowv, s0, 20); COMPV_WRITELANE(rowv, s1, 21); break;
+				case 3: COMPV_WRITELANE(rowv, w0, 6); COMPV_WRITELANE(rowv, w1, 7); COMPV_WRITELANE(rowv, s0, 22); COMPV_WRITELANE(rowv, s1, 23); break;
+				case 4: COMPV_WRITELANE(rowv, w0, 8); COMPV_WRITELANE(rowv, w1, 9); COMPV_WRITELANE(rowv, s0, 24); COMPV_WRITELANE(rowv, s1, 25); break;
+				case 5: COMPV_WRITELANE(rowv, w0, 10); COMPV_WRITELANE(rowv, w1, 11); COMPV_WRITELANE(rowv, s0, 26); COMPV_WRITELANE(rowv, s1, 27); break;
+				case 6: COMPV_WRITELANE(rowv, w0, 12); COMPV_WRITELANE(rowv, w1, 13); COMPV_WRITELANE(rowv, s0, 28); COMPV_WRITELANE(rowv, s1, 29); break;
+				default: COMPV_WRITELANE(rowv, w0, 14); COMPV_WRITELANE(rowv, w1, 15); COMPV_WRITELANE(rowv, s0, 30); COMPV_WRITELANE(rowv, s1, 31); break;
+				}
 			}
+			if (lane < 32) maskRows[rr * kMaskPitch + lane] = rowv;
 		}
+	};
 
-		// roll: direction class of the new centre row (constants canny_dete.h:58-61: tan(pi/8), tan(3pi/8) in Q16)
-#pragma unroll
-		for (int gi = 0; gi < 10; ++gi) { gU[gi] = gC[gi]; gC[gi] = gD[gi]; }
+	static_assert((kTileH + 4) % 6 == 2, "row loop is unrolled by 6 with a 2-step tail");
+	int it = 0;
+	for (; it < kTileH + 4 - 2; it += 6) {
+		step(std::integral_constant<int, 0>{}, it);
+		step(std::integral_constant<int, 1>{}, it + 1);
+		step(std::integral_constant<int, 2>{}, it + 2);
+		step(std::integral_constant<int, 3>{}, it + 3);
+		step(std::integral_constant<int, 4>{}, it + 4);
+		step(std::integral_constant<int, 5>{}, it + 5);
+	}
+	step(std::integral_constant<int, 0>{}, it);
+	step(std::integral_constant<int, 1>{}, it + 1);
+
+	// lane == row: fetch this lane's row of masks (rows beyond the image are all-zero: g was forced to 0 there)
+	uint32_t wlo[8], whi[8], slo[8], shi[8];
+	{
+		const uint32_t* mr = maskRows + lane * kMaskPitch;
 #pragma unroll
 		for (int p = 0; p < 8; ++p) {
-			const uint32_t ax = (uint32_t)gr.ax[p + 1], ay = (uint32_t)gr.ay[p + 1];
-			const uint32_t ays = ay << 16;
-			c1[p] = ays < __umul24(ax, 27145u);
-			c2[p] = ays < __umul24(ax, 158217u);
-			ngc[p] = gr.ng[p + 1];
+			wlo[p] = mr[2 * p]; whi[p] = mr[2 * p + 1];
+			slo[p] = mr[16 + 2 * p]; shi[p] = mr[16 + 2 * p + 1];
 		}
 	}
 
@@ -267,17 +299,17 @@ __global__ __launch_bounds__(kCannyWaves * 64) void canny_tile_kernel(CannyArgs 
 	// beyond the wave's own program order)
 #pragma unroll
 	for (int m = 0; m < 8; ++m) {
-		lds_rows[wave][lane][2 * m] = (uint32_t)Em[m];
-		lds_rows[wave][lane][2 * m + 1] = (uint32_t)(Em[m] >> 32);
+		lds_masks[wave][lane][2 * m] = (uint32_t)Em[m];
+		lds_masks[wave][lane][2 * m + 1] = (uint32_t)(Em[m] >> 32);
 	}
 	__builtin_amdgcn_wave_barrier();
 	__builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): LDS writes of this wave have landed
 	uint8_t* __restrict__ out = a.out + (size_t)frame * a.outFrameStride;
-	const uint8_t* lb = reinterpret_cast<const uint8_t*>(&lds_rows[wave][0][0]);
+	const uint8_t* lb = reinterpret_cast<const uint8_t*>(&lds_masks[wave][0][0]);
 	if (x0 + 8 <= a.So) {
 		const int rows = min(kTileH, H - y0);
 		for (int r = 0; r < rows; ++r) {
-			const uint32_t b = lb[r * 17 * 4 + lane];
+			const uint32_t b = lb[r * kMaskPitch * 4 + lane];
 			uint2 o;
 			o.x = spread4(b & 0xfu) * 0xffu;
 			o.y = spread4(b >> 4) * 0xffu;

@@ -133,21 +133,24 @@ constexpr int kStageCols = (kShtVoteThreads / 64) * 8;   // 128 edges per lane-r
 constexpr int kStageEdges = 64 * kStageCols;             // 8192 edges per stage
 constexpr int kStagePitch = kStageCols + 1;              // +1: lane-strided reads hit 64 different banks
 
-size_t sht_vote_lds_bytes(int R) { return ((size_t)R * 2 + (size_t)64 * kStagePitch) * sizeof(uint32_t); }
+size_t sht_vote_lds_bytes(int R) { return ((size_t)((R + 31) & ~31) * 2 + (size_t)64 * kStagePitch) * sizeof(uint32_t); }
 
 __global__ __launch_bounds__(kShtVoteThreads) void sht_vote_kernel(ShtArgs a)
 {
 	extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
 	const int R = a.R;
-	uint32_t* hist = smem;                 // [R][2]: (t0,t0+1) and (t0+2,t0+3) u16 pairs
-	uint32_t* stage = smem + 2 * R;        // [64][kStagePitch]
+	// [2][Rp]: pair 0 = thetas (t0,t0+1), pair 1 = (t0+2,t0+3) as u16 halves.  Pair-major so that one ds_add_u32
+	// instruction (fixed pair, 64 different rho) can spread over all 32 banks ([R][2] would only ever touch 16).
+	const int Rp = (R + 31) & ~31;
+	uint32_t* hist = smem;
+	uint32_t* stage = smem + 2 * Rp;       // [64][kStagePitch]
 	const int frame = blockIdx.z;
 	const int shard = blockIdx.y;
 	const int t0 = blockIdx.x * kShtThetaPerGroup;
 	const int tid = threadIdx.x;
 	const int lane = tid & 63, wave = tid >> 6;
 
-	for (int i = tid; i < 2 * R; i += kShtVoteThreads) hist[i] = 0u;
+	for (int i = tid; i < 2 * Rp; i += kShtVoteThreads) hist[i] = 0u;
 
 	int cq[kShtThetaPerGroup], sq[kShtThetaPerGroup];
 #pragma unroll
@@ -207,7 +210,7 @@ __global__ __launch_bounds__(kShtVoteThreads) void sht_vote_kernel(ShtArgs a)
 				if (k < nvalid) {
 					const int rho = (__mul24(x, cq[k]) + __mul24(y, sq[k])) >> 16;
 					const int idx = barrier - rho;
-					atomicAdd(&hist[idx * 2 + (k >> 1)], (k & 1) ? 0x10000u : 1u);
+					atomicAdd(&hist[(k >> 1) * Rp + idx], (k & 1) ? 0x10000u : 1u);
 				}
 			}
 		}
@@ -216,7 +219,7 @@ __global__ __launch_bounds__(kShtVoteThreads) void sht_vote_kernel(ShtArgs a)
 
 	int32_t* __restrict__ acc = a.acc + (size_t)frame * a.accFrameStride + (size_t)t0 * a.accPitch;
 	for (int r = tid; r < R; r += kShtVoteThreads) {
-		const uint32_t v0 = hist[2 * r], v1 = hist[2 * r + 1];
+		const uint32_t v0 = hist[r], v1 = hist[Rp + r];
 		const int c[4] = { (int)(v0 & 0xffffu), (int)(v0 >> 16), (int)(v1 & 0xffffu), (int)(v1 >> 16) };
 #pragma unroll
 		for (int k = 0; k < kShtThetaPerGroup; ++k) {
@@ -235,7 +238,7 @@ __global__ __launch_bounds__(kShtVoteThreads) void sht_vote_kernel(ShtArgs a)
 // descending radix sort over all frames yields frame-major, strength-descending, (row,col)-ascending order.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kNmsThreads = 256;
-constexpr int kNmsRowsPerThread = 4;
+constexpr int kNmsRowsPerThread = 4;   // 4 consecutive rho rows = one 16-byte load (accPitch is a multiple of 64)
 
 __global__ __launch_bounds__(kNmsThreads) void sht_nms_kernel(ShtArgs a)
 {
@@ -246,16 +249,19 @@ __global__ __launch_bounds__(kNmsThreads) void sht_nms_kernel(ShtArgs a)
 	const int32_t* __restrict__ acc = a.acc + (size_t)frame * a.accFrameStride;
 	const size_t p = a.accPitch;
 	const bool nmsCol = (c >= 1 && c <= a.nmsLastCol);
-	uint64_t keys[kNmsRowsPerThread];
+	uint64_t keys[kNmsRowsPerThread] = { 0, 0, 0, 0 }; // 0 = no line in this slot (a real key always has strength > 0)
 	int cnt = 0;
 	const uint64_t frameTag = (uint64_t)(a.frames - 1 - frame) << (16 + a.cellBits);
 	const uint32_t cellMask = (1u << a.cellBits) - 1u;
+	const int r0 = (blockIdx.x * kNmsThreads + threadIdx.x) * kNmsRowsPerThread;
+	int4 v4 = make_int4(0, 0, 0, 0);
+	if (r0 < a.accPitch) v4 = *reinterpret_cast<const int4*>(acc + (size_t)c * p + r0); // rows >= R read the zeroed/unused pitch tail
+	const int vv[4] = { v4.x, v4.y, v4.z, v4.w };
 #pragma unroll
 	for (int k = 0; k < kNmsRowsPerThread; ++k) {
-		const int r = (blockIdx.x * kNmsRowsPerThread + k) * kNmsThreads + threadIdx.x;
-		if (r >= a.R) continue;
-		const int v = acc[(size_t)c * p + r];
-		if (v <= a.threshold) continue;
+		const int r = r0 + k;
+		const int v = vv[k];
+		if (r >= a.R || v <= a.threshold) continue;
 		if (nmsCol && r >= 1 && r <= a.R - 2) {
 			const int32_t* l = acc + (size_t)(c - 1) * p + r;
 			const int32_t* m = acc + (size_t)c * p + r;
@@ -263,7 +269,8 @@ __global__ __launch_bounds__(kNmsThreads) void sht_nms_kernel(ShtArgs a)
 			if (l[-1] > v || l[0] > v || l[1] > v || m[-1] > v || m[1] > v || h[-1] > v || h[0] > v || h[1] > v) continue;
 		}
 		const uint32_t cell = (uint32_t)r * (uint32_t)a.T + (uint32_t)c;
-		keys[cnt++] = frameTag | ((uint64_t)(uint32_t)v << a.cellBits) | (uint64_t)(cellMask - cell);
+		keys[k] = frameTag | ((uint64_t)(uint32_t)v << a.cellBits) | (uint64_t)(cellMask - cell);
+		++cnt;
 	}
 	int incl = cnt;
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -286,8 +293,12 @@ __global__ __launch_bounds__(kNmsThreads) void sht_nms_kernel(ShtArgs a)
 	__syncthreads();
 	size_t pos = (size_t)s_base + wbase + (incl - cnt);
 	uint64_t* __restrict__ dst = a.lineKeys + (size_t)frame * a.lineCap;
-	for (int k = 0; k < cnt; ++k, ++pos) {
-		if (pos < a.lineCap) dst[pos] = keys[k];
+#pragma unroll
+	for (int k = 0; k < kNmsRowsPerThread; ++k) {
+		if (keys[k]) {
+			if (pos < a.lineCap) dst[pos] = keys[k];
+			++pos;
+		}
 	}
 }
 

@@ -16,6 +16,8 @@
 #include "stencil.hpp"
 #include "kernels.hpp"
 
+#include <type_traits>
+
 namespace compvhip {
 
 constexpr int kEdgeWaves = 4;
@@ -51,24 +53,24 @@ __global__ __launch_bounds__(kEdgeWaves * 64) void edge_dete_kernel(EdgeDeteArgs
 		scale = __fdiv_rn(255.f, (float)gmax);
 	}
 
-	Grad3State<A, B> st;
+	Grad3Ring<A, B> st;
 	st.reset();
 	unsigned int vmax = 0;
-	for (int it = 0; it < kTileH + 2; ++it) {
+	auto step = [&](auto phase, int it) {
+		constexpr int PH = decltype(phase)::value;
 		const int yin = y0 - 1 + it;
 		const int yl = min(max(yin, 0), H - 1);
 		const RowBytes rb = load_row(in + (size_t)yl * S, x0, S);
-		int v[12];
-		unpack12(rb, v);
-		GradRow gr;
-		st.push(v, gr);
+		int gg[10], ax[8];
+		bool ng[8];
+		st.template push<PH>(rb, gg, ax, ng);
 		const int yc = yin - 1;
-		if (it < 2 || yc >= H) continue;
+		if (it < 2 || yc >= H) return;
 		const bool rowok = (yc >= 1) && (yc <= H - 2);
 		uint32_t o0 = 0, o1 = 0;
 #pragma unroll
 		for (int p = 0; p < 8; ++p) {
-			int g = gr.ax[p + 1] + gr.ay[p + 1];
+			int g = gg[p + 1];
 			g = min(g, 65535); // adds_epu16
 			g = (rowok && ((colok >> p) & 1u)) ? g : 0;
 			if (!SCALE) {
@@ -84,6 +86,11 @@ __global__ __launch_bounds__(kEdgeWaves * 64) void edge_dete_kernel(EdgeDeteArgs
 		if (SCALE) {
 			if (x0 + 8 <= a.So) *reinterpret_cast<uint2*>(out + (size_t)yc * a.So + x0) = make_uint2(o0, o1);
 		}
+	};
+	static_assert((kTileH + 2) % 2 == 0, "row loop is unrolled by 2");
+	for (int it = 0; it < kTileH + 2; it += 2) {
+		step(std::integral_constant<int, 0>{}, it);
+		step(std::integral_constant<int, 1>{}, it + 1);
 	}
 	if (!SCALE) {
 		for (int o = 32; o > 0; o >>= 1) vmax = max(vmax, (unsigned int)__shfl_down(vmax, o));

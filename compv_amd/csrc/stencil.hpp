@@ -29,23 +29,45 @@ __device__ __forceinline__ int absdiff(int a, int b)
 	asm("v_sad_u32 %0, %1, %2, 0" : "=v"(d) : "v"(a), "v"(b));
 	return d;
 }
+// Lane masks straight from VOPC compares (the C++ route through bool + ballot costs a v_cndmask + v_cmp_ne per mask).
+__device__ __forceinline__ uint64_t mask_ge_i32(int a, int b)
+{
+	uint64_t m;
+	asm("v_cmp_ge_i32_e64 %0, %1, %2" : "=s"(m) : "v"(a), "v"(b));
+	return m;
+}
+__device__ __forceinline__ uint64_t mask_gt_i32_s(int a, int sb) // a > sb, sb wave-uniform
+{
+	uint64_t m;
+	asm("v_cmp_lt_i32_e64 %0, %2, %1" : "=s"(m) : "v"(a), "s"(sb));
+	return m;
+}
+__device__ __forceinline__ int absdiff_acc(int a, int b, int c)
+{
+	int d;
+	asm("v_sad_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); // |a-b| + c
+	return d;
+}
 
 // 16 input bytes around the lane's 8 pixels: columns x0-4 .. x0+11
 struct RowBytes {
 	uint32_t l, m0, m1, r;
 };
 
-// Loads never leave [rowptr, rowptr + S): S % 8 == 0 is a precondition of every device entry point.
+// Loads never leave [rowptr, rowptr + S): S % 8 == 0 is a precondition of every device entry point.  Addresses are
+// clamped instead of predicated (no divergent branches): a lane whose 8 pixels or 4-byte halos fall outside the row
+// reads other in-row bytes, which only ever feed gradient columns x <= 0 or x >= W-1 -- those are forced to zero by
+// the callers' column masks (zero OUTPUT border, compv_math_convlt.h:181-209).
 __device__ __forceinline__ RowBytes load_row(const uint8_t* __restrict__ rowptr, int x0, int S)
 {
 	RowBytes rb;
-	rb.l = rb.m0 = rb.m1 = rb.r = 0u;
-	if (x0 < S) {
-		const uint2 m = *reinterpret_cast<const uint2*>(rowptr + x0);
-		rb.m0 = m.x; rb.m1 = m.y;
-		if (x0 >= 4) rb.l = *reinterpret_cast<const uint32_t*>(rowptr + x0 - 4);
-		if (x0 + 12 <= S) rb.r = *reinterpret_cast<const uint32_t*>(rowptr + x0 + 8);
-	}
+	const int xm = min(x0, S - 8);
+	const int xl = max(xm - 4, 0);
+	const int xr = min(xm + 8, S - 4);
+	const uint2 m = *reinterpret_cast<const uint2*>(rowptr + xm);
+	rb.m0 = m.x; rb.m1 = m.y;
+	rb.l = *reinterpret_cast<const uint32_t*>(rowptr + xl);
+	rb.r = *reinterpret_cast<const uint32_t*>(rowptr + xr);
 	return rb;
 }
 
@@ -58,49 +80,52 @@ __device__ __forceinline__ void unpack12(const RowBytes& rb, int (&v)[12])
 	v[10] = rb.r & 0xff; v[11] = (rb.r >> 8) & 0xff;
 }
 
-// Gradient row for the 10 columns gi = 0..9  <->  x = x0 - 1 + gi (8 own pixels + one neighbour each side).
-struct GradRow {
-	int ax[10];   // |gx|
-	int ay[10];   // |gy|
-	bool ng[10];  // (gx ^ gy) < 0
-};
+// Gradient columns gi = 0..9  <->  x = x0 - 1 + gi (8 own pixels + one neighbour each side).
 
 // Rolling vertical state of the separable 3x3 operator with smoothing weights (A,B,A) and derivative (-1,0,1).
+// The two-row rings are indexed with the compile-time phase PH = (row index) mod 2, so a row loop unrolled by an
+// even factor needs no register-to-register copies to advance the window.
 template <int A, int B>
-struct Grad3State {
-	int P[12];    // A*I[y-2] + B*I[y-1]
-	int A1[12];   // I[y-1]
-	int hyA[10];  // hy[y-1]
-	int hyB[10];  // hy[y-2]
+struct Grad3Ring {
+	int vr[2][12];   // unpacked input rows y-1 / y-2 (ring)
+	int P[12];       // A*I[y-2] + B*I[y-1]
+	int hy[2][10];   // hy[y-1] / hy[y-2] (ring)
 
 	__device__ __forceinline__ void reset()
 	{
 #pragma unroll
-		for (int j = 0; j < 12; ++j) { P[j] = 0; A1[j] = 0; }
+		for (int j = 0; j < 12; ++j) { P[j] = 0; vr[0][j] = 0; vr[1][j] = 0; }
 #pragma unroll
-		for (int j = 0; j < 10; ++j) { hyA[j] = 0; hyB[j] = 0; }
+		for (int j = 0; j < 10; ++j) { hy[0][j] = 0; hy[1][j] = 0; }
 	}
 
-	// Push input row y (v = its 12 unpacked columns); returns the gradient of row y-1 (valid once rows y-2..y were pushed).
-	__device__ __forceinline__ void push(const int (&v)[12], GradRow& out)
+	// Push input row y (phase PH = parity of the push count); yields the gradient of row y-1 (valid once rows y-2..y were
+	// pushed): g[gi] = |gx|+|gy| for the 10 columns, ax[p] = |gx| and ng[p] = ((gx ^ gy) < 0) for the 8 own pixels.
+	template <int PH>
+	__device__ __forceinline__ void push(const RowBytes& rb, int (&g)[10], int (&axo)[8], bool (&ng)[8])
 	{
+		int (&cur)[12] = vr[PH & 1];
+		const int (&prev)[12] = vr[(PH + 1) & 1];
+		unpack12(rb, cur);
 		int C[12];
 #pragma unroll
 		for (int j = 0; j < 12; ++j) {
-			C[j] = P[j] + A * v[j];
-			P[j] = A * A1[j] + B * v[j];
-			A1[j] = v[j];
+			C[j] = P[j] + A * cur[j];
+			P[j] = A * prev[j] + B * cur[j];
 		}
+		int (&hyTop)[10] = hy[PH & 1]; // holds hy[y-2]; overwritten with hy[y] below
 #pragma unroll
 		for (int gi = 0; gi < 10; ++gi) {
-			const int hyN = A * (v[gi] + v[gi + 2]) + B * v[gi + 1];
+			const int hyN = A * (cur[gi] + cur[gi + 2]) + B * cur[gi + 1];
 			const int right = C[gi + 2], left = C[gi];
-			const int top = hyB[gi];
-			out.ax[gi] = absdiff(right, left);
-			out.ay[gi] = absdiff(hyN, top);
-			out.ng[gi] = (right < left) != (hyN < top);
-			hyB[gi] = hyA[gi];
-			hyA[gi] = hyN;
+			const int top = hyTop[gi];
+			const int ax = absdiff(right, left);
+			g[gi] = absdiff_acc(hyN, top, ax);          // |gy| + |gx|
+			if (gi >= 1 && gi <= 8) {
+				axo[gi - 1] = ax;
+				ng[gi - 1] = (right < left) != (hyN < top);
+			}
+			hyTop[gi] = hyN;
 		}
 	}
 };
