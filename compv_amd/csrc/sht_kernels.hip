@@ -128,12 +128,15 @@ __global__ __launch_bounds__(kCompactThreads) void sht_compact_kernel(ShtArgs a)
 // ---------------------------------------------------------------------------------------------------------------
 // voting
 // ---------------------------------------------------------------------------------------------------------------
-// LDS: [R][2] packed u16 counters + a staging area of kStageEdges edges laid out [64][kStageCols+1]
-constexpr int kStageCols = (kShtVoteThreads / 64) * 8;   // 128 edges per lane-row
-constexpr int kStageEdges = 64 * kStageCols;             // 8192 edges per stage
-constexpr int kStagePitch = kStageCols + 1;              // +1: lane-strided reads hit 64 different banks
+// LDS: two [Rp] arrays of packed u16 counter pairs + a double-buffered staging area of kStageEdges edges laid out
+// [64][kStageCols+1] (the +1 makes both the coalesced row-major fill and the lane==row reads bank-conflict free).
+constexpr int kVoteWaves = kShtVoteThreads / 64;         // 16
+constexpr int kEdgesPerThread = 4;                       // per stage
+constexpr int kStageCols = kVoteWaves * kEdgesPerThread; // 64 edges per lane-row
+constexpr int kStageEdges = 64 * kStageCols;             // 4096 edges per stage
+constexpr int kStagePitch = kStageCols + 1;
 
-size_t sht_vote_lds_bytes(int R) { return ((size_t)((R + 31) & ~31) * 2 + (size_t)64 * kStagePitch) * sizeof(uint32_t); }
+size_t sht_vote_lds_bytes(int R) { return ((size_t)((R + 31) & ~31) * 2 + (size_t)2 * 64 * kStagePitch) * sizeof(uint32_t); }
 
 __global__ __launch_bounds__(kShtVoteThreads) void sht_vote_kernel(ShtArgs a)
 {
@@ -143,7 +146,7 @@ __global__ __launch_bounds__(kShtVoteThreads) void sht_vote_kernel(ShtArgs a)
 	// instruction (fixed pair, 64 different rho) can spread over all 32 banks ([R][2] would only ever touch 16).
 	const int Rp = (R + 31) & ~31;
 	uint32_t* hist = smem;
-	uint32_t* stage = smem + 2 * Rp;       // [64][kStagePitch]
+	uint32_t* stage = smem + 2 * Rp;       // [2][64][kStagePitch]
 	const int frame = blockIdx.z;
 	const int shard = blockIdx.y;
 	const int t0 = blockIdx.x * kShtThetaPerGroup;
@@ -169,40 +172,42 @@ __global__ __launch_bounds__(kShtVoteThreads) void sht_vote_kernel(ShtArgs a)
 	const int barrier = a.barrier;
 	const int nstages = (cnt + kStageEdges - 1) / kStageEdges;
 
-	// stage s: thread tid fetches edges [s*kStageEdges + tid*8, +8) with two coalesced 16-byte loads ...
-	auto fetch = [&](int s, uint32_t (&e)[8]) {
-		const int base = s * kStageEdges + tid * 8;
+	// stage s: element j = k*1024 + tid (k = 0..3) -> coalesced dword loads, parked at [j / kStageCols][j % kStageCols]
+	auto fetch = [&](int s, uint32_t (&e)[kEdgesPerThread]) {
+		const int base = s * kStageEdges + tid;
 #pragma unroll
-		for (int k = 0; k < 8; ++k) e[k] = 0xffffffffu;
-		if (base + 8 <= cnt && ((reinterpret_cast<uintptr_t>(edges + base) & 15) == 0)) {
-			const uint4 v0 = *reinterpret_cast<const uint4*>(edges + base);
-			const uint4 v1 = *reinterpret_cast<const uint4*>(edges + base + 4);
-			e[0] = v0.x; e[1] = v0.y; e[2] = v0.z; e[3] = v0.w; e[4] = v1.x; e[5] = v1.y; e[6] = v1.z; e[7] = v1.w;
+		for (int k = 0; k < kEdgesPerThread; ++k) {
+			const int j = base + k * kShtVoteThreads;
+			e[k] = (j < cnt) ? edges[j] : 0xffffffffu;
 		}
-		else {
+	};
+	auto park = [&](int buf, const uint32_t (&e)[kEdgesPerThread]) {
+		uint32_t* dst = stage + buf * (64 * kStagePitch);
 #pragma unroll
-			for (int k = 0; k < 8; ++k) if (base + k < cnt) e[k] = edges[base + k];
+		for (int k = 0; k < kEdgesPerThread; ++k) {
+			const int j = k * kShtVoteThreads + tid;
+			dst[(j / kStageCols) * kStagePitch + (j % kStageCols)] = e[k];
 		}
 	};
 
-	uint32_t nxt[8];
-	if (nstages > 0) fetch(0, nxt);
+	// software pipeline: while stage s is voted from LDS buffer s&1, stage s+1 is parked into the other buffer and the
+	// global loads of stage s+2 are in flight -- one barrier per stage, a whole stage of latency budget per load
+	uint32_t regs[kEdgesPerThread];
+	if (nstages > 0) { fetch(0, regs); park(0, regs); }
+	if (nstages > 1) fetch(1, regs);
+	__syncthreads(); // histogram zeroed, stage 0 parked
 	for (int s = 0; s < nstages; ++s) {
-		__syncthreads(); // histogram zeroed / previous stage fully voted
-		// ... and parks them so that edge j of the stage sits at [j / kStageCols][j % kStageCols]
-		{
-			const int j = tid * 8;
-			uint32_t* dst = stage + (j / kStageCols) * kStagePitch + (j % kStageCols);
+		// lane l of wave w votes edges [l][w*4 .. w*4+3]: the 64 lanes of a wave are kStageCols raster positions apart, so
+		// raster neighbours (same rho around theta = 90 deg) never share an instruction
+		const uint32_t* src = stage + (s & 1) * (64 * kStagePitch) + lane * kStagePitch + wave * kEdgesPerThread;
+		uint32_t mine[kEdgesPerThread];
 #pragma unroll
-			for (int k = 0; k < 8; ++k) dst[k] = nxt[k];
-		}
-		__syncthreads();
-		if (s + 1 < nstages) fetch(s + 1, nxt); // in flight while this stage votes
-		// lane l of wave w votes edges [l][w*8 .. w*8+7]: the 64 lanes of a wave are kStageCols raster positions apart
-		const uint32_t* src = stage + lane * kStagePitch + wave * 8;
+		for (int i = 0; i < kEdgesPerThread; ++i) mine[i] = src[i];
+		if (s + 1 < nstages) park((s + 1) & 1, regs);
+		if (s + 2 < nstages) fetch(s + 2, regs);
 #pragma unroll
-		for (int i = 0; i < 8; ++i) {
-			const uint32_t xy = src[i];
+		for (int i = 0; i < kEdgesPerThread; ++i) {
+			const uint32_t xy = mine[i];
 			if (xy == 0xffffffffu) continue;
 			const int x = (int)(xy & 0xffffu), y = (int)(xy >> 16);
 #pragma unroll
@@ -214,8 +219,8 @@ __global__ __launch_bounds__(kShtVoteThreads) void sht_vote_kernel(ShtArgs a)
 				}
 			}
 		}
+		__syncthreads();
 	}
-	__syncthreads();
 
 	int32_t* __restrict__ acc = a.acc + (size_t)frame * a.accFrameStride + (size_t)t0 * a.accPitch;
 	for (int r = tid; r < R; r += kShtVoteThreads) {
@@ -238,7 +243,8 @@ __global__ __launch_bounds__(kShtVoteThreads) void sht_vote_kernel(ShtArgs a)
 // descending radix sort over all frames yields frame-major, strength-descending, (row,col)-ascending order.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kNmsThreads = 256;
-constexpr int kNmsRowsPerThread = 4;   // 4 consecutive rho rows = one 16-byte load (accPitch is a multiple of 64)
+constexpr int kNmsVec = 4;             // independent 16-byte loads in flight per thread
+constexpr int kNmsRowsPerThread = 4 * kNmsVec;
 
 __global__ __launch_bounds__(kNmsThreads) void sht_nms_kernel(ShtArgs a)
 {
@@ -249,28 +255,38 @@ __global__ __launch_bounds__(kNmsThreads) void sht_nms_kernel(ShtArgs a)
 	const int32_t* __restrict__ acc = a.acc + (size_t)frame * a.accFrameStride;
 	const size_t p = a.accPitch;
 	const bool nmsCol = (c >= 1 && c <= a.nmsLastCol);
-	uint64_t keys[kNmsRowsPerThread] = { 0, 0, 0, 0 }; // 0 = no line in this slot (a real key always has strength > 0)
+	uint64_t keys[kNmsRowsPerThread];
 	int cnt = 0;
 	const uint64_t frameTag = (uint64_t)(a.frames - 1 - frame) << (16 + a.cellBits);
 	const uint32_t cellMask = (1u << a.cellBits) - 1u;
-	const int r0 = (blockIdx.x * kNmsThreads + threadIdx.x) * kNmsRowsPerThread;
-	int4 v4 = make_int4(0, 0, 0, 0);
-	if (r0 < a.accPitch) v4 = *reinterpret_cast<const int4*>(acc + (size_t)c * p + r0); // rows >= R read the zeroed/unused pitch tail
-	const int vv[4] = { v4.x, v4.y, v4.z, v4.w };
+	// thread t of the block reads rows [base + v*1024 + 4t, +4) for v = 0..kNmsVec-1 (each wave load = 1 KiB contiguous)
+	const int base = blockIdx.x * (kNmsThreads * kNmsRowsPerThread) + threadIdx.x * 4;
+	int4 v4[kNmsVec];
 #pragma unroll
-	for (int k = 0; k < kNmsRowsPerThread; ++k) {
-		const int r = r0 + k;
-		const int v = vv[k];
-		if (r >= a.R || v <= a.threshold) continue;
-		if (nmsCol && r >= 1 && r <= a.R - 2) {
-			const int32_t* l = acc + (size_t)(c - 1) * p + r;
-			const int32_t* m = acc + (size_t)c * p + r;
-			const int32_t* h = acc + (size_t)(c + 1) * p + r;
-			if (l[-1] > v || l[0] > v || l[1] > v || m[-1] > v || m[1] > v || h[-1] > v || h[0] > v || h[1] > v) continue;
+	for (int v = 0; v < kNmsVec; ++v) {
+		const int r0 = base + v * (kNmsThreads * 4);
+		v4[v] = make_int4(0, 0, 0, 0);
+		if (r0 < a.accPitch) v4[v] = *reinterpret_cast<const int4*>(acc + (size_t)c * p + r0); // the pitch tail (>= R) is never used
+	}
+#pragma unroll
+	for (int v = 0; v < kNmsVec; ++v) {
+		const int vv[4] = { v4[v].x, v4[v].y, v4[v].z, v4[v].w };
+#pragma unroll
+		for (int k = 0; k < 4; ++k) {
+			const int r = base + v * (kNmsThreads * 4) + k;
+			const int val = vv[k];
+			keys[v * 4 + k] = 0; // 0 = no line in this slot (a real key always has strength > 0)
+			if (r >= a.R || val <= a.threshold) continue;
+			if (nmsCol && r >= 1 && r <= a.R - 2) {
+				const int32_t* l = acc + (size_t)(c - 1) * p + r;
+				const int32_t* m = acc + (size_t)c * p + r;
+				const int32_t* h = acc + (size_t)(c + 1) * p + r;
+				if (l[-1] > val || l[0] > val || l[1] > val || m[-1] > val || m[1] > val || h[-1] > val || h[0] > val || h[1] > val) continue;
+			}
+			const uint32_t cell = (uint32_t)r * (uint32_t)a.T + (uint32_t)c;
+			keys[v * 4 + k] = frameTag | ((uint64_t)(uint32_t)val << a.cellBits) | (uint64_t)(cellMask - cell);
+			++cnt;
 		}
-		const uint32_t cell = (uint32_t)r * (uint32_t)a.T + (uint32_t)c;
-		keys[k] = frameTag | ((uint64_t)(uint32_t)v << a.cellBits) | (uint64_t)(cellMask - cell);
-		++cnt;
 	}
 	int incl = cnt;
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;

@@ -1,0 +1,140 @@
+// headless_samples.cxx -- the call sequences of samples/edges_canny/main.cxx:37-72 and samples/hough_lines/main.cxx:52-109
+// (minus camera and window, which need devices a headless GPU box does not have), run TWICE against the real CompV
+// library: first with the stock CPU factories, then after compv_hip_plugin_register() swapped the factories by id.
+// The application code between the two runs is IDENTICAL -- only the registered factory differs -- and the outputs are
+// compared: edge maps byte for byte, Hough lines as sets of (rho, theta, strength) (the reference's order among
+// equal strengths is unspecified: unstable std::sort, core/features/hough/compv_core_feature_houghsht.cxx:243-249).
+//
+// usage: headless_samples [W H [frames]]      exit code 0 = drop-in parity on every frame
+#include <compv/base/compv_base.h>
+#include <compv/base/compv_features.h>
+#include <compv/base/compv_debug.h>
+#include <compv/base/image/compv_image.h>
+#include <compv/core/compv_core.h>
+
+#include <algorithm>
+#include <chrono>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <tuple>
+#include <vector>
+
+using namespace compv;
+
+extern "C" int compv_hip_plugin_register(void);
+
+// SURVEY.md 8(d) synthetic frame
+static void synthFrame(CompVMatPtr img, uint32_t seed)
+{
+	const size_t W = img->cols(), H = img->rows();
+	uint32_t s = seed;
+	for (size_t j = 0; j < H; ++j) {
+		uint8_t* p = img->ptr<uint8_t>(j);
+		for (size_t i = 0; i < W; ++i) {
+			s = s * 1664525u + 1013904223u;
+			uint32_t v = 40u + ((((uint32_t)(i / 64) + (uint32_t)(j / 64)) & 1u) * 150u) + (s >> 28);
+			if (((i + 2 * j) % 257) < 3) v = 255u;
+			p[i] = (uint8_t)v;
+		}
+	}
+}
+
+struct Result {
+	std::vector<uint8_t> sobel, canny, cannyMean;
+	std::vector<std::tuple<float, float, size_t> > lines;
+	std::vector<float> cart;
+	double ms;
+};
+
+// The application code: same calls, same order, same parameters as the samples.
+static COMPV_ERROR_CODE runSamples(size_t W, size_t H, uint32_t seed, Result& r)
+{
+	CompVMatPtr image, mat, edges, sob;
+	CompVEdgeDetePtr ptrCanny, ptrSobel;
+	CompVHoughPtr ptrHough;
+	CompVHoughLineVector linesPolar;
+	CompVLineFloat32Vector linesCartesian;
+
+	COMPV_CHECK_CODE_RETURN(CompVImage::newObj8u(&image, COMPV_SUBTYPE_PIXELS_Y, W, H));
+	synthFrame(image, seed);
+
+	const auto t0 = std::chrono::steady_clock::now();
+	// samples/edges_sobel: CompVEdgeDete::newObj(&dete, COMPV_SOBEL_ID) ; process(image, &edges)
+	COMPV_CHECK_CODE_RETURN(CompVEdgeDete::newObj(&ptrSobel, COMPV_SOBEL_ID));
+	COMPV_CHECK_CODE_RETURN(ptrSobel->process(image, &sob));
+
+	// samples/edges_canny/main.cxx:44-45,68-72: newObj(COMPV_CANNY_ID, low, high, kernel) ; process(mat, &mat) IN PLACE
+	COMPV_CHECK_CODE_RETURN(CompVEdgeDete::newObj(&ptrCanny, COMPV_CANNY_ID, 59.f, 119.f, 3));
+	COMPV_CHECK_CODE_RETURN(image->clone(&mat));
+	COMPV_CHECK_CODE_RETURN(ptrCanny->process(mat, &mat));
+
+	// samples/hough_lines/main.cxx:59-72,102-109
+	COMPV_CHECK_CODE_RETURN(CompVHough::newObj(&ptrHough, COMPV_HOUGHSHT_ID, 1.f, 1.f, 100));
+	COMPV_CHECK_CODE_RETURN(ptrHough->setInt(COMPV_HOUGH_SET_INT_MAXLINES, 0));
+	COMPV_CHECK_CODE_RETURN(ptrHough->process(mat, linesPolar));
+	COMPV_CHECK_CODE_RETURN(ptrHough->toCartesian(mat->cols(), mat->rows(), linesPolar, linesCartesian));
+
+	// hough_lines sets the Canny thresholds per frame through set(): PERCENT_OF_MEAN variant
+	COMPV_CHECK_CODE_RETURN(ptrCanny->setInt(COMPV_CANNY_SET_INT_THRESHOLD_TYPE, COMPV_CANNY_THRESHOLD_TYPE_PERCENT_OF_MEAN));
+	COMPV_CHECK_CODE_RETURN(ptrCanny->setFloat32(COMPV_CANNY_SET_FLT32_THRESHOLD_LOW, 0.68f));
+	COMPV_CHECK_CODE_RETURN(ptrCanny->setFloat32(COMPV_CANNY_SET_FLT32_THRESHOLD_HIGH, 1.36f));
+	COMPV_CHECK_CODE_RETURN(ptrCanny->process(image, &edges));
+	r.ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+
+	auto grab = [&](const CompVMatPtr& m, std::vector<uint8_t>& out) {
+		out.resize(W * H);
+		for (size_t j = 0; j < H; ++j) memcpy(&out[j * W], m->ptr<const uint8_t>(j), W);
+	};
+	grab(sob, r.sobel); grab(mat, r.canny); grab(edges, r.cannyMean);
+	r.lines.clear();
+	for (size_t i = 0; i < linesPolar.size(); ++i) r.lines.push_back(std::make_tuple(linesPolar[i].rho, linesPolar[i].theta, linesPolar[i].strength));
+	std::sort(r.lines.begin(), r.lines.end());
+	r.cart.clear();
+	{
+		// cartesian endpoints follow the polar order: canonicalise through the same sort key
+		std::vector<std::tuple<float, float, size_t, float, float, float, float> > c;
+		for (size_t i = 0; i < linesPolar.size(); ++i)
+			c.push_back(std::make_tuple(linesPolar[i].rho, linesPolar[i].theta, linesPolar[i].strength, linesCartesian[i].a.x, linesCartesian[i].a.y, linesCartesian[i].b.x, linesCartesian[i].b.y));
+		std::sort(c.begin(), c.end());
+		for (auto& t : c) { r.cart.push_back(std::get<3>(t)); r.cart.push_back(std::get<4>(t)); r.cart.push_back(std::get<5>(t)); r.cart.push_back(std::get<6>(t)); }
+	}
+	// error behaviour is part of the contract
+	CompVEdgeDetePtr bad;
+	COMPV_CHECK_CODE_RETURN(CompVEdgeDete::newObj(&bad, COMPV_CANNY_ID, 100.f, 50.f, 3));
+	CompVMatPtr tmp;
+	const COMPV_ERROR_CODE e = bad->process(image, &tmp);
+	COMPV_CHECK_EXP_RETURN(e != COMPV_ERROR_CODE_E_INVALID_STATE, COMPV_ERROR_CODE_E_UNITTEST_FAILED, "tLow >= tHigh must give E_INVALID_STATE");
+	CompVHoughPtr badH;
+	COMPV_CHECK_EXP_RETURN(COMPV_ERROR_CODE_IS_OK(CompVHough::newObj(&badH, COMPV_HOUGHSHT_ID, 0.5f, 1.f, 100)), COMPV_ERROR_CODE_E_UNITTEST_FAILED, "SHT must reject rho != 1");
+	return COMPV_ERROR_CODE_S_OK;
+}
+
+int main(int argc, char** argv)
+{
+	const size_t W = argc > 2 ? (size_t)atoi(argv[1]) : 1280, H = argc > 2 ? (size_t)atoi(argv[2]) : 720;
+	const int frames = argc > 3 ? atoi(argv[3]) : 2;
+	CompVDebugMgr::setLevel(COMPV_DEBUG_LEVEL_ERROR);
+	// CompVInit() of compv_api.h minus GL/camera/drawing (absent on a headless box): base + core
+	if (COMPV_ERROR_CODE_IS_NOK(CompVBase::init(-1)) || COMPV_ERROR_CODE_IS_NOK(CompVCore::init())) { fprintf(stderr, "CompV init failed\n"); return 2; }
+
+	std::vector<Result> cpu(frames), gpu(frames);
+	for (int f = 0; f < frames; ++f) {
+		if (COMPV_ERROR_CODE_IS_NOK(runSamples(W, H, 12345u + f, cpu[f]))) { fprintf(stderr, "CPU run failed\n"); return 3; }
+	}
+	if (compv_hip_plugin_register() != 0) { fprintf(stderr, "HIP plugin registration failed (no GPU?)\n"); return 4; }
+	for (int f = 0; f < frames; ++f) {
+		if (COMPV_ERROR_CODE_IS_NOK(runSamples(W, H, 12345u + f, gpu[f]))) { fprintf(stderr, "HIP run failed\n"); return 5; }
+	}
+	int bad = 0;
+	for (int f = 0; f < frames; ++f) {
+		const bool okS = cpu[f].sobel == gpu[f].sobel, okC = cpu[f].canny == gpu[f].canny, okM = cpu[f].cannyMean == gpu[f].cannyMean;
+		const bool okL = cpu[f].lines == gpu[f].lines, okX = cpu[f].cart == gpu[f].cart;
+		size_t e = 0; for (uint8_t v : cpu[f].canny) e += v ? 1 : 0;
+		printf("frame %d (%zux%zu): sobel %s, canny(in-place) %s [%zu edge px], canny(mean mode) %s, hough lines %s [%zu], cartesian %s | CompV CPU %.2f ms, HIP plugin %.2f ms (incl. H2D/D2H)\n",
+			f, W, H, okS ? "==" : "DIFF", okC ? "==" : "DIFF", e, okM ? "==" : "DIFF", okL ? "==" : "DIFF", cpu[f].lines.size(), okX ? "==" : "DIFF", cpu[f].ms, gpu[f].ms);
+		bad += !(okS && okC && okM && okL && okX);
+	}
+	printf(bad ? "DROP-IN PARITY FAILED\n" : "DROP-IN PARITY OK\n");
+	return bad ? 1 : 0;
+}
