@@ -42,16 +42,29 @@ def cpu_baseline(W, H, budget_s=20.0):
     from oracle_bindings import Oracle, RefShim, have_refshim, synth_frame
     cores = os.cpu_count() or 1
     if have_refshim():
-        ref = RefShim(-1)   # all host cores (CompVBase::init(-1))
-        probe = synth_batch(1, W, H, 12345)
-        ms, _, _ = ref.bench_pipeline(probe, T_LOW, T_HIGH, THETA_DEG, SHT_THRESHOLD)
-        n = int(max(2, min(64, budget_s * 1000.0 / max(ms, 1e-3))))
+        # CompVBase::init(numThreads): -1 = one worker per logical CPU.  The best of a short thread-count sweep is used
+        # for the main sample, so that an over-subscribed thread pool does not flatter the GPU.
+        probe = synth_batch(2, W, H, 12345)
+        sweep = {}
+        ref = None
+        for t in (-1, 1, 8, 32):
+            if t > cores:
+                continue
+            if ref is None:
+                ref = RefShim(t)
+            else:
+                ref.reinit(t)
+            ms, _, _ = ref.bench_pipeline(probe, T_LOW, T_HIGH, THETA_DEG, SHT_THRESHOLD)
+            sweep[ref.threads] = round(ms / 2, 2)
+        best = min(sweep, key=sweep.get)
+        ref.reinit(best)
+        n = int(max(2, min(64, budget_s * 1000.0 / max(sweep[best], 1e-3))))
         frames = synth_batch(n, W, H, 12345)
         ms, edges, lines = ref.bench_pipeline(frames, T_LOW, T_HIGH, THETA_DEG, SHT_THRESHOLD)
         return {"value": round(n * W * H / (ms * 1e-3) / 1e6, 2), "unit": "Mpixels/s", "cores": ref.threads, "host_cpus": cores,
                 "kind": "reference",
-                "sample": "%d frames %dx%d, CompV AVX2 intrinsics path (COMPV_ASM=0), %d threads, Canny(59,119)+SHT(1deg,100)" % (n, W, H, ref.threads),
-                "ms_per_frame": round(ms / n, 3)}
+                "sample": "%d frames %dx%d, CompV AVX2 intrinsics path (COMPV_ASM=0), %d threads (best of sweep), Canny(59,119)+SHT(1deg,100)" % (n, W, H, ref.threads),
+                "ms_per_frame": round(ms / n, 3), "ms_per_frame_by_threads": sweep}
     orc = Oracle()
     img = synth_frame(W, H, 12345)
     t0 = time.time()
@@ -92,9 +105,12 @@ def main():
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local_rank if dist_on else 0)
 
+    from compv_amd import sharding
     W, H, F = args.width, args.height, args.frames_per_gpu
-    # frame f of the global batch uses seed 12345+f; rank r owns frames [r*F, (r+1)*F)
-    frames = synth_batch(F, W, H, 12345 + rank * F)
+    # weak scaling: the global batch is world*F frames, frame f uses seed 12345+f, rank r owns a contiguous block
+    mine = sharding.shard_range(world * F, world, rank)
+    assert len(mine) == F
+    frames = synth_batch(F, W, H, sharding.frame_seed(mine[0]))
     d_in = torch.from_numpy(frames).to(dev)
     d_edges = torch.empty_like(d_in)
     line_cap = 1 << 16
@@ -130,10 +146,7 @@ def main():
     if dist_on:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if dist_on:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = sharding.max_over_ranks(elapsed, dist if dist_on else None, dev)
     plan.set_timing(False)
 
     counts = d_counts.cpu().numpy()

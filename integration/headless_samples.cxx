@@ -5,7 +5,12 @@
 // compared: edge maps byte for byte, Hough lines as sets of (rho, theta, strength) (the reference's order among
 // equal strengths is unspecified: unstable std::sort, core/features/hough/compv_core_feature_houghsht.cxx:243-249).
 //
-// usage: headless_samples [W H [frames]]      exit code 0 = drop-in parity on every frame
+// usage: headless_samples [W H [frames [cpuThreads]]]      exit code 0 = drop-in parity on every frame
+// cpuThreads (default 1) is CompVBase::init()'s thread count for the CPU reference run.  The default is the single-threaded
+// path because the reference's multi-threaded gradient is not deterministic: each row band also recomputes |gx|+|gy| for
+// its two overlap rows from gx/gy rows that the neighbouring band may not have written yet
+// (core/features/edges/compv_core_feature_canny_dete.cxx:190-199), so with many threads and few rows per band the CPU
+// result itself occasionally differs from run to run.
 #include <compv/base/compv_base.h>
 #include <compv/base/compv_features.h>
 #include <compv/base/compv_debug.h>
@@ -114,9 +119,10 @@ int main(int argc, char** argv)
 {
 	const size_t W = argc > 2 ? (size_t)atoi(argv[1]) : 1280, H = argc > 2 ? (size_t)atoi(argv[2]) : 720;
 	const int frames = argc > 3 ? atoi(argv[3]) : 2;
+	const int cpuThreads = argc > 4 ? atoi(argv[4]) : 1;
 	CompVDebugMgr::setLevel(COMPV_DEBUG_LEVEL_ERROR);
 	// CompVInit() of compv_api.h minus GL/camera/drawing (absent on a headless box): base + core
-	if (COMPV_ERROR_CODE_IS_NOK(CompVBase::init(-1)) || COMPV_ERROR_CODE_IS_NOK(CompVCore::init())) { fprintf(stderr, "CompV init failed\n"); return 2; }
+	if (COMPV_ERROR_CODE_IS_NOK(CompVBase::init(cpuThreads)) || COMPV_ERROR_CODE_IS_NOK(CompVCore::init())) { fprintf(stderr, "CompV init failed\n"); return 2; }
 
 	std::vector<Result> cpu(frames), gpu(frames);
 	for (int f = 0; f < frames; ++f) {

@@ -1,0 +1,43 @@
+"""CPU tests of the N > 1 path (gloo, world_size 2): frame sharding, barrier-bracketed timing with MAX over ranks,
+gather of per-frame results."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+from compv_amd import sharding
+from oracle_bindings import synth_frame
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_shard_range_partitions_every_frame_once():
+    for total in (1, 7, 32, 256, 257):
+        for world in (1, 2, 3, 4, 8):
+            seen = []
+            for r in range(world):
+                seen.extend(sharding.shard_range(total, world, r))
+            assert seen == list(range(total))
+            sizes = [len(sharding.shard_range(total, world, r)) for r in range(world)]
+            assert max(sizes) - min(sizes) <= 1
+
+
+def test_two_ranks_gloo(tmp_path, oracle):
+    out = tmp_path / "dist.json"
+    frames = 5
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", "29541", os.path.join(ROOT, "tests", "_dist_worker.py"), str(out), str(frames)]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    res = json.loads(out.read_text())
+    assert res["world"] == 2
+    # the gathered per-frame results equal a single-process run over the whole batch, in frame order
+    exp = []
+    for f in range(frames):
+        rc, e = oracle.canny(synth_frame(160, 120, sharding.frame_seed(f)), 59.0, 119.0)
+        exp.append(int((e != 0).sum()))
+    assert res["counts"] == exp
+    assert res["tmax"] >= res["elapsed_rank0"] - 1e-6 and res["tmax"] >= 0.1   # rank 1 sleeps longer: MAX picks it
