@@ -166,13 +166,25 @@ def main():
             "sht_vote_kernel": F * (W * H + R * T * 4.0),
         }
 
+        def measured_traffic(name):
+            # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, KiB; see
+            # tools/traffic_from_pmc.py for the calibration) -- only valid for the workload they were collected on
+            try:
+                rounds = sorted(d for d in os.listdir(os.path.join(ROOT, "profiles")) if os.path.exists(os.path.join(ROOT, "profiles", d, "traffic.json")))
+                t = json.load(open(os.path.join(ROOT, "profiles", rounds[-1], "traffic.json")))
+                if t["workload"] == {"W": W, "H": H, "frames": F}:
+                    return t["kernels"][name]["hbm_bytes"]
+            except Exception:
+                pass
+            return None
+
         def roof(name, nbytes):
             if name not in kern:
                 return None
             ms = kern[name]["ms_per_launch"]
             ach = nbytes / (ms * 1e-3) / 1e9
             return {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None, "ms_per_launch": round(ms, 4),
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": measured_traffic(name), "ms_per_launch": round(ms, 4),
                     "algorithmic_bytes_per_launch": int(nbytes)}
         roofline = roof(dom, alg.get(dom, F * W * H * 1.0)) if dom else None
         rc = roof("canny_tile_kernel", alg["canny_tile_kernel"])

@@ -31,7 +31,7 @@ EXPORTS = [
     "compvhip_live_allocations", "compvhip_edge_dete_u8", "compvhip_canny_u8", "compvhip_houghsht_u8",
     "compvhip_houghsht_dims", "compvhip_plan_create", "compvhip_plan_destroy", "compvhip_plan_canny",
     "compvhip_plan_houghsht", "compvhip_plan_pipeline", "compvhip_plan_acc", "compvhip_plan_edge_counts",
-    "compvhip_plan_set_timing", "compvhip_plan_get_timing", "compvhip_plan_acc_export",
+    "compvhip_plan_set_timing", "compvhip_plan_get_timing", "compvhip_plan_acc_export", "compvhip_plan_edge_dete",
 ]
 
 
@@ -93,6 +93,7 @@ def load():
     L.compvhip_plan_destroy.restype = None
     L.compvhip_plan_canny.argtypes = [vp, vp, C.c_float, C.c_float, i32, i32, vp, vp]
     L.compvhip_plan_houghsht.argtypes = [vp, vp, i32, i32, vp, sz, vp, vp]
+    L.compvhip_plan_edge_dete.argtypes = [vp, vp, i32, vp, vp]
     L.compvhip_plan_pipeline.argtypes = [vp, vp, C.c_float, C.c_float, i32, i32, vp, vp, sz, vp, vp]
     L.compvhip_plan_acc.argtypes = [vp, sz, C.POINTER(vp), C.POINTER(sz), C.POINTER(sz), C.POINTER(sz)]
     L.compvhip_plan_acc_export.argtypes = [vp, sz, vp, sz, vp]
@@ -203,6 +204,9 @@ class Plan:
 
     def canny(self, d_in, tLow, tHigh, d_edges, ksize=3, threshold_type=THRESHOLD_COMPARE_TO_GRADIENT, stream=0):
         self.ctx._chk(self.lib.compvhip_plan_canny(self.h, d_in, tLow, tHigh, ksize, threshold_type, d_edges, stream))
+
+    def edge_dete(self, d_in, op, d_out, stream=0):
+        self.ctx._chk(self.lib.compvhip_plan_edge_dete(self.h, d_in, op, d_out, stream))
 
     def houghsht(self, d_edges, threshold, max_lines, d_lines, line_cap, d_counts, stream=0):
         self.ctx._chk(self.lib.compvhip_plan_houghsht(self.h, d_edges, threshold, max_lines, d_lines, line_cap, d_counts, stream))

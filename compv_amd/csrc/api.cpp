@@ -481,6 +481,28 @@ int compvhip_plan_canny(compvhip_plan* p, const uint8_t* d_in, float tLow, float
 	return planCannyImpl(p, d_in, tLow, tHigh, ksize, type, d_edges, static_cast<hipStream_t>(stream), true);
 }
 
+int compvhip_plan_edge_dete(compvhip_plan* p, const uint8_t* d_in, int op, uint8_t* d_out, void* stream)
+{
+	if (!p) return COMPVHIP_E_INVALID_PARAMETER;
+	compvhip_ctx* ctx = p->ctx;
+	if (!d_in || !d_out) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "null frame pointer");
+	if (op != COMPVHIP_OP_SOBEL && op != COMPVHIP_OP_SCHARR && op != COMPVHIP_OP_PREWITT)
+		return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "invalid detector id"); // edge_dete.cxx:246
+	const size_t bytes = p->S * p->H * p->frames;
+	if ((d_in < d_out + bytes) && (d_out < d_in + bytes)) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "d_in and d_out must not alias");
+	HIPCHK(ctx, hipSetDevice(ctx->device));
+	hipStream_t st = static_cast<hipStream_t>(stream);
+	if (p->timing) timelineClear(p);
+	EdgeDeteArgs a;
+	a.in = d_in; a.out = d_out; a.gmax = p->sums;
+	a.inFrameStride = p->S * p->H; a.outFrameStride = p->S * p->H;
+	a.W = static_cast<int>(p->W); a.H = static_cast<int>(p->H); a.S = static_cast<int>(p->S); a.So = static_cast<int>(p->S);
+	a.tilesX = p->tilesX; a.tilesY = p->tilesY;
+	Stamp s(p, st, "edge_dete_kernels");
+	HIPCHK(ctx, launch_edge_dete(a, op, static_cast<int>(p->frames), st));
+	return COMPVHIP_OK;
+}
+
 static int planShtImpl(compvhip_plan* p, const uint8_t* d_edges, int threshold, int maxLines, compvhip_line* d_lines, size_t lineCap, int32_t* d_counts,
                        hipStream_t st, bool clearTimeline)
 {

@@ -100,9 +100,10 @@ __global__ __launch_bounds__(kCannyWaves * 64) void canny_tile_kernel(CannyArgs 
 
 	const int lane = threadIdx.x & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	const int tileX = blockIdx.x;
-	const int tileY = blockIdx.y * kCannyWaves + wave;
-	const int frame = blockIdx.z;
+	int tileX, group;
+	if (!xcd_tile_map(blockIdx.x, a.tilesX, a.groups, tileX, group)) return;
+	const int frame = group / a.blockRows;
+	const int tileY = (group - frame * a.blockRows) * kCannyWaves + wave;
 	if (tileY >= a.tilesY) return; // whole wave
 
 	const int W = a.W, H = a.H, S = a.S;
@@ -454,9 +455,12 @@ __global__ void mean_thresholds_kernel(const unsigned int* __restrict__ sums, in
 // ---------------------------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------------------------
-hipError_t launch_canny_tiles(const CannyArgs& a, int frames, bool gap, hipStream_t stream)
+hipError_t launch_canny_tiles(const CannyArgs& a0, int frames, bool gap, hipStream_t stream)
 {
-	dim3 grid(a.tilesX, (a.tilesY + kCannyWaves - 1) / kCannyWaves, frames);
+	CannyArgs a = a0;
+	a.blockRows = (a.tilesY + kCannyWaves - 1) / kCannyWaves;
+	a.groups = a.blockRows * frames;
+	dim3 grid(8 * ((a.groups + 7) / 8) * a.tilesX);
 	dim3 block(kCannyWaves * 64);
 	if (gap) hipLaunchKernelGGL(canny_tile_kernel<true>, grid, block, 0, stream, a);
 	else hipLaunchKernelGGL(canny_tile_kernel<false>, grid, block, 0, stream, a);

@@ -24,6 +24,7 @@ struct CannyArgs {
 	int tilesX, tilesY;
 	int tLow, tHigh;
 	int simdEnd, cStart;      // quirk Q3 coverage: [1,simdEnd) U [cStart,W-1)
+	int blockRows, groups;    // filled by the launcher: workgroup rows per frame, row groups in the launch (XCD-aware map)
 };
 
 struct ResolveArgs {
@@ -49,6 +50,7 @@ struct EdgeDeteArgs {
 	size_t inFrameStride, outFrameStride;
 	int W, H, S, So;
 	int tilesX, tilesY;
+	int blockRows, groups;    // filled by the launcher (XCD-aware map)
 };
 hipError_t launch_edge_dete(const EdgeDeteArgs& a, int op, int frames, hipStream_t stream);
 

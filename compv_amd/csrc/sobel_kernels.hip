@@ -27,9 +27,10 @@ __global__ __launch_bounds__(kEdgeWaves * 64) void edge_dete_kernel(EdgeDeteArgs
 {
 	const int lane = threadIdx.x & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	const int tileX = blockIdx.x;
-	const int tileY = blockIdx.y * kEdgeWaves + wave;
-	const int frame = blockIdx.z;
+	int tileX, group;
+	if (!xcd_tile_map(blockIdx.x, a.tilesX, a.groups, tileX, group)) return;
+	const int frame = group / a.blockRows;
+	const int tileY = (group - frame * a.blockRows) * kEdgeWaves + wave;
 	if (tileY >= a.tilesY) return;
 
 	const int W = a.W, H = a.H, S = a.S;
@@ -99,11 +100,14 @@ __global__ __launch_bounds__(kEdgeWaves * 64) void edge_dete_kernel(EdgeDeteArgs
 }
 
 template <int A, int B>
-static hipError_t launch_op(const EdgeDeteArgs& a, int frames, hipStream_t stream)
+static hipError_t launch_op(const EdgeDeteArgs& a0, int frames, hipStream_t stream)
 {
+	EdgeDeteArgs a = a0;
+	a.blockRows = (a.tilesY + kEdgeWaves - 1) / kEdgeWaves;
+	a.groups = a.blockRows * frames;
 	hipError_t e = hipMemsetAsync(a.gmax, 0, sizeof(unsigned int) * frames, stream);
 	if (e != hipSuccess) return e;
-	dim3 grid(a.tilesX, (a.tilesY + kEdgeWaves - 1) / kEdgeWaves, frames);
+	dim3 grid(8 * ((a.groups + 7) / 8) * a.tilesX);
 	dim3 block(kEdgeWaves * 64);
 	hipLaunchKernelGGL((edge_dete_kernel<A, B, false>), grid, block, 0, stream, a);
 	hipLaunchKernelGGL((edge_dete_kernel<A, B, true>), grid, block, 0, stream, a);

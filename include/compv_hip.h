@@ -123,6 +123,10 @@ COMPVHIP_API void compvhip_plan_destroy(compvhip_plan* plan);
 COMPVHIP_API int compvhip_plan_canny(compvhip_plan* plan, const uint8_t* d_in, float tLow, float tHigh, int ksize,
                                      int thresholdType, uint8_t* d_edges, void* stream);
 
+/* Sobel / Scharr / Prewitt detector (compvhip_edge_dete_u8 semantics) on `frames` device frames; d_in and d_out must
+ * not alias.  Fully asynchronous on `stream`. */
+COMPVHIP_API int compvhip_plan_edge_dete(compvhip_plan* plan, const uint8_t* d_in, int op, uint8_t* d_out, void* stream);
+
 /* SHT on the edge maps produced by the last compvhip_plan_canny() of this plan (uses its 1-bit edge masks, no byte
  * re-read) or, when d_edges != NULL, on arbitrary device edge maps.  Results stay on the device:
  * d_lines: frames * lineCap compvhip_line (sorted as compvhip_houghsht_u8), d_counts: frames int32 (lines found,
