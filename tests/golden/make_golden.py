@@ -35,6 +35,9 @@ CASES = [
 ]
 
 
+KHT_CASES = ("small_320x240", "q3_641x480", "ragged_333x77", "hd_1280x720", "fhd_1920x1080", "uhd_3840x2160", "dense_1282x720")
+
+
 def main():
     ref = RefShim(1)
     assert ref.avx2, "goldens must come from the AVX2 intrinsics path"
@@ -63,6 +66,11 @@ def main():
                         "sum_theta": float(np.sum(np.array([l[1] for l in lines], np.float64)))}
             keep = lines if len(lines) <= 4096 else lines[:4096]
             arrays[name + "/sht_lines"] = np.array([(l[0], l[1], l[2]) for l in keep], np.float64).reshape(-1, 3)
+        if name in KHT_CASES:
+            kl, gs = ref.kht(can, 1.0, 1.0, 1)
+            m["kht"] = {"rho": 1.0, "theta_deg": 1.0, "threshold": 1, "lines": len(kl), "gs": repr(gs),
+                        "sum_strength": int(sum(l[2] for l in kl))}
+            arrays[name + "/kht_lines"] = np.array([(l[0], l[1], l[2]) for l in kl], np.float64).reshape(-1, 3)  # reference order
         meta[name] = m
         print(name, m["canny_edges"], m.get("sht", {}).get("lines"))
     with open(os.path.join(HERE, "golden.json"), "w") as f:

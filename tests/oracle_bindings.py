@@ -53,16 +53,30 @@ class OrcLine(C.Structure):
     _fields_ = [("rho", C.c_float), ("theta", C.c_float), ("strength", C.c_int64), ("row", C.c_int32), ("col", C.c_int32)]
 
 
+class KhtLine(C.Structure):
+    _fields_ = [("rho", C.c_float), ("theta", C.c_float), ("strength", C.c_int32), ("rho_index", C.c_int32), ("theta_index", C.c_int32)]
+
+
 class RefLine(C.Structure):
     _fields_ = [("rho", C.c_float), ("theta", C.c_float), ("strength", C.c_longlong)]
 
 
 def build_oracle():
-    src = os.path.join(ORACLE_DIR, "compv_oracle.c")
+    srcs = [os.path.join(ORACLE_DIR, f) for f in ("compv_oracle.c", "kht_oracle.c")]
+    cxx = os.path.join(ORACLE_DIR, "kht_sort.cpp")
+    deps = srcs + [cxx] + [os.path.join(ORACLE_DIR, f) for f in ("compv_oracle.h", "kht_oracle.h")]
     out = os.path.join(ORACLE_DIR, "liboracle.so")
-    if (not os.path.exists(out)) or os.path.getmtime(out) < os.path.getmtime(src) \
-            or os.path.getmtime(out) < os.path.getmtime(os.path.join(ORACLE_DIR, "compv_oracle.h")):
-        subprocess.check_call(["gcc", "-O2", "-fPIC", "-shared", "-std=c11", "-o", out, src, "-lm"])
+    if (not os.path.exists(out)) or any(os.path.getmtime(out) < os.path.getmtime(d) for d in deps):
+        # -ffp-contract=off: the reference's KHT is plain IEEE double arithmetic (no FMA contraction)
+        objs = []
+        for s in srcs:
+            o = s[:-2] + ".o"
+            subprocess.check_call(["gcc", "-O2", "-fPIC", "-std=gnu11", "-ffp-contract=off", "-c", s, "-o", o])
+            objs.append(o)
+        o = cxx[:-4] + ".o"
+        subprocess.check_call(["g++", "-O2", "-fPIC", "-std=c++11", "-c", cxx, "-o", o])
+        objs.append(o)
+        subprocess.check_call(["g++", "-shared", "-o", out] + objs + ["-lm"])
     return out
 
 
@@ -86,6 +100,17 @@ class Oracle:
         L.orc_sht_acc.argtypes = [C.c_void_p, sz, sz, sz, C.c_void_p, C.c_void_p, sz, C.c_void_p, sz]
         L.orc_sht_lines.argtypes = [C.c_void_p, sz, sz, sz, C.c_int32, C.c_int32, C.c_float, C.c_int, C.c_void_p, sz, C.c_void_p]
         L.orc_sht.argtypes = [C.c_void_p, sz, sz, sz, C.c_float, C.c_int32, C.c_int, C.c_void_p, sz, C.c_void_p]
+
+    def kht(self, edges, rho=1.0, theta_deg=1.0, threshold=1, max_lines=0, min_dev=2.0, min_size=10, min_height=0.002, cap=1 << 16):
+        """CompVHoughKht::process restated: returns ([(rho, theta, strength, rho_index, theta_index)], GS)."""
+        H, W = edges.shape
+        L = self.lib
+        L.orc_kht.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_float, C.c_float, C.c_int32, C.c_int, C.c_double, C.c_size_t,
+                              C.c_double, C.c_void_p, C.c_size_t, C.c_void_p, C.c_void_p]
+        buf = (KhtLine * cap)(); n = C.c_size_t(0); gs = C.c_double(0)
+        r = L.orc_kht(_p(edges), W, H, edges.strides[0], rho, theta_deg, threshold, max_lines, min_dev, min_size, min_height, buf, cap, C.byref(n), C.byref(gs))
+        assert r == 0, r
+        return [(buf[i].rho, buf[i].theta, buf[i].strength, buf[i].rho_index, buf[i].theta_index) for i in range(min(n.value, cap))], gs.value
 
     def synth(self, W, H, seed=12345):
         out = np.zeros((H, W), np.uint8)
