@@ -32,6 +32,7 @@ EXPORTS = [
     "compvhip_houghsht_dims", "compvhip_plan_create", "compvhip_plan_destroy", "compvhip_plan_canny",
     "compvhip_plan_houghsht", "compvhip_plan_pipeline", "compvhip_plan_acc", "compvhip_plan_edge_counts",
     "compvhip_plan_set_timing", "compvhip_plan_get_timing", "compvhip_plan_acc_export", "compvhip_plan_edge_dete",
+    "compvhip_houghkht_u8",
 ]
 
 
@@ -87,6 +88,8 @@ def load():
     L.compvhip_edge_dete_u8.argtypes = [vp, vp, sz, sz, sz, i32, vp, sz]
     L.compvhip_canny_u8.argtypes = [vp, vp, sz, sz, sz, C.c_float, C.c_float, i32, i32, vp, sz]
     L.compvhip_houghsht_u8.argtypes = [vp, vp, sz, sz, sz, C.c_float, C.c_float, i32, i32, vp, sz, C.POINTER(sz), vp, sz]
+    L.compvhip_houghkht_u8.argtypes = [vp, vp, sz, sz, sz, C.c_float, C.c_float, i32, i32, C.c_double, sz, C.c_double, vp, sz, C.POINTER(sz),
+                                       C.POINTER(C.c_double)]
     L.compvhip_houghsht_dims.argtypes = [sz, sz, C.c_float, C.POINTER(sz), C.POINTER(sz), C.POINTER(C.c_float)]
     L.compvhip_plan_create.argtypes = [vp, sz, sz, sz, sz, C.c_float, C.POINTER(vp)]
     L.compvhip_plan_destroy.argtypes = [vp]
@@ -178,6 +181,20 @@ class Context:
         self._chk(rc)
         lines = lines[:n.value]
         return (lines, acc) if want_acc else lines
+
+
+    def houghkht(self, edges, rho=1.0, theta_deg=1.0, threshold=1, max_lines=0, min_dev=2.0, min_size=10, min_height=0.002, cap=1 << 14):
+        """Returns (lines, GS); lines['row'] / ['col'] hold the rho / theta indices."""
+        H, W = edges.shape
+        lines = np.zeros(cap, LINE_DTYPE)
+        n = C.c_size_t(0)
+        gs = C.c_double(1.0)
+        rc = self.lib.compvhip_houghkht_u8(self.h, _ptr(edges), W, H, edges.strides[0], rho, theta_deg, threshold, max_lines, min_dev, min_size,
+                                           min_height, _ptr(lines), cap, C.byref(n), C.byref(gs))
+        if rc == E_OUT_OF_BOUND and n.value > cap:
+            return self.houghkht(edges, rho, theta_deg, threshold, max_lines, min_dev, min_size, min_height, cap=n.value)
+        self._chk(rc)
+        return lines[:n.value], gs.value
 
 
 class Plan:

@@ -7,6 +7,7 @@
 // Device-pointer ("plan") entry points run the same kernels on batches of frames resident in HBM.
 #include "../../include/compv_hip.h"
 #include "kernels.hpp"
+#include "kht.hpp"
 
 #include <hip/hip_runtime.h>
 
@@ -38,6 +39,11 @@ struct compvhip_ctx {
 	compvhip_line* dLines = nullptr; size_t dLinesCap = 0;
 	int32_t* dCounts = nullptr;
 	int32_t* dAccOut = nullptr; size_t dAccOutElems = 0;
+	// KHT scratch (device)
+	int32_t* khtCounts = nullptr; size_t khtCountsElems = 0;
+	KhtVoteParams* khtParams = nullptr; size_t khtParamsCap = 0;
+	KhtCell* khtCells = nullptr; size_t khtCellsCap = 0;
+	int* khtCellCount = nullptr;
 };
 
 struct TimingEntry { const char* name; hipEvent_t a, b; };
@@ -363,6 +369,7 @@ void compvhip_ctx_destroy(compvhip_ctx* ctx)
 	(void)hipSetDevice(ctx->device);
 	if (ctx->hostPlan) compvhip_plan_destroy(ctx->hostPlan);
 	dfree(ctx, ctx->dIn); dfree(ctx, ctx->dOut); dfree(ctx, ctx->dLines); dfree(ctx, ctx->dCounts); dfree(ctx, ctx->dAccOut);
+	dfree(ctx, ctx->khtCounts); dfree(ctx, ctx->khtParams); dfree(ctx, ctx->khtCells); dfree(ctx, ctx->khtCellCount);
 	if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
 	delete ctx;
 }
@@ -718,6 +725,71 @@ int compvhip_houghsht_u8(compvhip_ctx* ctx, const uint8_t* edges, size_t W, size
 		HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
 	}
 	if (found > cap) return fail(ctx, COMPVHIP_E_OUT_OF_BOUND, "line buffer too small");
+	return COMPVHIP_OK;
+}
+
+int compvhip_houghkht_u8(compvhip_ctx* ctx, const uint8_t* edges, size_t W, size_t H, size_t S, float rho, float thetaDeg, int threshold, int maxLines,
+                         double clusterMinDeviation, size_t clusterMinSize, double kernelMinHeight, compvhip_line* lines, size_t cap, size_t* n, double* gs)
+{
+	if (!ctx) return COMPVHIP_E_INVALID_PARAMETER;
+	if (!edges || !n || (cap && !lines) || S < W || !W || !H) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "null/invalid argument"); // houghkht.cxx:210-211
+	if (!(rho > 0.f) || rho > 1.f || !(thetaDeg > 0.f) || threshold <= 0) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "rho in (0,1], theta > 0, threshold > 0"); // :146-163,491
+	if (!(clusterMinDeviation > 0.0) || !clusterMinSize || !(kernelMinHeight > 0.0)) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "invalid KHT knob"); // :169-186
+	if (W > 32767 || H > 32767) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "image size out of range");
+	*n = 0;
+	KhtAxes ax;
+	if (!khtAxes(W, H, rho, thetaDeg, ax)) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "degenerate KHT parameter space");
+	// host: clone the edges (the linker destroys them, :323-336), link, subdivide, build the kernels
+	std::vector<uint8_t> work(W * H);
+	for (size_t j = 0; j < H; ++j) memcpy(&work[j * W], edges + j * S, W);
+	std::vector<KhtPos> poss; std::vector<KhtRange> strings, clusters; std::vector<KhtKernel> kernels;
+	khtLink(work.data(), W, H, W, clusterMinSize, poss, strings);
+	if (strings.empty()) return COMPVHIP_OK;
+	khtClusters(poss, strings, clusterMinSize, clusterMinDeviation, clusters);
+	if (clusters.empty()) return COMPVHIP_OK;
+	double hmax = 0.0;
+	khtKernels(poss, clusters, kernels, hmax);
+	const double GS = khtPruneAndScale(kernels, hmax, kernelMinHeight);
+	if (kernels.empty()) return COMPVHIP_OK;
+	if (gs) *gs = GS;
+	std::vector<KhtVoteParams> params;
+	khtVoteParams(ax, kernels, params);
+
+	// device: Gaussian voting + smoothing/threshold
+	HIPCHK(ctx, hipSetDevice(ctx->device));
+	const int stride = static_cast<int>(alignUp(ax.rhoN + 2, 16));
+	const size_t countsElems = (ax.T + 2) * static_cast<size_t>(stride);
+	if (ctx->khtCountsElems < countsElems) { dfree(ctx, ctx->khtCounts); HIPCHK(ctx, dmalloc(ctx, &ctx->khtCounts, countsElems)); ctx->khtCountsElems = countsElems; }
+	if (ctx->khtParamsCap < params.size()) { dfree(ctx, ctx->khtParams); HIPCHK(ctx, dmalloc(ctx, &ctx->khtParams, params.size())); ctx->khtParamsCap = params.size(); }
+	const size_t cellCap = ax.T * ax.rhoN;
+	if (ctx->khtCellsCap < cellCap) { dfree(ctx, ctx->khtCells); HIPCHK(ctx, dmalloc(ctx, &ctx->khtCells, cellCap)); ctx->khtCellsCap = cellCap; }
+	if (!ctx->khtCellCount) HIPCHK(ctx, dmalloc(ctx, &ctx->khtCellCount, 1));
+	hipStream_t st = ctx->stream;
+	HIPCHK(ctx, hipMemsetAsync(ctx->khtCounts, 0, countsElems * sizeof(int32_t), st));
+	HIPCHK(ctx, hipMemsetAsync(ctx->khtCellCount, 0, sizeof(int), st));
+	HIPCHK(ctx, hipMemcpyAsync(ctx->khtParams, params.data(), params.size() * sizeof(KhtVoteParams), hipMemcpyHostToDevice, st));
+	KhtGpuArgs a;
+	a.params = ctx->khtParams; a.nKernels = static_cast<int>(params.size()); a.counts = ctx->khtCounts; a.stride = stride;
+	a.rhoN = static_cast<int>(ax.rhoN); a.T = static_cast<int>(ax.T); a.dRho = ax.dRho; a.dThetaDeg = ax.dThetaDeg; a.gs = GS;
+	a.threshold = threshold; a.cells = ctx->khtCells; a.cellCount = ctx->khtCellCount; a.cellCap = static_cast<int>(cellCap);
+	HIPCHK(ctx, launch_kht_vote(a, st));
+	HIPCHK(ctx, launch_kht_peaks(a, st));
+	int cellCount = 0;
+	HIPCHK(ctx, hipMemcpyAsync(&cellCount, ctx->khtCellCount, sizeof(int), hipMemcpyDeviceToHost, st));
+	HIPCHK(ctx, hipStreamSynchronize(st));
+	std::vector<KhtCell> cells(static_cast<size_t>(std::min<int>(cellCount, static_cast<int>(cellCap))));
+	if (!cells.empty()) HIPCHK(ctx, hipMemcpy(cells.data(), ctx->khtCells, cells.size() * sizeof(KhtCell), hipMemcpyDeviceToHost));
+
+	// host: sort + sweep (order dependent, :1195-1247)
+	std::vector<KhtLine> out;
+	khtPeaks(ax, cells, maxLines, out);
+	*n = out.size();
+	const size_t ncopy = std::min(out.size(), cap);
+	for (size_t i = 0; i < ncopy; ++i) {
+		lines[i].rho = out[i].rho; lines[i].theta = out[i].theta; lines[i].strength = out[i].strength;
+		lines[i].row = out[i].rhoIndex; lines[i].col = out[i].thetaIndex;
+	}
+	if (out.size() > cap) return fail(ctx, COMPVHIP_E_OUT_OF_BOUND, "line buffer too small");
 	return COMPVHIP_OK;
 }
 

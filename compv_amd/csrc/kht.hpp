@@ -1,0 +1,45 @@
+// kht.hpp -- types shared by the host stages (kht_host.cpp), the GPU stages (kht_kernels.hip) and the C ABI (api.cpp) of
+// the kernel-based Hough transform.  Reference: core/features/hough/compv_core_feature_houghkht.{h,cxx}.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+#include <vector>
+
+namespace compvhip {
+
+struct KhtAxes { double dRho, dThetaRad, dThetaDeg, r; size_t rhoN, T, W, H; };
+struct KhtPos { int y, x; double cy, cx; };                 // CompVHoughKhtPos (houghkht.h:31-38)
+struct KhtRange { size_t begin, end; };                     // CompVHoughKhtString / Cluster
+struct KhtKernel { double rho, theta, h, sigmaThetaSquare, sigmaRhoSquare, m2, sigmaRhoTimesTheta; }; // CompVHoughKhtKernel (:52-62)
+struct KhtLine { float rho, theta; int32_t strength, rhoIndex, thetaIndex; };
+
+// per-kernel constants of vote_Algorithm4, precomputed on the host (all divisions / square roots)
+struct KhtVoteParams { double srsScale, stsScale, sScale, r2, x, y; unsigned rhoIndex, thetaIndex; };
+// one vote cell that passed the 3x3 smoothing + threshold; `order` = position in the reference's emission order
+struct KhtCell { uint32_t order; uint32_t rhoIndex; uint32_t thetaIndex; int32_t count; };
+
+bool khtAxes(size_t W, size_t H, float rho, float thetaDeg, KhtAxes& ax);
+void khtFillAxes(const KhtAxes& ax, std::vector<double>& rho, std::vector<double>& theta);
+void khtLink(uint8_t* edges, size_t W, size_t H, size_t S, size_t minSize, std::vector<KhtPos>& poss, std::vector<KhtRange>& strings);
+void khtClusters(const std::vector<KhtPos>& poss, const std::vector<KhtRange>& strings, size_t minSize, double minDev, std::vector<KhtRange>& clusters);
+void khtKernels(const std::vector<KhtPos>& poss, const std::vector<KhtRange>& clusters, std::vector<KhtKernel>& kernels, double& hmax);
+double khtPruneAndScale(std::vector<KhtKernel>& kernels, double hmax, double minHeight);
+void khtVoteParams(const KhtAxes& ax, const std::vector<KhtKernel>& kernels, std::vector<KhtVoteParams>& params);
+void khtPeaks(const KhtAxes& ax, std::vector<KhtCell>& cells, int maxLines, std::vector<KhtLine>& lines);
+
+// GPU stages
+struct KhtGpuArgs {
+	const KhtVoteParams* params; int nKernels;
+	int32_t* counts;          // (T+2) x stride, zeroed
+	int stride;               // >= rhoN + 2
+	int rhoN, T;
+	double dRho, dThetaDeg, gs;
+	int32_t threshold;
+	KhtCell* cells; int* cellCount; int cellCap;
+};
+hipError_t launch_kht_vote(const KhtGpuArgs& a, hipStream_t stream);
+hipError_t launch_kht_peaks(const KhtGpuArgs& a, hipStream_t stream);
+
+} // namespace compvhip

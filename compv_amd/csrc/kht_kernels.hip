@@ -1,0 +1,132 @@
+// kht_kernels.hip -- GPU stages of the kernel-based Hough transform for gfx950.
+//
+//   kht_vote_kernel   vote_Algorithm4 (core/features/hough/compv_core_feature_houghkht.cxx:1088-1148): every elliptical
+//                     Gaussian kernel is rasterised into the int32 (rho,theta) count map in four quadrant walks.  One
+//                     thread = one (kernel, quadrant) walk; votes are added with global int32 atomics, exactly like the
+//                     reference's __sync_fetch_and_add, so the map is independent of the execution order.
+//   kht_peaks_kernel  peaks_Section3_4_VotesCount (:1151-1192,1282-1308 and intrin_sse2.cxx:20-96): 3x3 binomial
+//                     smoothing of the non-zero cells, threshold, compaction of the surviving cells (with their position
+//                     in the reference's emission order, which the host needs for the order-dependent sweep).
+//
+// Built with -ffp-contract=off: the float64 expressions below must round once per operation, like the reference's SSE2
+// code, or the integer votes differ.  All divisions and square roots were done on the host (KhtVoteParams).
+#include "kht.hpp"
+
+namespace compvhip {
+
+__device__ __forceinline__ double exp_fast_small(double x)
+{
+	// (1 + x/1024)^1024, houghkht.cxx:77-88
+	x = 1.0 + (x * (1.0 / 1024.0));
+	x *= x; x *= x; x *= x; x *= x; x *= x; x *= x; x *= x; x *= x; x *= x; x *= x;
+	return x;
+}
+
+__global__ __launch_bounds__(64) void kht_vote_kernel(KhtGpuArgs a)
+{
+	const int id = blockIdx.x * blockDim.x + threadIdx.x;
+	if (id >= a.nKernels * 4) return;
+	const KhtVoteParams p = a.params[id >> 2];
+	const int quad = id & 3;
+	// the four quadrants (:1080-1083)
+	int incRhoIndex = (quad & 2) ? -1 : 1;
+	const int incThetaIndex = (quad & 1) ? -1 : 1;
+	unsigned long long rhoStartIndex = (unsigned long long)p.rhoIndex - ((quad & 2) ? 1u : 0u);
+	unsigned long long thetaIndex = (unsigned long long)p.thetaIndex - ((quad & 1) ? 1u : 0u);
+	const double rhoStart = (quad & 2) ? -a.dRho : 0.0;
+	const double thetaStart = (quad & 1) ? -a.dThetaDeg : 0.0;
+
+	const unsigned long long rhoSize = (unsigned long long)a.rhoN, thetaSize = (unsigned long long)a.T;
+	const double incRho = a.dRho * incRhoIndex;      // fixed before any wrap-around flips incRhoIndex (:1092)
+	const double incTheta = a.dThetaDeg * incThetaIndex;
+	double theta = thetaStart, rho;
+	unsigned long long thetaCount = 0;
+	do {
+		// kernel exceeds the parameter-space limits: wrap theta, mirror rho (:1114-1118)
+		if (!thetaIndex || thetaIndex > thetaSize) {
+			rhoStartIndex = (rhoSize - rhoStartIndex) + 1;
+			thetaIndex = thetaIndex ? 1 : thetaSize;
+			incRhoIndex = -incRhoIndex;
+		}
+		if (rhoStartIndex >= 1) {
+			int32_t* pcount = a.counts + thetaIndex * (unsigned long long)a.stride;
+			unsigned long long rhoIndex = rhoStartIndex;
+			rho = rhoStart;
+			const double w = (theta * theta) * p.stsScale;
+			const double k = p.r2 * theta * p.sScale;
+			double krho = k * rho;
+			const double ki = k * incRho;
+			double z = ((rho * rho) * p.srsScale) - krho + w;
+			int votes;
+			while ((rhoIndex <= rhoSize) && (votes = (int)(((p.x * exp_fast_small(-z * p.y)) * a.gs) + 0.5)) > 0) {
+				atomicAdd(&pcount[rhoIndex], votes);
+				rhoIndex += (long long)incRhoIndex;
+				rho += incRho;
+				krho += ki;
+				z = ((rho * rho) * p.srsScale) - krho + w;
+			}
+			thetaIndex += (long long)incThetaIndex;
+			theta += incTheta;
+		}
+		else break;
+	} while ((rho != rhoStart) && (++thetaCount < thetaSize));
+}
+
+__device__ __forceinline__ int smooth3x3(const int32_t* c, int stride)
+{
+	const int32_t *t = c - stride, *b = c + stride;
+	return t[-1] + (t[0] << 1) + t[1] + b[-1] + (b[0] << 1) + b[1] + (c[-1] << 1) + (c[0] << 2) + (c[1] << 1);
+}
+
+__global__ __launch_bounds__(256) void kht_peaks_kernel(KhtGpuArgs a, int sseCovEnd, int consumed, int remains, int simd)
+{
+	const int ti = blockIdx.y + 1;                           // theta index 1 .. T-1 (:437)
+	const int c = blockIdx.x * blockDim.x + threadIdx.x + 1; // column 1 .. rhoN
+	if (ti >= a.T || c > a.rhoN) return;
+	const int vs = a.rhoN + 2;
+	const int32_t* cell = a.counts + (size_t)ti * a.stride + c;
+	const int v = *cell;
+	if (!v) return;
+	int emitRho = -1; uint32_t order = 0;
+	if (simd) {
+		if (c < sseCovEnd) { if (v > 0) { emitRho = c; order = (uint32_t)ti * 2u * vs + c; } }
+		else if (c > consumed && c < consumed + remains) { emitRho = c - consumed; order = (uint32_t)ti * 2u * vs + vs + (c - consumed); } // quirk Q6
+	}
+	else if (c < a.rhoN) { emitRho = c; order = (uint32_t)ti * 2u * vs + c; }
+	if (emitRho < 0) return;
+	const int s = smooth3x3(cell, a.stride);
+	if (s < a.threshold) return;
+	const int idx = atomicAdd(a.cellCount, 1);
+	if (idx < a.cellCap) {
+		KhtCell o; o.order = order; o.rhoIndex = (uint32_t)emitRho; o.thetaIndex = (uint32_t)ti; o.count = s;
+		a.cells[idx] = o;
+	}
+}
+
+hipError_t launch_kht_vote(const KhtGpuArgs& a, hipStream_t stream)
+{
+	if (a.nKernels <= 0) return hipSuccess;
+	const int threads = a.nKernels * 4;
+	hipLaunchKernelGGL(kht_vote_kernel, dim3((threads + 63) / 64), dim3(64), 0, stream, a);
+	return hipGetLastError();
+}
+
+hipError_t launch_kht_peaks(const KhtGpuArgs& a, hipStream_t stream)
+{
+	// column coverage of the reference's scan (:1166-1187): SSE2 groups of 4 from column 1 while rho_index < rhoN-3, then a
+	// scalar remainder that starts at (rhoN & ~3) + 1
+	const int simd = a.rhoN > 4;
+	int sseCovEnd = 1, consumed = a.rhoN + 1, remains = 0;
+	if (simd) {
+		const int sseEnd = a.rhoN - 3;
+		const int iters = (sseEnd - 1 + 3) / 4; // ri = 1, 5, ... < sseEnd
+		sseCovEnd = 1 + 4 * (iters > 0 ? iters : 0);
+		consumed = (a.rhoN & ~3) + 1;
+		remains = a.rhoN > consumed ? a.rhoN - consumed : 0;
+	}
+	dim3 grid((a.rhoN + 255) / 256, a.T > 1 ? a.T - 1 : 1);
+	hipLaunchKernelGGL(kht_peaks_kernel, grid, dim3(256), 0, stream, a, sseCovEnd, consumed, remains, simd);
+	return hipGetLastError();
+}
+
+} // namespace compvhip

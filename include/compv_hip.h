@@ -106,6 +106,19 @@ COMPVHIP_API int compvhip_houghsht_u8(compvhip_ctx* ctx, const uint8_t* edges, s
                                       compvhip_line* lines, size_t cap, size_t* n,
                                       int32_t* acc, size_t accStride);
 
+/* CompVHoughKht::process (core/features/hough/compv_core_feature_houghkht.cxx:208-447): kernel-based Hough transform.
+ * rho in (0,1], thetaDeg in degrees, threshold on the 3x3-smoothed vote count, maxLines <= 0 keeps every line;
+ * clusterMinDeviation / clusterMinSize / kernelMinHeight are the COMPV_HOUGHKHT_SET_* knobs (defaults 2.0, 10, 0.002,
+ * houghkht.cxx:38-40).  Lines come back in the reference's order (descending smoothed count, the reference's own
+ * std::sort tie order); rho is measured from the image centre (toCartesian, :1249-1280); row/col of compvhip_line hold
+ * the rho/theta indices.  *gs receives COMPV_HOUGHKHT_GET_FLT64_GS when kernels survive (left untouched otherwise, like
+ * the reference's m_dGS).  Hybrid: edge linking, cluster subdivision, per-cluster statistics and the final sweep are
+ * sequential and run on the host inside this library; Gaussian voting and vote-map smoothing run on the GPU. */
+COMPVHIP_API int compvhip_houghkht_u8(compvhip_ctx* ctx, const uint8_t* edges, size_t W, size_t H, size_t S,
+                                      float rho, float thetaDeg, int threshold, int maxLines,
+                                      double clusterMinDeviation, size_t clusterMinSize, double kernelMinHeight,
+                                      compvhip_line* lines, size_t cap, size_t* n, double* gs);
+
 /* Geometry helper: R (rho rows), T (theta bins) and the float32 theta step for a W x H image
  * (initCoords, houghsht.cxx:318-348). */
 COMPVHIP_API int compvhip_houghsht_dims(size_t W, size_t H, float thetaDeg, size_t* R, size_t* T, float* thetaStepRad);

@@ -1,6 +1,6 @@
 // compv_hip_plugin.cxx -- the reference-side binding: CompV C++ classes that implement CompV's own abstract
 // CompVEdgeDete / CompVHough interfaces on top of the C ABI in include/compv_hip.h, and the factory table that
-// re-registers the ids COMPV_CANNY_ID / COMPV_SOBEL_ID / COMPV_SCHARR_ID / COMPV_PREWITT_ID / COMPV_HOUGHSHT_ID.
+// re-registers the ids COMPV_CANNY_ID / COMPV_SOBEL_ID / COMPV_SCHARR_ID / COMPV_PREWITT_ID / COMPV_HOUGHSHT_ID / COMPV_HOUGHKHT_ID.
 //
 // CompVFeature::addFactory() REPLACES an existing id (base/compv_features.cxx:30-40), so after
 //     CompVInit(); compv_hip_plugin_register();
@@ -315,6 +315,161 @@ private:
 };
 
 // ------------------------------------------------------------------------------------------------------------------
+// Hough KHT  (replaces CompVHoughKht)
+// ------------------------------------------------------------------------------------------------------------------
+class CompVHoughKhtHip : public CompVHough
+{
+protected:
+	CompVHoughKhtHip(float rho, float thetaDeg, size_t threshold)
+		: CompVHough(COMPV_HOUGHKHT_ID), m_fRho(rho), m_fThetaDeg(thetaDeg), m_nThreshold(threshold), m_nMaxLines(INT_MAX)
+		, m_dClusterMinDeviation(2.0), m_nClusterMinSize(10), m_dKernelMinHeight(0.002), m_dGS(1.0) { } // houghkht.cxx:38-40,117-129
+public:
+	virtual ~CompVHoughKhtHip() { }
+	COMPV_OBJECT_GET_ID(CompVHoughKhtHip);
+
+	// ids / checks of CompVHoughKht::set (houghkht.cxx:140-192)
+	virtual COMPV_ERROR_CODE set(int id, const void* valuePtr, size_t valueSize) override
+	{
+		COMPV_CHECK_EXP_RETURN(!valuePtr || !valueSize, COMPV_ERROR_CODE_E_INVALID_PARAMETER);
+		switch (id) {
+		case COMPV_HOUGH_SET_FLT32_RHO: {
+			COMPV_CHECK_EXP_RETURN(valueSize != sizeof(compv_float32_t) || *reinterpret_cast<const compv_float32_t*>(valuePtr) <= 0.f || *reinterpret_cast<const compv_float32_t*>(valuePtr) > 1.f, COMPV_ERROR_CODE_E_INVALID_PARAMETER);
+			m_fRho = *reinterpret_cast<const compv_float32_t*>(valuePtr);
+			return COMPV_ERROR_CODE_S_OK;
+		}
+		case COMPV_HOUGH_SET_FLT32_THETA: {
+			COMPV_CHECK_EXP_RETURN(valueSize != sizeof(compv_float32_t) || *reinterpret_cast<const compv_float32_t*>(valuePtr) <= 0.f, COMPV_ERROR_CODE_E_INVALID_PARAMETER);
+			m_fThetaDeg = *reinterpret_cast<const compv_float32_t*>(valuePtr);
+			return COMPV_ERROR_CODE_S_OK;
+		}
+		case COMPV_HOUGH_SET_INT_THRESHOLD: {
+			COMPV_CHECK_EXP_RETURN(valueSize != sizeof(int) || *reinterpret_cast<const int*>(valuePtr) <= 0, COMPV_ERROR_CODE_E_INVALID_PARAMETER);
+			m_nThreshold = static_cast<size_t>(*reinterpret_cast<const int*>(valuePtr));
+			return COMPV_ERROR_CODE_S_OK;
+		}
+		case COMPV_HOUGH_SET_INT_MAXLINES: {
+			COMPV_CHECK_EXP_RETURN(valueSize != sizeof(int), COMPV_ERROR_CODE_E_INVALID_PARAMETER);
+			m_nMaxLines = static_cast<size_t>(*reinterpret_cast<const int*>(valuePtr) <= 0 ? INT_MAX : *reinterpret_cast<const int*>(valuePtr));
+			return COMPV_ERROR_CODE_S_OK;
+		}
+		case COMPV_HOUGHKHT_SET_FLT32_CLUSTER_MIN_DEVIATION: {
+			COMPV_CHECK_EXP_RETURN(valueSize != sizeof(compv_float32_t) || *reinterpret_cast<const compv_float32_t*>(valuePtr) <= 0.f, COMPV_ERROR_CODE_E_INVALID_PARAMETER);
+			m_dClusterMinDeviation = static_cast<double>(*reinterpret_cast<const compv_float32_t*>(valuePtr));
+			return COMPV_ERROR_CODE_S_OK;
+		}
+		case COMPV_HOUGHKHT_SET_INT_CLUSTER_MIN_SIZE: {
+			COMPV_CHECK_EXP_RETURN(valueSize != sizeof(int) || *reinterpret_cast<const int*>(valuePtr) <= 0, COMPV_ERROR_CODE_E_INVALID_PARAMETER);
+			m_nClusterMinSize = static_cast<size_t>(*reinterpret_cast<const int*>(valuePtr));
+			return COMPV_ERROR_CODE_S_OK;
+		}
+		case COMPV_HOUGHKHT_SET_FLT32_KERNEL_MIN_HEIGTH: {
+			COMPV_CHECK_EXP_RETURN(valueSize != sizeof(compv_float32_t) || *reinterpret_cast<const compv_float32_t*>(valuePtr) <= 0.f, COMPV_ERROR_CODE_E_INVALID_PARAMETER);
+			m_dKernelMinHeight = static_cast<double>(*reinterpret_cast<const compv_float32_t*>(valuePtr));
+			return COMPV_ERROR_CODE_S_OK;
+		}
+		case COMPV_HOUGHKHT_SET_BOOL_OVERRIDE_INPUT_EDGES: {
+			COMPV_CHECK_EXP_RETURN(valueSize != sizeof(bool), COMPV_ERROR_CODE_E_INVALID_PARAMETER);
+			return COMPV_ERROR_CODE_S_OK; // the HIP path always works on its own copy: nothing to override
+		}
+		default: {
+			COMPV_DEBUG_ERROR_EX(COMPV_THIS_CLASSNAME, "Set with id %d not implemented", id);
+			return COMPV_ERROR_CODE_E_NOT_IMPLEMENTED;
+		}
+		}
+	}
+
+	// COMPV_HOUGHKHT_GET_FLT64_GS (houghkht.cxx:194-206)
+	virtual COMPV_ERROR_CODE get(int id, const void** valuePtrPtr, size_t valueSize) override
+	{
+		COMPV_CHECK_EXP_RETURN(!valuePtrPtr || !valueSize, COMPV_ERROR_CODE_E_INVALID_PARAMETER);
+		switch (id) {
+		case COMPV_HOUGHKHT_GET_FLT64_GS: {
+			COMPV_CHECK_EXP_RETURN(valueSize != sizeof(compv_float64_t), COMPV_ERROR_CODE_E_INVALID_PARAMETER);
+			*reinterpret_cast<compv_float64_t*>(const_cast<void*>(*valuePtrPtr)) = m_dGS;
+			return COMPV_ERROR_CODE_S_OK;
+		}
+		default:
+			return COMPV_ERROR_CODE_E_NOT_IMPLEMENTED;
+		}
+	}
+
+	virtual COMPV_ERROR_CODE process(const CompVMatPtr& edges, CompVHoughLineVector& lines, const CompVMatPtr& directions = NULL) override
+	{
+		COMPV_CHECK_EXP_RETURN(!edges || edges->isEmpty(), COMPV_ERROR_CODE_E_INVALID_PARAMETER, "Edges null or empty");
+		COMPV_CHECK_EXP_RETURN(edges->elmtInBytes() != sizeof(uint8_t) || edges->planeCount() != 1, COMPV_ERROR_CODE_E_INVALID_PARAMETER, "Edges must be 8U_1D (e.g. grayscale image)");
+		compvhip_ctx* ctx = NULL;
+		COMPV_CHECK_CODE_RETURN(m_Ctx.get(&ctx));
+		lines.clear();
+		const int maxLines = (m_nMaxLines >= static_cast<size_t>(INT_MAX)) ? 0 : static_cast<int>(m_nMaxLines);
+		size_t n = 0;
+		if (m_Lines.size() < 4096) m_Lines.resize(4096);
+		int rc = COMPVHIP_OK;
+		for (int attempt = 0; attempt < 2; ++attempt) {
+			rc = compvhip_houghkht_u8(ctx, edges->ptr<const uint8_t>(), edges->cols(), edges->rows(), edges->stride(), m_fRho, m_fThetaDeg,
+				static_cast<int>(m_nThreshold), maxLines, m_dClusterMinDeviation, m_nClusterMinSize, m_dKernelMinHeight, m_Lines.data(), m_Lines.size(), &n, &m_dGS);
+			if (rc != COMPVHIP_E_OUT_OF_BOUND) break;
+			m_Lines.resize(n);
+		}
+		COMPVHIP_CHECK(ctx, rc);
+		lines.reserve(n);
+		for (size_t i = 0; i < n; ++i) lines.push_back(CompVHoughLine(m_Lines[i].rho, m_Lines[i].theta, static_cast<size_t>(m_Lines[i].strength)));
+		return COMPV_ERROR_CODE_S_OK;
+	}
+
+	// rho is measured from the image centre: same arithmetic as houghkht.cxx:1249-1280
+	virtual COMPV_ERROR_CODE toCartesian(const size_t imageWidth, const size_t imageHeight, const CompVHoughLineVector& polar, CompVLineFloat32Vector& cartesian) override
+	{
+		COMPV_CHECK_EXP_RETURN(!imageWidth || !imageHeight, COMPV_ERROR_CODE_E_INVALID_PARAMETER);
+		cartesian.clear();
+		if (polar.empty()) return COMPV_ERROR_CODE_S_OK;
+		cartesian.resize(polar.size());
+		const compv_float32_t widthF = static_cast<compv_float32_t>(imageWidth);
+		const compv_float32_t heightF = static_cast<compv_float32_t>(imageHeight);
+		const compv_float32_t r = std::sqrt((widthF * widthF) + (heightF * heightF));
+		const compv_float32_t half_widthF = widthF * 0.5f, half_heightF = heightF * 0.5f;
+		for (size_t k = 0; k < polar.size(); ++k) {
+			const compv_float32_t rho = polar[k].rho, theta = polar[k].theta;
+			CompVLineFloat32& l = cartesian[k];
+			if (theta == 0.f) {
+				l.a.x = l.b.x = (rho + half_widthF);
+				l.a.y = r;
+				l.b.y = -r;
+			}
+			else {
+				const compv_float32_t a = (std::cos(theta) * half_widthF), b = (1.f / std::sin(theta));
+				l.a.x = 0;
+				l.a.y = ((rho + a) * b) + half_heightF;
+				l.b.x = widthF;
+				l.b.y = ((rho - a) * b) + half_heightF;
+			}
+			l.a.z = l.b.z = 1.f;
+		}
+		return COMPV_ERROR_CODE_S_OK;
+	}
+
+	static COMPV_ERROR_CODE newObj(CompVHoughPtrPtr hough, float rho, float theta, size_t threshold)
+	{
+		COMPV_CHECK_EXP_RETURN(!hough || rho <= 0 || rho > 1.f, COMPV_ERROR_CODE_E_INVALID_PARAMETER);
+		CompVPtr<CompVHoughKhtHip*> hough_ = new CompVHoughKhtHip(rho, theta, threshold);
+		COMPV_CHECK_EXP_RETURN(!hough_, COMPV_ERROR_CODE_E_OUT_OF_MEMORY);
+		*hough = *hough_;
+		return COMPV_ERROR_CODE_S_OK;
+	}
+
+private:
+	CompVHipCtxHolder m_Ctx;
+	float m_fRho;
+	float m_fThetaDeg;
+	size_t m_nThreshold;
+	size_t m_nMaxLines;
+	double m_dClusterMinDeviation;
+	size_t m_nClusterMinSize;
+	double m_dKernelMinHeight;
+	double m_dGS;
+	std::vector<compvhip_line> m_Lines;
+};
+
+// ------------------------------------------------------------------------------------------------------------------
 // factory table (file-static: addFactory stores the POINTER, core/compv_core.cxx:56-103 does the same)
 // ------------------------------------------------------------------------------------------------------------------
 static const CompVFeatureFactory cannyHipFactory = { COMPV_CANNY_ID, "Canny edge detector (HIP/gfx950)", nullptr, nullptr, CompVEdgeDeteCannyHip::newObj, nullptr, nullptr };
@@ -322,6 +477,7 @@ static const CompVFeatureFactory sobelHipFactory = { COMPV_SOBEL_ID, "Sobel edge
 static const CompVFeatureFactory scharrHipFactory = { COMPV_SCHARR_ID, "Scharr edge detector (HIP/gfx950)", nullptr, nullptr, CompVEdgeDeteBaseHip::newObjScharr, nullptr, nullptr };
 static const CompVFeatureFactory prewittHipFactory = { COMPV_PREWITT_ID, "Prewitt edge detector (HIP/gfx950)", nullptr, nullptr, CompVEdgeDeteBaseHip::newObjPrewitt, nullptr, nullptr };
 static const CompVFeatureFactory houghShtHipFactory = { COMPV_HOUGHSHT_ID, "Hough standard (HIP/gfx950)", nullptr, nullptr, nullptr, CompVHoughShtHip::newObj, nullptr };
+static const CompVFeatureFactory houghKhtHipFactory = { COMPV_HOUGHKHT_ID, "Hough kernel-based (HIP/gfx950)", nullptr, nullptr, nullptr, CompVHoughKhtHip::newObj, nullptr };
 
 COMPV_NAMESPACE_END()
 
@@ -338,5 +494,6 @@ extern "C" __attribute__((visibility("default"))) int compv_hip_plugin_register(
 	if (COMPV_ERROR_CODE_IS_NOK(CompVFeature::addFactory(&scharrHipFactory))) return -2;
 	if (COMPV_ERROR_CODE_IS_NOK(CompVFeature::addFactory(&prewittHipFactory))) return -2;
 	if (COMPV_ERROR_CODE_IS_NOK(CompVFeature::addFactory(&houghShtHipFactory))) return -2;
+	if (COMPV_ERROR_CODE_IS_NOK(CompVFeature::addFactory(&houghKhtHipFactory))) return -2;
 	return 0;
 }

@@ -49,6 +49,9 @@ struct Result {
 	std::vector<uint8_t> sobel, canny, cannyMean;
 	std::vector<std::tuple<float, float, size_t> > lines;
 	std::vector<float> cart;
+	std::vector<std::tuple<float, float, size_t> > khtLines; // in the order returned (the reference's sweep order)
+	std::vector<float> khtCart;
+	double khtGS;
 	double ms;
 };
 
@@ -79,6 +82,28 @@ static COMPV_ERROR_CODE runSamples(size_t W, size_t H, uint32_t seed, Result& r)
 	COMPV_CHECK_CODE_RETURN(ptrHough->setInt(COMPV_HOUGH_SET_INT_MAXLINES, 0));
 	COMPV_CHECK_CODE_RETURN(ptrHough->process(mat, linesPolar));
 	COMPV_CHECK_CODE_RETURN(ptrHough->toCartesian(mat->cols(), mat->rows(), linesPolar, linesCartesian));
+
+	// samples/hough_lines/main.cxx:59-72 with HOUGH_ID == COMPV_HOUGHKHT_ID: newObj(rho, theta, HOUGHKHT_THRESHOLD) + the three KHT knobs
+	{
+		CompVHoughPtr ptrKht;
+		CompVHoughLineVector khtPolar;
+		CompVLineFloat32Vector khtCartesian;
+		COMPV_CHECK_CODE_RETURN(CompVHough::newObj(&ptrKht, COMPV_HOUGHKHT_ID, 1.f, 1.f, 1));
+		COMPV_CHECK_CODE_RETURN(ptrKht->setInt(COMPV_HOUGH_SET_INT_MAXLINES, 0));
+		COMPV_CHECK_CODE_RETURN(ptrKht->setFloat32(COMPV_HOUGHKHT_SET_FLT32_CLUSTER_MIN_DEVIATION, 2.0f));
+		COMPV_CHECK_CODE_RETURN(ptrKht->setInt(COMPV_HOUGHKHT_SET_INT_CLUSTER_MIN_SIZE, 10));
+		COMPV_CHECK_CODE_RETURN(ptrKht->setFloat32(COMPV_HOUGHKHT_SET_FLT32_KERNEL_MIN_HEIGTH, 0.002f));
+		COMPV_CHECK_CODE_RETURN(ptrKht->process(mat, khtPolar));
+		COMPV_CHECK_CODE_RETURN(ptrKht->toCartesian(mat->cols(), mat->rows(), khtPolar, khtCartesian));
+		compv_float64_t gs = 0;
+		COMPV_CHECK_CODE_RETURN(ptrKht->getFloat64(COMPV_HOUGHKHT_GET_FLT64_GS, &gs));
+		r.khtGS = gs;
+		r.khtLines.clear(); r.khtCart.clear();
+		for (size_t i = 0; i < khtPolar.size(); ++i) {
+			r.khtLines.push_back(std::make_tuple(khtPolar[i].rho, khtPolar[i].theta, khtPolar[i].strength));
+			r.khtCart.push_back(khtCartesian[i].a.x); r.khtCart.push_back(khtCartesian[i].a.y); r.khtCart.push_back(khtCartesian[i].b.x); r.khtCart.push_back(khtCartesian[i].b.y);
+		}
+	}
 
 	// hough_lines sets the Canny thresholds per frame through set(): PERCENT_OF_MEAN variant
 	COMPV_CHECK_CODE_RETURN(ptrCanny->setInt(COMPV_CANNY_SET_INT_THRESHOLD_TYPE, COMPV_CANNY_THRESHOLD_TYPE_PERCENT_OF_MEAN));
@@ -136,10 +161,11 @@ int main(int argc, char** argv)
 	for (int f = 0; f < frames; ++f) {
 		const bool okS = cpu[f].sobel == gpu[f].sobel, okC = cpu[f].canny == gpu[f].canny, okM = cpu[f].cannyMean == gpu[f].cannyMean;
 		const bool okL = cpu[f].lines == gpu[f].lines, okX = cpu[f].cart == gpu[f].cart;
+		const bool okK = cpu[f].khtLines == gpu[f].khtLines && cpu[f].khtCart == gpu[f].khtCart && cpu[f].khtGS == gpu[f].khtGS;
 		size_t e = 0; for (uint8_t v : cpu[f].canny) e += v ? 1 : 0;
-		printf("frame %d (%zux%zu): sobel %s, canny(in-place) %s [%zu edge px], canny(mean mode) %s, hough lines %s [%zu], cartesian %s | CompV CPU %.2f ms, HIP plugin %.2f ms (incl. H2D/D2H)\n",
-			f, W, H, okS ? "==" : "DIFF", okC ? "==" : "DIFF", e, okM ? "==" : "DIFF", okL ? "==" : "DIFF", cpu[f].lines.size(), okX ? "==" : "DIFF", cpu[f].ms, gpu[f].ms);
-		bad += !(okS && okC && okM && okL && okX);
+		printf("frame %d (%zux%zu): sobel %s, canny(in-place) %s [%zu edge px], canny(mean mode) %s, hough lines %s [%zu], cartesian %s, KHT lines+order+GS %s [%zu] | CompV CPU %.2f ms, HIP plugin %.2f ms (incl. H2D/D2H)\n",
+			f, W, H, okS ? "==" : "DIFF", okC ? "==" : "DIFF", e, okM ? "==" : "DIFF", okL ? "==" : "DIFF", cpu[f].lines.size(), okX ? "==" : "DIFF", okK ? "==" : "DIFF", cpu[f].khtLines.size(), cpu[f].ms, gpu[f].ms);
+		bad += !(okS && okC && okM && okL && okX && okK);
 	}
 	printf(bad ? "DROP-IN PARITY FAILED\n" : "DROP-IN PARITY OK\n");
 	return bad ? 1 : 0;

@@ -264,3 +264,50 @@ def test_no_leaks(oracle):
     # destroy hostPlan & staging, then the count must return to zero just before the ctx itself goes
     ctx.close()
     assert ctx.h is None
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# KHT (BASELINE config 5): hybrid host/GPU path vs oracle and vs the fixtures from the compiled reference
+# ---------------------------------------------------------------------------------------------------------------
+def _kht_tuple(lines):
+    return [(float(l["rho"]), float(l["theta"]), int(l["strength"])) for l in lines]
+
+
+@pytest.mark.parametrize("W,H,tl,th,rho,deg,thr", [(320, 240, 59., 119., 1.0, 1.0, 1), (641, 480, 59., 119., 1.0, 1.0, 1), (640, 480, 59., 119., 0.5, 1.0, 1),
+                                                     (480, 360, 59., 119., 1.0, 0.5, 150), (257, 129, 0.8, 1.6, 1.0, 2.0, 1), (333, 77, 0.8, 1.6, 1.0, 1.0, 1)])
+def test_houghkht_matches_oracle(hip_ctx, oracle, W, H, tl, th, rho, deg, thr):
+    img = synth_frame(W, H, 99)
+    rc, edges = oracle.canny(img, tl, th)
+    exp, gs_exp = oracle.kht(edges, rho, deg, thr)
+    got, gs = hip_ctx.houghkht(edges, rho, deg, thr)
+    assert gs == gs_exp                                      # COMPV_HOUGHKHT_GET_FLT64_GS, bit-exact
+    assert _kht_tuple(got) == [(float(np.float32(l[0])), float(np.float32(l[1])), int(l[2])) for l in exp]   # values AND order
+    if len(exp) > 3:
+        top, _ = hip_ctx.houghkht(edges, rho, deg, thr, max_lines=3)
+        assert _kht_tuple(top) == _kht_tuple(got[:3])
+
+
+@pytest.mark.parametrize("name", ["small_320x240", "hd_1280x720", "fhd_1920x1080", "dense_1282x720", "uhd_3840x2160"])
+def test_houghkht_golden(hip_ctx, golden, name):
+    """Line set (values and order) and GS recorded from the compiled reference; 4K = BASELINE config 5."""
+    meta, arrays = golden
+    m = meta[name]
+    img = synth_frame(m["W"], m["H"], m["seed"])
+    can = hip_ctx.canny(img, m["tLow"], m["tHigh"], 3, m["threshold_type"])
+    lines, gs = hip_ctx.houghkht(can, 1.0, 1.0, 1)
+    k = m["kht"]
+    assert repr(gs) == k["gs"]
+    assert len(lines) == k["lines"]
+    exp = arrays[name + "/kht_lines"]
+    got = np.stack([lines["rho"].astype(np.float64), lines["theta"].astype(np.float64), lines["strength"].astype(np.float64)], axis=1)
+    assert (got == exp).all()
+
+
+def test_houghkht_empty_and_errors(hip_ctx):
+    from compv_amd import capi
+    e = np.zeros((64, 64), np.uint8)
+    lines, gs = hip_ctx.houghkht(e)
+    assert len(lines) == 0 and gs == 1.0
+    with pytest.raises(capi.CompvHipError) as ex:
+        hip_ctx.houghkht(e, rho=1.5)                           # rho must be in (0,1] (houghkht.cxx:491)
+    assert ex.value.code == capi.E_INVALID_PARAMETER
