@@ -265,14 +265,14 @@ ShtArgs shtArgs(compvhip_plan* p, int threshold)
 }
 
 // Enqueue canny tiles + `rounds` speculative resolve rounds starting at p->roundsUsed.
-int enqueueCanny(compvhip_plan* p, const uint8_t* d_in, uint8_t* d_out, int tLow, int tHigh, bool meanMode, float fLow, float fHigh, hipStream_t st)
+int enqueueCanny(compvhip_plan* p, const uint8_t* d_in, uint8_t* d_out, int tLow, int tHigh, int ksize, bool meanMode, float fLow, float fHigh, hipStream_t st)
 {
 	compvhip_ctx* ctx = p->ctx;
 	CannyArgs a;
 	a.in = d_in; a.out = d_out; a.ebits = p->ebits; a.ubits = p->ubits; a.thrDev = meanMode ? p->thrDev : nullptr;
 	a.inFrameStride = p->S * p->H; a.outFrameStride = p->S * p->H; a.bitsFrameStride = p->bitsFrameStride;
 	a.W = static_cast<int>(p->W); a.H = static_cast<int>(p->H); a.S = static_cast<int>(p->S); a.So = static_cast<int>(p->S);
-	a.wb = p->wb; a.tilesX = p->tilesX; a.tilesY = p->tilesY; a.tLow = tLow; a.tHigh = tHigh;
+	a.wb = p->wb; a.tilesX = p->tilesX; a.tilesY = p->tilesY; a.tLow = tLow; a.tHigh = tHigh; a.ksize = ksize;
 	cannyCoverage(p->W, &a.simdEnd, &a.cStart);
 	// coverage [1,simdEnd) U [cStart,W-1) equals the whole interior unless the two pieces leave a hole (W = 1 mod 16 ...)
 	const bool gap = !((a.simdEnd >= a.W - 1) || (a.cStart <= a.simdEnd));
@@ -322,7 +322,6 @@ int validateCannyParams(compvhip_ctx* ctx, float tLow, float tHigh, int ksize, i
 	if (type != COMPVHIP_CANNY_THRESHOLD_COMPARE_TO_GRADIENT && type != COMPVHIP_CANNY_THRESHOLD_PERCENT_OF_MEAN)
 		return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "invalid threshold type"); // :83
 	if (tLow >= tHigh) return fail(ctx, COMPVHIP_E_INVALID_STATE, "tLow >= tHigh"); // :126
-	if (ksize == 5) return fail(ctx, COMPVHIP_E_NOT_IMPLEMENTED, "5x5 Sobel in Canny: next scope row (SURVEY 8f-3)");
 	*lo = 0; *hi = 0;
 	if (type == COMPVHIP_CANNY_THRESHOLD_COMPARE_TO_GRADIENT) {
 		gradientThresholds(tLow, tHigh, lo, hi);
@@ -462,8 +461,9 @@ static int planCannyImpl(compvhip_plan* p, const uint8_t* d_in, float tLow, floa
 		if (!p->tmpOut) HIPCHK(ctx, dmalloc(ctx, &p->tmpOut, bytes));
 		out = p->tmpOut;
 	}
+	if (p->W < static_cast<size_t>(ksize) || p->H < static_cast<size_t>(ksize)) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "image smaller than the kernel"); // compv_math_convlt.h:100
 	const bool mean = (type == COMPVHIP_CANNY_THRESHOLD_PERCENT_OF_MEAN);
-	rc = enqueueCanny(p, d_in, out, lo, hi, mean, tLow, tHigh, st);
+	rc = enqueueCanny(p, d_in, out, lo, hi, ksize, mean, tLow, tHigh, st);
 	if (rc) return rc;
 	rc = enqueueResolve(p, out, kSpecRounds, st);
 	if (rc) return rc;

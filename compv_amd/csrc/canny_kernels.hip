@@ -92,9 +92,10 @@ __device__ __forceinline__ void flood_down(const uint64_t (&W)[8], uint64_t (&S)
 // ---------------------------------------------------------------------------------------------------------------
 // Kernel 1
 // ---------------------------------------------------------------------------------------------------------------
-template <bool GAP>
+template <int KS, bool GAP>
 __global__ __launch_bounds__(kCannyWaves * 64) void canny_tile_kernel(CannyArgs a)
 {
+	constexpr int R = KS / 2; // kernel radius = width of the zero OUTPUT border of the gradient
 	constexpr int kMaskPitch = 33; // 32 mask dwords per row + 1: lane==row reads are bank-conflict free
 	__shared__ uint32_t lds_masks[kCannyWaves][kTileH][kMaskPitch];
 
@@ -118,14 +119,14 @@ __global__ __launch_bounds__(kCannyWaves * 64) void canny_tile_kernel(CannyArgs 
 
 	// columns gi = 0..9 <-> x = x0-1+gi: g is forced to 0 outside [1, W-2] (zero OUTPUT border of the convolution,
 	// compv_math_convlt.h:181-209) -- only tiles touching column 0 or W-1.. need the per-column test.
-	const bool edgeTile = (tileX == 0) || ((tileX + 1) * kTileW + 1 >= W - 1);
+	const bool edgeTile = (tileX == 0) || ((tileX + 1) * kTileW + 1 >= W - R);
 	uint32_t colok = 0x3ffu;
 	if (edgeTile) {
 		colok = 0;
 #pragma unroll
 		for (int gi = 0; gi < 10; ++gi) {
 			const int x = x0 - 1 + gi;
-			if (x >= 1 && x <= W - 2) colok |= 1u << gi;
+			if (x >= R && x <= W - 1 - R) colok |= 1u << gi;
 		}
 	}
 	// quirk Q3 column coverage of the NMS and of the seed scan: [1,simdEnd) U [cStart,W-1)
@@ -140,10 +141,11 @@ __global__ __launch_bounds__(kCannyWaves * 64) void canny_tile_kernel(CannyArgs 
 	}
 
 	// tiles whose first/last gradient rows fall on the image border rows (g forced to 0 there)
-	const bool vEdgeTile = (tileY == 0) || (y0 + kTileH + 1 >= H - 1);
+	const bool vEdgeTile = (tileY == 0) || (y0 + kTileH + 1 >= H - R);
 
 	Grad3Ring<1, 2> st;
-	st.reset();
+	Grad5State st5;
+	if (KS == 3) st.reset(); else st5.reset();
 	int gr[3][10];           // ring of the last three gradient-magnitude rows
 	int axr[2][8];           // ring of |gx| of the last two gradient rows (direction class is evaluated at NMS time)
 	bool ngr[2][8];          // ring of sign(gx^gy)
@@ -154,26 +156,27 @@ __global__ __launch_bounds__(kCannyWaves * 64) void canny_tile_kernel(CannyArgs 
 
 	uint32_t* maskRows = &lds_masks[wave][0][0];
 
-	RowBytes nextRow = load_row(in + (size_t)min(max(y0 - 2, 0), H - 1) * S, x0, S);
+	RowBytes nextRow = load_row(in + (size_t)min(max(y0 - 1 - R, 0), H - 1) * S, x0, S);
 
-	// One row step.  Input rows y0-2 .. y0+kTileH+1 are pushed; pushing row yin yields the gradient of row yc = yin-1
-	// and allows the NMS of row yo = yc-1.  PH = it mod 6 selects the ring slots at compile time.
+	// One row step.  Input rows y0-1-R .. y0+kTileH+R are pushed; pushing row yin yields the gradient of row yc = yin-R
+	// and allows the NMS of row yo = yc-1.  PH = it mod 6 selects the ring slots at compile time (3x3 path).
 	auto step = [&](auto phase, int it) {
 		constexpr int PH = decltype(phase)::value;
 		constexpr int gNew = PH % 3, gMid = (PH + 2) % 3, gOld = (PH + 1) % 3;
 		constexpr int aNew = PH % 2, aMid = (PH + 1) % 2;
-		const int yin = y0 - 2 + it;
+		const int yin = y0 - 1 - R + it;
 		const RowBytes rb = nextRow;
 		// software prefetch: the next row's loads are in flight while this row is processed
 		nextRow = load_row(in + (size_t)min(max(yin + 1, 0), H - 1) * S, x0, S);
 		int (&gD)[10] = gr[gNew];
 		const int (&gC)[10] = gr[gMid];
 		const int (&gU)[10] = gr[gOld];
-		st.template push<PH & 1>(rb, gD, axr[aNew], ngr[aNew]);
+		if constexpr (KS == 3) st.template push<PH & 1>(rb, gD, axr[aNew], ngr[aNew]);
+		else st5.push(rb, gD, axr[aNew], ngr[aNew]);
 
-		const int yc = yin - 1;
+		const int yc = yin - R;
 		if (vEdgeTile) {
-			if (!((yc >= 1) && (yc <= H - 2))) {
+			if (!((yc >= R) && (yc <= H - 1 - R))) {
 #pragma unroll
 				for (int gi = 0; gi < 10; ++gi) gD[gi] = 0;
 			}
@@ -227,18 +230,30 @@ __global__ __launch_bounds__(kCannyWaves * 64) void canny_tile_kernel(CannyArgs 
 		}
 	};
 
-	static_assert((kTileH + 4) % 6 == 2, "row loop is unrolled by 6 with a 2-step tail");
-	int it = 0;
-	for (; it < kTileH + 4 - 2; it += 6) {
+	if constexpr (KS == 3) {
+		static_assert((kTileH + 4) % 6 == 2, "row loop is unrolled by 6 with a 2-step tail");
+		int it = 0;
+		for (; it < kTileH + 4 - 2; it += 6) {
+			step(std::integral_constant<int, 0>{}, it);
+			step(std::integral_constant<int, 1>{}, it + 1);
+			step(std::integral_constant<int, 2>{}, it + 2);
+			step(std::integral_constant<int, 3>{}, it + 3);
+			step(std::integral_constant<int, 4>{}, it + 4);
+			step(std::integral_constant<int, 5>{}, it + 5);
+		}
 		step(std::integral_constant<int, 0>{}, it);
 		step(std::integral_constant<int, 1>{}, it + 1);
-		step(std::integral_constant<int, 2>{}, it + 2);
-		step(std::integral_constant<int, 3>{}, it + 3);
-		step(std::integral_constant<int, 4>{}, it + 4);
-		step(std::integral_constant<int, 5>{}, it + 5);
 	}
-	step(std::integral_constant<int, 0>{}, it);
-	step(std::integral_constant<int, 1>{}, it + 1);
+	else {
+		// 5x5: plain rolled loop; phase 0 every step (new -> slot 0, centre = slot 2, old = slot 1), then shift the windows
+		for (int it = 0; it < kTileH + 2 + 2 * R; ++it) {
+			step(std::integral_constant<int, 0>{}, it);
+#pragma unroll
+			for (int gi = 0; gi < 10; ++gi) { gr[1][gi] = gr[2][gi]; gr[2][gi] = gr[0][gi]; }
+#pragma unroll
+			for (int p = 0; p < 8; ++p) { axr[1][p] = axr[0][p]; ngr[1][p] = ngr[0][p]; }
+		}
+	}
 
 	// lane == row: fetch this lane's row of masks (rows beyond the image are all-zero: g was forced to 0 there)
 	uint32_t wlo[8], whi[8], slo[8], shi[8];
@@ -462,8 +477,14 @@ hipError_t launch_canny_tiles(const CannyArgs& a0, int frames, bool gap, hipStre
 	a.groups = a.blockRows * frames;
 	dim3 grid(8 * ((a.groups + 7) / 8) * a.tilesX);
 	dim3 block(kCannyWaves * 64);
-	if (gap) hipLaunchKernelGGL(canny_tile_kernel<true>, grid, block, 0, stream, a);
-	else hipLaunchKernelGGL(canny_tile_kernel<false>, grid, block, 0, stream, a);
+	if (a.ksize == 5) {
+		if (gap) hipLaunchKernelGGL((canny_tile_kernel<5, true>), grid, block, 0, stream, a);
+		else hipLaunchKernelGGL((canny_tile_kernel<5, false>), grid, block, 0, stream, a);
+	}
+	else {
+		if (gap) hipLaunchKernelGGL((canny_tile_kernel<3, true>), grid, block, 0, stream, a);
+		else hipLaunchKernelGGL((canny_tile_kernel<3, false>), grid, block, 0, stream, a);
+	}
 	return hipGetLastError();
 }
 

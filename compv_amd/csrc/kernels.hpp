@@ -25,6 +25,7 @@ struct CannyArgs {
 	int tLow, tHigh;
 	int simdEnd, cStart;      // quirk Q3 coverage: [1,simdEnd) U [cStart,W-1)
 	int blockRows, groups;    // filled by the launcher: workgroup rows per frame, row groups in the launch (XCD-aware map)
+	int ksize;                // Sobel kernel size of the gradient: 3 or 5
 };
 
 struct ResolveArgs {

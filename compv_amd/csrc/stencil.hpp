@@ -144,4 +144,51 @@ struct Grad3Ring {
 	}
 };
 
+// 5x5 Sobel (Canny kernel size 5): vt {1,4,6,4,1}, hz {1,2,0,-2,-1} (base/include/compv/base/compv_features.h:129-130).
+// Separable and linear without saturation (|gx|,|gy| <= 12240), so the vertical pass is done first on the unpacked
+// columns and the horizontal pass second -- bit-identical to the reference's hz-then-vt order:
+//   C5[x] = I[y-2]+4I[y-1]+6I[y]+4I[y+1]+I[y+2]     gx = C5[x-2] + 2C5[x-1] - 2C5[x+1] - C5[x+2]
+//   D5[x] = I[y-2]+2I[y-1]-2I[y+1]-I[y+2]           gy = D5[x-2] + 4D5[x-1] + 6D5[x] + 4D5[x+1] + D5[x+2]
+// The rare 5x5 path keeps its four previous input rows in a plain shift register (no phase unrolling).
+struct Grad5State {
+	int rows[4][14]; // input rows y-4 .. y-1, columns x0-3 .. x0+10
+
+	__device__ __forceinline__ void reset()
+	{
+#pragma unroll
+		for (int r = 0; r < 4; ++r)
+#pragma unroll
+			for (int j = 0; j < 14; ++j) rows[r][j] = 0;
+	}
+
+	// Push input row y; yields the gradient of row y-2 (valid once rows y-4..y were pushed).
+	__device__ __forceinline__ void push(const RowBytes& rb, int (&g)[10], int (&axo)[8], bool (&ng)[8])
+	{
+		int cur[14];
+		cur[0] = (rb.l >> 8) & 0xff; cur[1] = (rb.l >> 16) & 0xff; cur[2] = rb.l >> 24;
+		cur[3] = rb.m0 & 0xff; cur[4] = (rb.m0 >> 8) & 0xff; cur[5] = (rb.m0 >> 16) & 0xff; cur[6] = rb.m0 >> 24;
+		cur[7] = rb.m1 & 0xff; cur[8] = (rb.m1 >> 8) & 0xff; cur[9] = (rb.m1 >> 16) & 0xff; cur[10] = rb.m1 >> 24;
+		cur[11] = rb.r & 0xff; cur[12] = (rb.r >> 8) & 0xff; cur[13] = (rb.r >> 16) & 0xff;
+		int C5[14], D5[14];
+#pragma unroll
+		for (int j = 0; j < 14; ++j) {
+			C5[j] = rows[0][j] + 4 * (rows[1][j] + rows[3][j]) + 6 * rows[2][j] + cur[j];
+			D5[j] = rows[0][j] + 2 * (rows[1][j] - rows[3][j]) - cur[j];
+			rows[0][j] = rows[1][j]; rows[1][j] = rows[2][j]; rows[2][j] = rows[3][j]; rows[3][j] = cur[j];
+		}
+#pragma unroll
+		for (int gi = 0; gi < 10; ++gi) {
+			const int j = gi + 2;
+			const int gx = C5[j - 2] + 2 * (C5[j - 1] - C5[j + 1]) - C5[j + 2];
+			const int gy = D5[j - 2] + 4 * (D5[j - 1] + D5[j + 1]) + 6 * D5[j] + D5[j + 2];
+			const int ax = abs(gx), ay = abs(gy);
+			g[gi] = ax + ay;
+			if (gi >= 1 && gi <= 8) {
+				axo[gi - 1] = ax;
+				ng[gi - 1] = (gx ^ gy) < 0;
+			}
+		}
+	}
+};
+
 } // namespace compvhip

@@ -61,6 +61,18 @@ def test_canny_matches_oracle(hip_ctx, oracle, W, H):
             assert (got == exp).all(), (W, H, k, tl, th, int((got != exp).sum()))
 
 
+@pytest.mark.parametrize("W,H", [(9, 9), (20, 20), (64, 64), (129, 130), (513, 65), (641, 333), (1282, 720)])
+def test_canny_5x5_sobel_matches_oracle(hip_ctx, oracle, W, H):
+    """Kernel size 5 (COMPV_CANNY_SET_INT_KERNEL_SIZE): 2-px zero border, |g| up to 24480."""
+    rng = np.random.default_rng(W + H)
+    for img in (synth_frame(W, H, 5), rng.integers(0, 256, (H, W), dtype=np.uint8)):
+        for (tl, th) in [(400.0, 900.0), (0.8, 1.6), (2000.0, 6000.0)]:
+            rc, exp = oracle.canny(img, tl, th, 5)
+            assert rc == 0
+            got = hip_ctx.canny(img, tl, th, ksize=5)
+            assert (got == exp).all(), (W, H, tl, th, int((got != exp).sum()))
+
+
 def test_canny_long_weak_chains(hip_ctx, oracle):
     """Hysteresis stress: weak spirals / long chains with one strong seed cross many tiles and bands."""
     W, H = 1100, 700

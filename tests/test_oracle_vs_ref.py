@@ -50,3 +50,15 @@ def test_sht_acc_and_lines(oracle, refshim, W, H, tl, th, thr, deg):
     acc = oracle.sht_acc(e, deg)
     assert (acc == refshim.sht_acc(e, s, c, R)).all()     # the reference's own SSE4.1/AVX2 voting leaves
     assert _canon_orc(oracle.sht_lines_from_acc(acc, W, H, deg, thr)) == _canon_ref(refshim.sht(e, deg, thr))
+
+
+@pytest.mark.parametrize("W,H", [(64, 64), (129, 130), (640, 480), (641, 333), (20, 20), (9, 9)])
+def test_canny_5x5_sobel(oracle, refshim, W, H):
+    """COMPV_CANNY_SET_INT_KERNEL_SIZE = 5 (kernels compv_features.h:129-130)."""
+    rng = np.random.default_rng(W + H)
+    for img in (synth_frame(W, H, 5), rng.integers(0, 256, (H, W), dtype=np.uint8)):
+        for (tl, th) in [(400.0, 900.0), (0.8, 1.6), (2000.0, 6000.0)]:
+            rc, a = oracle.canny(img, tl, th, 5)
+            rc2, b = refshim.canny(img, tl, th, 5)
+            assert rc == 0 and rc2 == 0
+            assert (a == b).all(), (W, H, tl, th, int((a != b).sum()))
