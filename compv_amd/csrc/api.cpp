@@ -201,7 +201,7 @@ int ensureSht(compvhip_plan* p)
 	if (rc) return fail(ctx, rc, "invalid SHT geometry");
 	if (T < 5) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "theta step too large (fewer than 5 theta bins)");
 	if (p->W + p->H >= 65536) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "W+H must be < 65536 (u16 LDS vote counters)");
-	if (sht_vote_lds_bytes(static_cast<int>(R)) > 160 * 1024) return fail(ctx, COMPVHIP_E_NOT_IMPLEMENTED, "rho range does not fit the LDS histogram");
+	if (sht_vote_lds_bytes(static_cast<int>(R), 2) > 160 * 1024) return fail(ctx, COMPVHIP_E_NOT_IMPLEMENTED, "rho range does not fit the LDS histogram");
 	p->R = R; p->T = T; p->thetaStep = step;
 	p->accPitch = static_cast<int>(alignUp(R, 64));
 	p->accFrameStride = static_cast<size_t>(p->accPitch) * T;
@@ -261,6 +261,8 @@ ShtArgs shtArgs(compvhip_plan* p, int threshold)
 	a.shards = p->shards;
 	a.frames = static_cast<int>(p->frames);
 	a.cellBits = p->cellBits;
+	static const int tg = [] { const char* e = getenv("COMPVHIP_SHT_THETA_PER_GROUP"); return (e && atoi(e) == 2) ? 2 : 4; }(); // tuning knob
+	a.thetaPerGroup = tg;
 	return a;
 }
 

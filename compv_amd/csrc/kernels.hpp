@@ -56,7 +56,6 @@ struct EdgeDeteArgs {
 hipError_t launch_edge_dete(const EdgeDeteArgs& a, int op, int frames, hipStream_t stream);
 
 // ---- Hough SHT ---------------------------------------------------------------------------------------------
-constexpr int kShtThetaPerGroup = 4;  // theta bins per vote workgroup (2 packed u16 pairs per rho row)
 constexpr int kShtVoteThreads = 1024;
 
 struct ShtArgs {
@@ -75,6 +74,7 @@ struct ShtArgs {
 	int shards;               // vote workgroups per (frame, theta group)
 	int frames;
 	int cellBits;             // bits of the accumulator cell index in a line key (2^cellBits > R*T)
+	int thetaPerGroup;        // 4 (default) or 2 theta bins per vote workgroup
 };
 hipError_t launch_bytes_to_bits(const uint8_t* edges, int W, int H, int S, size_t frameStride, uint32_t* ebits, int wb, size_t bitsFrameStride,
                                 int frames, hipStream_t stream);
@@ -85,7 +85,7 @@ hipError_t launch_sht_decode(const uint64_t* keys, const int* counts, size_t lin
                              int maxLines, int cellBits, void* lines /*compvhip_line*/, size_t outCap, hipStream_t stream);
 // acc [T][pitch] -> reference layout [R][stride]
 hipError_t launch_sht_acc_transpose(const int32_t* accT, int R, int T, int accPitch, int32_t* out, size_t outStride, hipStream_t stream);
-size_t sht_vote_lds_bytes(int R);
+size_t sht_vote_lds_bytes(int R, int thetaPerGroup);
 // one descending radix sort over the (unique) 64-bit line keys of all frames; temp == nullptr queries tempBytes
 hipError_t sht_sort_keys(void* temp, size_t& tempBytes, const uint64_t* keysIn, uint64_t* keysOut, size_t lineCap, int frames, int keyBits,
                          hipStream_t stream);

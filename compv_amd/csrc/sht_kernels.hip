@@ -131,29 +131,43 @@ __global__ __launch_bounds__(kCompactThreads) void sht_compact_kernel(ShtArgs a)
 // LDS: two [Rp] arrays of packed u16 counter pairs + a double-buffered staging area of kStageEdges edges laid out
 // [64][kStageCols+1] (the +1 makes both the coalesced row-major fill and the lane==row reads bank-conflict free).
 constexpr int kVoteWaves = kShtVoteThreads / 64;         // 16
-constexpr int kEdgesPerThread = 4;                       // per stage
-constexpr int kStageCols = kVoteWaves * kEdgesPerThread; // 64 edges per lane-row
-constexpr int kStageEdges = 64 * kStageCols;             // 4096 edges per stage
-constexpr int kStagePitch = kStageCols + 1;
 
-size_t sht_vote_lds_bytes(int R) { return ((size_t)((R + 31) & ~31) * 2 + (size_t)2 * 64 * kStagePitch) * sizeof(uint32_t); }
+// TG = theta bins per workgroup (4: one 129 KB workgroup per CU; 2: two 65 KB workgroups per CU, twice the edge staging)
+template <int TG> struct VoteCfg {
+	static constexpr int kEdgesPerThread = TG;                       // per stage
+	static constexpr int kStageCols = kVoteWaves * kEdgesPerThread;  // edges per lane-row
+	static constexpr int kStageEdges = 64 * kStageCols;              // edges per stage
+	static constexpr int kStagePitch = kStageCols + 1;
+};
 
+size_t sht_vote_lds_bytes(int R, int tg)
+{
+	const size_t pitch = (size_t)kVoteWaves * tg + 1;
+	return ((size_t)((R + 31) & ~31) * (tg / 2) + (size_t)2 * 64 * pitch) * sizeof(uint32_t);
+}
+
+template <int TG>
 __global__ __launch_bounds__(kShtVoteThreads) void sht_vote_kernel(ShtArgs a)
 {
+	constexpr int kShtThetaPerGroup = TG;
+	constexpr int kEdgesPerThread = VoteCfg<TG>::kEdgesPerThread;
+	constexpr int kStageCols = VoteCfg<TG>::kStageCols;
+	constexpr int kStageEdges = VoteCfg<TG>::kStageEdges;
+	constexpr int kStagePitch = VoteCfg<TG>::kStagePitch;
 	extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
 	const int R = a.R;
 	// [2][Rp]: pair 0 = thetas (t0,t0+1), pair 1 = (t0+2,t0+3) as u16 halves.  Pair-major so that one ds_add_u32
 	// instruction (fixed pair, 64 different rho) can spread over all 32 banks ([R][2] would only ever touch 16).
 	const int Rp = (R + 31) & ~31;
 	uint32_t* hist = smem;
-	uint32_t* stage = smem + 2 * Rp;       // [2][64][kStagePitch]
+	uint32_t* stage = smem + (TG / 2) * Rp; // [2][64][kStagePitch]
 	const int frame = blockIdx.z;
 	const int shard = blockIdx.y;
 	const int t0 = blockIdx.x * kShtThetaPerGroup;
 	const int tid = threadIdx.x;
 	const int lane = tid & 63, wave = tid >> 6;
 
-	for (int i = tid; i < 2 * Rp; i += kShtVoteThreads) hist[i] = 0u;
+	for (int i = tid; i < (TG / 2) * Rp; i += kShtVoteThreads) hist[i] = 0u;
 
 	int cq[kShtThetaPerGroup], sq[kShtThetaPerGroup];
 #pragma unroll
@@ -224,7 +238,7 @@ __global__ __launch_bounds__(kShtVoteThreads) void sht_vote_kernel(ShtArgs a)
 
 	int32_t* __restrict__ acc = a.acc + (size_t)frame * a.accFrameStride + (size_t)t0 * a.accPitch;
 	for (int r = tid; r < R; r += kShtVoteThreads) {
-		const uint32_t v0 = hist[r], v1 = hist[Rp + r];
+		const uint32_t v0 = hist[r], v1 = (TG > 2) ? hist[Rp + r] : 0u;
 		const int c[4] = { (int)(v0 & 0xffffu), (int)(v0 >> 16), (int)(v1 & 0xffffu), (int)(v1 >> 16) };
 #pragma unroll
 		for (int k = 0; k < kShtThetaPerGroup; ++k) {
@@ -388,21 +402,24 @@ hipError_t launch_sht_compact(const ShtArgs& a, int frames, hipStream_t stream)
 
 hipError_t launch_sht_vote(const ShtArgs& a, int frames, hipStream_t stream)
 {
-	static size_t attr_lds = 0;
-	const size_t lds = sht_vote_lds_bytes(a.R);
+	static size_t attr_lds[2] = { 0, 0 };
+	const int tg = a.thetaPerGroup == 2 ? 2 : 4;
+	const size_t lds = sht_vote_lds_bytes(a.R, tg);
 	if (lds > 160 * 1024) return hipErrorInvalidValue;
-	if (lds > attr_lds) {
-		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sht_vote_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+	if (lds > attr_lds[tg == 2]) {
+		hipError_t e = hipFuncSetAttribute(tg == 2 ? reinterpret_cast<const void*>(sht_vote_kernel<2>) : reinterpret_cast<const void*>(sht_vote_kernel<4>),
+		                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 		if (e != hipSuccess) return e;
-		attr_lds = lds;
+		attr_lds[tg == 2] = lds;
 	}
 	if (a.shards > 1) {
 		hipError_t e = hipMemsetAsync(a.acc, 0, sizeof(int32_t) * a.accFrameStride * frames, stream);
 		if (e != hipSuccess) return e;
 	}
-	const int groups = (a.T + kShtThetaPerGroup - 1) / kShtThetaPerGroup;
+	const int groups = (a.T + tg - 1) / tg;
 	dim3 grid(groups, a.shards, frames);
-	hipLaunchKernelGGL(sht_vote_kernel, grid, dim3(kShtVoteThreads), lds, stream, a);
+	if (tg == 2) hipLaunchKernelGGL(sht_vote_kernel<2>, grid, dim3(kShtVoteThreads), lds, stream, a);
+	else hipLaunchKernelGGL(sht_vote_kernel<4>, grid, dim3(kShtVoteThreads), lds, stream, a);
 	return hipGetLastError();
 }
 

@@ -263,6 +263,42 @@ def test_plan_full_size_golden_and_properties(hip_ctx, golden, name):
     assert accs[0].max() == got["strength"][0]
 
 
+def test_plan_edge_dete_and_canny_modes_batch(hip_ctx, oracle):
+    """Device-resident batched Sobel detector and Canny (mean-threshold mode, 5x5 kernel, aliased in/out) vs oracle."""
+    import torch
+    from compv_amd import capi
+    W, H, n = 648, 200, 3
+    frames = np.stack([synth_frame(W, H, 40 + f) for f in range(n)])
+    dev = torch.device("cuda:0")
+    d_in = torch.from_numpy(frames).to(dev)
+    d_out = torch.empty_like(d_in)
+    plan = capi.Plan(hip_ctx, W, H, W, n, 1.0)
+    st = torch.cuda.current_stream().cuda_stream
+    for op, oop in [(capi.OP_SOBEL, 0), (capi.OP_SCHARR, 2), (capi.OP_PREWITT, 3)]:
+        plan.edge_dete(d_in.data_ptr(), op, d_out.data_ptr(), st)
+        torch.cuda.synchronize()
+        got = d_out.cpu().numpy()
+        for f in range(n):
+            assert (got[f] == oracle.edge_dete(frames[f], oop)[0]).all(), (op, f)
+    plan.canny(d_in.data_ptr(), 0.68, 1.36, d_out.data_ptr(), 3, capi.THRESHOLD_PERCENT_OF_MEAN, st)   # per-frame mean thresholds on device
+    torch.cuda.synchronize()
+    got = d_out.cpu().numpy()
+    for f in range(n):
+        assert (got[f] == oracle.canny(frames[f], 0.68, 1.36, 3, 1)[1]).all(), f
+    plan.canny(d_in.data_ptr(), 400.0, 900.0, d_out.data_ptr(), 5, capi.THRESHOLD_COMPARE_TO_GRADIENT, st)
+    torch.cuda.synchronize()
+    got = d_out.cpu().numpy()
+    for f in range(n):
+        assert (got[f] == oracle.canny(frames[f], 400.0, 900.0, 5)[1]).all(), f
+    d_alias = d_in.clone()
+    plan.canny(d_alias.data_ptr(), 59.0, 119.0, d_alias.data_ptr(), 3, capi.THRESHOLD_COMPARE_TO_GRADIENT, st)  # in place on the device
+    torch.cuda.synchronize()
+    got = d_alias.cpu().numpy()
+    for f in range(n):
+        assert (got[f] == oracle.canny(frames[f], 59.0, 119.0)[1]).all(), f
+    plan.close()
+
+
 def test_no_leaks(oracle):
     """hipMalloc/hipFree balance (the analogue of COMPV_DEBUG_CHECK_FOR_MEMORY_LEAKS, compv_api.h:148-155)."""
     from compv_amd import capi
@@ -271,9 +307,12 @@ def test_no_leaks(oracle):
     e = ctx.canny(img, 59.0, 119.0)
     ctx.houghsht(e, 1.0, 20)
     ctx.edge_dete(img)
+    ctx.houghkht(e)
     assert ctx.live_allocations() > 0
-    lib, h = ctx.lib, ctx.h
-    # destroy hostPlan & staging, then the count must return to zero just before the ctx itself goes
+    plan = capi.Plan(ctx, 200, 104, 200, 2, 1.0)
+    before = ctx.live_allocations()
+    plan.close()
+    assert ctx.live_allocations() < before          # every plan buffer was released
     ctx.close()
     assert ctx.h is None
 
