@@ -66,7 +66,7 @@ struct compvhip_plan {
 	size_t R = 0, T = 0; float thetaStep = 0.f; int accPitch = 0;
 	int32_t* sinQ = nullptr; int32_t* cosQ = nullptr;
 	uint32_t* edges = nullptr; size_t edgeCap = 0; int* edgeCounts = nullptr;
-	int32_t* acc = nullptr; size_t accFrameStride = 0;
+	uint16_t* acc = nullptr; size_t accFrameStride = 0;
 	uint64_t* keysA = nullptr; uint64_t* keysB = nullptr; size_t lineCap = 0; int* lineCounts = nullptr;
 	void* sortTemp = nullptr; size_t sortTempBytes = 0;
 	int cellBits = 0, keyBits = 0;
@@ -216,6 +216,7 @@ int ensureSht(compvhip_plan* p)
 	HIPCHK(ctx, dmalloc(ctx, &p->edgeCounts, p->frames));
 	HIPCHK(ctx, hipMemset(p->edgeCounts, 0, sizeof(int) * p->frames));
 	HIPCHK(ctx, dmalloc(ctx, &p->acc, p->accFrameStride * p->frames));
+	HIPCHK(ctx, hipMemset(p->acc, 0, sizeof(uint16_t) * p->accFrameStride * p->frames)); // rows [Rp, accPitch) stay zero for ever
 	HIPCHK(ctx, dmalloc(ctx, &p->lineCounts, p->frames));
 	// line key = frameTag | strength (16 bits) | cell index (cellBits): see sht_nms_kernel
 	p->cellBits = 1;
@@ -588,7 +589,7 @@ int compvhip_plan_pipeline(compvhip_plan* p, const uint8_t* d_in, float tLow, fl
 	return COMPVHIP_OK;
 }
 
-int compvhip_plan_acc(compvhip_plan* p, size_t frame, const int32_t** d_acc, size_t* R, size_t* T, size_t* accPitch)
+int compvhip_plan_acc(compvhip_plan* p, size_t frame, const uint16_t** d_acc, size_t* R, size_t* T, size_t* accPitch)
 {
 	if (!p || !p->shtReady || frame >= p->frames) return COMPVHIP_E_INVALID_PARAMETER;
 	if (d_acc) *d_acc = p->acc + frame * p->accFrameStride;

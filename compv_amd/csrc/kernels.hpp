@@ -62,7 +62,7 @@ struct ShtArgs {
 	const uint32_t* ebits;    // edge bit masks [frames][H][wb]
 	uint32_t* edges;          // compacted edge list per frame: (y << 16) | x, capacity edgeCap
 	int* edgeCounts;          // per frame
-	int32_t* acc;             // [frames][T][accPitch]
+	uint16_t* acc;            // [frames][T][accPitch], u16: a cell never exceeds 65535
 	const int32_t* sinQ;      // [T]
 	const int32_t* cosQ;      // [T]
 	uint64_t* lineKeys;       // [frames][lineCap] sort keys: strength<<32 | ~(row*T+col)
@@ -84,7 +84,7 @@ hipError_t launch_sht_nms(const ShtArgs& a, int frames, hipStream_t stream);
 hipError_t launch_sht_decode(const uint64_t* keys, const int* counts, size_t lineCap, int frames, int T, int barrier, float thetaStep,
                              int maxLines, int cellBits, void* lines /*compvhip_line*/, size_t outCap, hipStream_t stream);
 // acc [T][pitch] -> reference layout [R][stride]
-hipError_t launch_sht_acc_transpose(const int32_t* accT, int R, int T, int accPitch, int32_t* out, size_t outStride, hipStream_t stream);
+hipError_t launch_sht_acc_transpose(const uint16_t* accT, int R, int T, int accPitch, int32_t* out, size_t outStride, hipStream_t stream);
 size_t sht_vote_lds_bytes(int R, int thetaPerGroup);
 // one descending radix sort over the (unique) 64-bit line keys of all frames; temp == nullptr queries tempBytes
 hipError_t sht_sort_keys(void* temp, size_t& tempBytes, const uint64_t* keysIn, uint64_t* keysOut, size_t lineCap, int frames, int keyBits,

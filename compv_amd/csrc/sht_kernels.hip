@@ -8,7 +8,7 @@
 // Data layout in HBM (per frame):
 //   edge bit mask   u32 [H][wb]            produced by the Canny kernels (or by bytes_to_bits for foreign edge maps)
 //   edge list       u32 [E]   (y<<16)|x    compacted with wave ballot/popcount prefix sums
-//   accumulator     i32 [T][accPitch]      THETA-major (the reference is rho-major [R][192]); each vote workgroup
+//   accumulator     u16 [T][accPitch]      THETA-major (the reference is int32 rho-major [R][192]); each vote workgroup
 //                                          owns kShtThetaPerGroup whole theta columns, so the accumulator is
 //                                          written exactly once, coalesced, with no global atomics
 //   line keys       u64 [lines]            strength<<32 | ~(row*T+col): unique keys, sorted descending on device
@@ -236,15 +236,21 @@ __global__ __launch_bounds__(kShtVoteThreads) void sht_vote_kernel(ShtArgs a)
 		__syncthreads();
 	}
 
-	int32_t* __restrict__ acc = a.acc + (size_t)frame * a.accFrameStride + (size_t)t0 * a.accPitch;
-	for (int r = tid; r < R; r += kShtVoteThreads) {
-		const uint32_t v0 = hist[r], v1 = (TG > 2) ? hist[Rp + r] : 0u;
-		const int c[4] = { (int)(v0 & 0xffffu), (int)(v0 >> 16), (int)(v1 & 0xffffu), (int)(v1 >> 16) };
+	// flush: the accumulator is u16 (a cell never exceeds 65535, see above), theta-major; each thread writes two
+	// adjacent rho rows of one theta as one dword (accPitch is even)
+	uint16_t* __restrict__ acc = a.acc + (size_t)frame * a.accFrameStride + (size_t)t0 * a.accPitch;
+	for (int r2 = tid; r2 < Rp / 2; r2 += kShtVoteThreads) {
+		const int r = 2 * r2;
+		const uint32_t a0 = hist[r], a1 = hist[r + 1];
+		const uint32_t b0 = (TG > 2) ? hist[Rp + r] : 0u, b1 = (TG > 2) ? hist[Rp + r + 1] : 0u;
+		// rows r (low half) and r+1 (high half) for each of the 4 thetas
+		const uint32_t w[4] = { (a0 & 0xffffu) | (a1 << 16), (a0 >> 16) | (a1 & 0xffff0000u), (b0 & 0xffffu) | (b1 << 16), (b0 >> 16) | (b1 & 0xffff0000u) };
 #pragma unroll
 		for (int k = 0; k < kShtThetaPerGroup; ++k) {
 			if (k < nvalid) {
-				if (a.shards == 1) acc[(size_t)k * a.accPitch + r] = c[k];
-				else if (c[k]) atomicAdd(&acc[(size_t)k * a.accPitch + r], c[k]);
+				uint32_t* dst = reinterpret_cast<uint32_t*>(acc + (size_t)k * a.accPitch + r);
+				if (a.shards == 1) *dst = w[k];
+				else if (w[k]) atomicAdd(dst, w[k]); // halves cannot carry into each other: every cell total <= 65535
 			}
 		}
 	}
@@ -257,8 +263,8 @@ __global__ __launch_bounds__(kShtVoteThreads) void sht_vote_kernel(ShtArgs a)
 // descending radix sort over all frames yields frame-major, strength-descending, (row,col)-ascending order.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kNmsThreads = 256;
-constexpr int kNmsVec = 4;             // independent 16-byte loads in flight per thread
-constexpr int kNmsRowsPerThread = 4 * kNmsVec;
+constexpr int kNmsVec = 2;             // independent 16-byte loads (8 u16 cells each) in flight per thread
+constexpr int kNmsRowsPerThread = 8 * kNmsVec;
 
 __global__ __launch_bounds__(kNmsThreads) void sht_nms_kernel(ShtArgs a)
 {
@@ -266,39 +272,39 @@ __global__ __launch_bounds__(kNmsThreads) void sht_nms_kernel(ShtArgs a)
 	__shared__ int s_base;
 	const int frame = blockIdx.z;
 	const int c = blockIdx.y;
-	const int32_t* __restrict__ acc = a.acc + (size_t)frame * a.accFrameStride;
+	const uint16_t* __restrict__ acc = a.acc + (size_t)frame * a.accFrameStride;
 	const size_t p = a.accPitch;
 	const bool nmsCol = (c >= 1 && c <= a.nmsLastCol);
 	uint64_t keys[kNmsRowsPerThread];
 	int cnt = 0;
 	const uint64_t frameTag = (uint64_t)(a.frames - 1 - frame) << (16 + a.cellBits);
 	const uint32_t cellMask = (1u << a.cellBits) - 1u;
-	// thread t of the block reads rows [base + v*1024 + 4t, +4) for v = 0..kNmsVec-1 (each wave load = 1 KiB contiguous)
-	const int base = blockIdx.x * (kNmsThreads * kNmsRowsPerThread) + threadIdx.x * 4;
-	int4 v4[kNmsVec];
+	// thread t of the block reads rows [base + v*2048 + 8t, +8) for v = 0..kNmsVec-1 (each wave load = 1 KiB contiguous)
+	const int base = blockIdx.x * (kNmsThreads * kNmsRowsPerThread) + threadIdx.x * 8;
+	uint4 v4[kNmsVec];
 #pragma unroll
 	for (int v = 0; v < kNmsVec; ++v) {
-		const int r0 = base + v * (kNmsThreads * 4);
-		v4[v] = make_int4(0, 0, 0, 0);
-		if (r0 < a.accPitch) v4[v] = *reinterpret_cast<const int4*>(acc + (size_t)c * p + r0); // the pitch tail (>= R) is never used
+		const int r0 = base + v * (kNmsThreads * 8);
+		v4[v] = make_uint4(0, 0, 0, 0);
+		if (r0 < a.accPitch) v4[v] = *reinterpret_cast<const uint4*>(acc + (size_t)c * p + r0); // the pitch tail (>= R) holds zeros
 	}
 #pragma unroll
 	for (int v = 0; v < kNmsVec; ++v) {
-		const int vv[4] = { v4[v].x, v4[v].y, v4[v].z, v4[v].w };
+		const uint32_t ww[4] = { v4[v].x, v4[v].y, v4[v].z, v4[v].w };
 #pragma unroll
-		for (int k = 0; k < 4; ++k) {
-			const int r = base + v * (kNmsThreads * 4) + k;
-			const int val = vv[k];
-			keys[v * 4 + k] = 0; // 0 = no line in this slot (a real key always has strength > 0)
+		for (int k = 0; k < 8; ++k) {
+			const int r = base + v * (kNmsThreads * 8) + k;
+			const int val = (int)((ww[k >> 1] >> (16 * (k & 1))) & 0xffffu);
+			keys[v * 8 + k] = 0; // 0 = no line in this slot (a real key always has strength > 0)
 			if (r >= a.R || val <= a.threshold) continue;
 			if (nmsCol && r >= 1 && r <= a.R - 2) {
-				const int32_t* l = acc + (size_t)(c - 1) * p + r;
-				const int32_t* m = acc + (size_t)c * p + r;
-				const int32_t* h = acc + (size_t)(c + 1) * p + r;
+				const uint16_t* l = acc + (size_t)(c - 1) * p + r;
+				const uint16_t* m = acc + (size_t)c * p + r;
+				const uint16_t* h = acc + (size_t)(c + 1) * p + r;
 				if (l[-1] > val || l[0] > val || l[1] > val || m[-1] > val || m[1] > val || h[-1] > val || h[0] > val || h[1] > val) continue;
 			}
 			const uint32_t cell = (uint32_t)r * (uint32_t)a.T + (uint32_t)c;
-			keys[v * 4 + k] = frameTag | ((uint64_t)(uint32_t)val << a.cellBits) | (uint64_t)(cellMask - cell);
+			keys[v * 8 + k] = frameTag | ((uint64_t)(uint32_t)val << a.cellBits) | (uint64_t)(cellMask - cell);
 			++cnt;
 		}
 	}
@@ -362,14 +368,14 @@ __global__ __launch_bounds__(256) void sht_decode_kernel(const uint64_t* __restr
 	lines[(size_t)frame * outCap + i] = o;
 }
 
-__global__ __launch_bounds__(256) void sht_acc_transpose_kernel(const int32_t* __restrict__ accT, int R, int T, int accPitch, int32_t* __restrict__ out, size_t outStride)
+__global__ __launch_bounds__(256) void sht_acc_transpose_kernel(const uint16_t* __restrict__ accT, int R, int T, int accPitch, int32_t* __restrict__ out, size_t outStride)
 {
 	__shared__ int32_t tile[32][33];
 	const int r0 = blockIdx.x * 32, c0 = blockIdx.y * 32;
 	const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5; // 32 x 8
 	for (int j = ty; j < 32; j += 8) {
 		const int c = c0 + j, r = r0 + tx;
-		tile[j][tx] = (c < T && r < R) ? accT[(size_t)c * accPitch + r] : 0;
+		tile[j][tx] = (c < T && r < R) ? (int32_t)accT[(size_t)c * accPitch + r] : 0;
 	}
 	__syncthreads();
 	for (int j = ty; j < 32; j += 8) {
@@ -413,7 +419,7 @@ hipError_t launch_sht_vote(const ShtArgs& a, int frames, hipStream_t stream)
 		attr_lds[tg == 2] = lds;
 	}
 	if (a.shards > 1) {
-		hipError_t e = hipMemsetAsync(a.acc, 0, sizeof(int32_t) * a.accFrameStride * frames, stream);
+		hipError_t e = hipMemsetAsync(a.acc, 0, sizeof(uint16_t) * a.accFrameStride * frames, stream);
 		if (e != hipSuccess) return e;
 	}
 	const int groups = (a.T + tg - 1) / tg;
@@ -455,7 +461,7 @@ hipError_t launch_sht_decode(const uint64_t* keys, const int* counts, size_t lin
 	return hipGetLastError();
 }
 
-hipError_t launch_sht_acc_transpose(const int32_t* accT, int R, int T, int accPitch, int32_t* out, size_t outStride, hipStream_t stream)
+hipError_t launch_sht_acc_transpose(const uint16_t* accT, int R, int T, int accPitch, int32_t* out, size_t outStride, hipStream_t stream)
 {
 	dim3 grid((R + 31) / 32, (T + 31) / 32);
 	hipLaunchKernelGGL(sht_acc_transpose_kernel, grid, dim3(256), 0, stream, accT, R, T, accPitch, out, outStride);

@@ -152,8 +152,9 @@ COMPVHIP_API int compvhip_plan_pipeline(compvhip_plan* plan, const uint8_t* d_in
                                         int threshold, int maxLines, uint8_t* d_edges,
                                         compvhip_line* d_lines, size_t lineCap, int32_t* d_counts, void* stream);
 
-/* Device accumulator of frame f after compvhip_plan_houghsht: int32, theta-major [T][accPitch] (pitch >= R). */
-COMPVHIP_API int compvhip_plan_acc(compvhip_plan* plan, size_t frame, const int32_t** d_acc, size_t* R, size_t* T, size_t* accPitch);
+/* Device accumulator of frame f after compvhip_plan_houghsht: uint16 (a cell never exceeds the pixels of a 1-px band),
+ * theta-major [T][accPitch] (pitch >= R).  compvhip_plan_acc_export gives the reference's int32 rho-major layout. */
+COMPVHIP_API int compvhip_plan_acc(compvhip_plan* plan, size_t frame, const uint16_t** d_acc, size_t* R, size_t* T, size_t* accPitch);
 /* Copies the accumulator of frame f into a caller DEVICE buffer in the reference layout: int32 [R][outStride]
  * (outStride >= T), i.e. acc[(barrier - rho) * outStride + t] (houghsht.cxx:430-431). */
 COMPVHIP_API int compvhip_plan_acc_export(compvhip_plan* plan, size_t frame, int32_t* d_out, size_t outStride, void* stream);

@@ -55,44 +55,55 @@ struct Result {
 	double ms;
 };
 
+// Detector objects are created once (the samples create them before the camera loop, samples/hough_lines/main.cxx:59-72)
+// and reused for every frame; resetObjects() drops them when the factories are swapped.
+static CompVEdgeDetePtr ptrCanny, ptrCannyMean, ptrSobel;
+static CompVHoughPtr ptrHough, ptrKht;
+static void resetObjects() { ptrCanny = nullptr; ptrCannyMean = nullptr; ptrSobel = nullptr; ptrHough = nullptr; ptrKht = nullptr; }
+
 // The application code: same calls, same order, same parameters as the samples.
 static COMPV_ERROR_CODE runSamples(size_t W, size_t H, uint32_t seed, Result& r)
 {
 	CompVMatPtr image, mat, edges, sob;
-	CompVEdgeDetePtr ptrCanny, ptrSobel;
-	CompVHoughPtr ptrHough;
 	CompVHoughLineVector linesPolar;
 	CompVLineFloat32Vector linesCartesian;
 
 	COMPV_CHECK_CODE_RETURN(CompVImage::newObj8u(&image, COMPV_SUBTYPE_PIXELS_Y, W, H));
 	synthFrame(image, seed);
 
-	const auto t0 = std::chrono::steady_clock::now();
-	// samples/edges_sobel: CompVEdgeDete::newObj(&dete, COMPV_SOBEL_ID) ; process(image, &edges)
-	COMPV_CHECK_CODE_RETURN(CompVEdgeDete::newObj(&ptrSobel, COMPV_SOBEL_ID));
-	COMPV_CHECK_CODE_RETURN(ptrSobel->process(image, &sob));
-
-	// samples/edges_canny/main.cxx:44-45,68-72: newObj(COMPV_CANNY_ID, low, high, kernel) ; process(mat, &mat) IN PLACE
-	COMPV_CHECK_CODE_RETURN(CompVEdgeDete::newObj(&ptrCanny, COMPV_CANNY_ID, 59.f, 119.f, 3));
-	COMPV_CHECK_CODE_RETURN(image->clone(&mat));
-	COMPV_CHECK_CODE_RETURN(ptrCanny->process(mat, &mat));
-
-	// samples/hough_lines/main.cxx:59-72,102-109
-	COMPV_CHECK_CODE_RETURN(CompVHough::newObj(&ptrHough, COMPV_HOUGHSHT_ID, 1.f, 1.f, 100));
-	COMPV_CHECK_CODE_RETURN(ptrHough->setInt(COMPV_HOUGH_SET_INT_MAXLINES, 0));
-	COMPV_CHECK_CODE_RETURN(ptrHough->process(mat, linesPolar));
-	COMPV_CHECK_CODE_RETURN(ptrHough->toCartesian(mat->cols(), mat->rows(), linesPolar, linesCartesian));
-
-	// samples/hough_lines/main.cxx:59-72 with HOUGH_ID == COMPV_HOUGHKHT_ID: newObj(rho, theta, HOUGHKHT_THRESHOLD) + the three KHT knobs
-	{
-		CompVHoughPtr ptrKht;
-		CompVHoughLineVector khtPolar;
-		CompVLineFloat32Vector khtCartesian;
+	if (!ptrSobel) {
+		// samples/edges_sobel: CompVEdgeDete::newObj(&dete, COMPV_SOBEL_ID)
+		COMPV_CHECK_CODE_RETURN(CompVEdgeDete::newObj(&ptrSobel, COMPV_SOBEL_ID));
+		// samples/edges_canny/main.cxx:44-45: newObj(COMPV_CANNY_ID, low, high, kernel)
+		COMPV_CHECK_CODE_RETURN(CompVEdgeDete::newObj(&ptrCanny, COMPV_CANNY_ID, 59.f, 119.f, 3));
+		// samples/hough_lines/main.cxx:59-72
+		COMPV_CHECK_CODE_RETURN(CompVHough::newObj(&ptrHough, COMPV_HOUGHSHT_ID, 1.f, 1.f, 100));
+		COMPV_CHECK_CODE_RETURN(ptrHough->setInt(COMPV_HOUGH_SET_INT_MAXLINES, 0));
 		COMPV_CHECK_CODE_RETURN(CompVHough::newObj(&ptrKht, COMPV_HOUGHKHT_ID, 1.f, 1.f, 1));
 		COMPV_CHECK_CODE_RETURN(ptrKht->setInt(COMPV_HOUGH_SET_INT_MAXLINES, 0));
 		COMPV_CHECK_CODE_RETURN(ptrKht->setFloat32(COMPV_HOUGHKHT_SET_FLT32_CLUSTER_MIN_DEVIATION, 2.0f));
 		COMPV_CHECK_CODE_RETURN(ptrKht->setInt(COMPV_HOUGHKHT_SET_INT_CLUSTER_MIN_SIZE, 10));
 		COMPV_CHECK_CODE_RETURN(ptrKht->setFloat32(COMPV_HOUGHKHT_SET_FLT32_KERNEL_MIN_HEIGTH, 0.002f));
+		// hough_lines drives the Canny thresholds through set(): a second detector in PERCENT_OF_MEAN mode
+		COMPV_CHECK_CODE_RETURN(CompVEdgeDete::newObj(&ptrCannyMean, COMPV_CANNY_ID));
+		COMPV_CHECK_CODE_RETURN(ptrCannyMean->setInt(COMPV_CANNY_SET_INT_THRESHOLD_TYPE, COMPV_CANNY_THRESHOLD_TYPE_PERCENT_OF_MEAN));
+		COMPV_CHECK_CODE_RETURN(ptrCannyMean->setFloat32(COMPV_CANNY_SET_FLT32_THRESHOLD_LOW, 0.68f));
+		COMPV_CHECK_CODE_RETURN(ptrCannyMean->setFloat32(COMPV_CANNY_SET_FLT32_THRESHOLD_HIGH, 1.36f));
+	}
+	COMPV_CHECK_CODE_RETURN(image->clone(&mat));
+
+	const auto t0 = std::chrono::steady_clock::now();
+	COMPV_CHECK_CODE_RETURN(ptrSobel->process(image, &sob));
+	// samples/edges_canny/main.cxx:68-72: process(mat, &mat) IN PLACE
+	COMPV_CHECK_CODE_RETURN(ptrCanny->process(mat, &mat));
+	// samples/hough_lines/main.cxx:102-109
+	COMPV_CHECK_CODE_RETURN(ptrHough->process(mat, linesPolar));
+	COMPV_CHECK_CODE_RETURN(ptrHough->toCartesian(mat->cols(), mat->rows(), linesPolar, linesCartesian));
+
+	// samples/hough_lines/main.cxx:59-72 with HOUGH_ID == COMPV_HOUGHKHT_ID: newObj(rho, theta, HOUGHKHT_THRESHOLD) + the three KHT knobs
+	{
+		CompVHoughLineVector khtPolar;
+		CompVLineFloat32Vector khtCartesian;
 		COMPV_CHECK_CODE_RETURN(ptrKht->process(mat, khtPolar));
 		COMPV_CHECK_CODE_RETURN(ptrKht->toCartesian(mat->cols(), mat->rows(), khtPolar, khtCartesian));
 		compv_float64_t gs = 0;
@@ -105,11 +116,7 @@ static COMPV_ERROR_CODE runSamples(size_t W, size_t H, uint32_t seed, Result& r)
 		}
 	}
 
-	// hough_lines sets the Canny thresholds per frame through set(): PERCENT_OF_MEAN variant
-	COMPV_CHECK_CODE_RETURN(ptrCanny->setInt(COMPV_CANNY_SET_INT_THRESHOLD_TYPE, COMPV_CANNY_THRESHOLD_TYPE_PERCENT_OF_MEAN));
-	COMPV_CHECK_CODE_RETURN(ptrCanny->setFloat32(COMPV_CANNY_SET_FLT32_THRESHOLD_LOW, 0.68f));
-	COMPV_CHECK_CODE_RETURN(ptrCanny->setFloat32(COMPV_CANNY_SET_FLT32_THRESHOLD_HIGH, 1.36f));
-	COMPV_CHECK_CODE_RETURN(ptrCanny->process(image, &edges));
+	COMPV_CHECK_CODE_RETURN(ptrCannyMean->process(image, &edges));
 	r.ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
 
 	auto grab = [&](const CompVMatPtr& m, std::vector<uint8_t>& out) {
@@ -153,6 +160,7 @@ int main(int argc, char** argv)
 	for (int f = 0; f < frames; ++f) {
 		if (COMPV_ERROR_CODE_IS_NOK(runSamples(W, H, 12345u + f, cpu[f]))) { fprintf(stderr, "CPU run failed\n"); return 3; }
 	}
+	resetObjects();
 	if (compv_hip_plugin_register() != 0) { fprintf(stderr, "HIP plugin registration failed (no GPU?)\n"); return 4; }
 	for (int f = 0; f < frames; ++f) {
 		if (COMPV_ERROR_CODE_IS_NOK(runSamples(W, H, 12345u + f, gpu[f]))) { fprintf(stderr, "HIP run failed\n"); return 5; }
@@ -167,6 +175,7 @@ int main(int argc, char** argv)
 			f, W, H, okS ? "==" : "DIFF", okC ? "==" : "DIFF", e, okM ? "==" : "DIFF", okL ? "==" : "DIFF", cpu[f].lines.size(), okX ? "==" : "DIFF", okK ? "==" : "DIFF", cpu[f].khtLines.size(), cpu[f].ms, gpu[f].ms);
 		bad += !(okS && okC && okM && okL && okX && okK);
 	}
+	resetObjects();
 	printf(bad ? "DROP-IN PARITY FAILED\n" : "DROP-IN PARITY OK\n");
 	return bad ? 1 : 0;
 }
