@@ -69,7 +69,7 @@ struct compvhip_plan {
 	uint16_t* acc = nullptr; size_t accFrameStride = 0;
 	uint64_t* keysA = nullptr; uint64_t* keysB = nullptr; size_t lineCap = 0; int* lineCounts = nullptr;
 	void* sortTemp = nullptr; size_t sortTempBytes = 0;
-	int cellBits = 0, keyBits = 0;
+	int cellBits = 0, strengthBits = 16, keyBits = 0;
 	int shards = 1;
 	// timing
 	bool timing = false;
@@ -218,12 +218,17 @@ int ensureSht(compvhip_plan* p)
 	HIPCHK(ctx, dmalloc(ctx, &p->acc, p->accFrameStride * p->frames));
 	HIPCHK(ctx, hipMemset(p->acc, 0, sizeof(uint16_t) * p->accFrameStride * p->frames)); // rows [Rp, accPitch) stay zero for ever
 	HIPCHK(ctx, dmalloc(ctx, &p->lineCounts, p->frames));
-	// line key = frameTag | strength (16 bits) | cell index (cellBits): see sht_nms_kernel
+	// line key = frameTag | strength (strengthBits) | cell index (cellBits): see sht_nms_kernel. A cell of column theta counts the
+	// pixels with (x*cosQ + y*sinQ) in one 65536-wide interval; max(|cosQ|,|sinQ|) >= 46340 so every x (or every y) contributes at
+	// most 2 pixels: count <= 2*max(W,H). Fewer key bits = fewer radix-sort passes.
+	p->strengthBits = 1;
+	while ((static_cast<size_t>(1) << p->strengthBits) <= 2 * (p->W > p->H ? p->W : p->H)) p->strengthBits++;
+	if (p->strengthBits > 16) p->strengthBits = 16; // the accumulator itself is u16
 	p->cellBits = 1;
 	while ((static_cast<size_t>(1) << p->cellBits) <= R * T) p->cellBits++;
 	int frameBits = 0;
 	while ((static_cast<size_t>(1) << frameBits) < p->frames) frameBits++;
-	p->keyBits = frameBits + 16 + p->cellBits;
+	p->keyBits = frameBits + p->strengthBits + p->cellBits;
 	if (p->keyBits > 64) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "too many frames x accumulator cells for a 64-bit line key");
 	p->shtReady = true;
 	return COMPVHIP_OK;
@@ -261,7 +266,7 @@ ShtArgs shtArgs(compvhip_plan* p, int threshold)
 	a.nmsLastCol = static_cast<int>((p->T - 1) & ~static_cast<size_t>(3)); // quirk Q2: NMS covers theta columns [1, (T-1)&~3]
 	a.shards = p->shards;
 	a.frames = static_cast<int>(p->frames);
-	a.cellBits = p->cellBits;
+	a.cellBits = p->cellBits; a.strengthBits = p->strengthBits;
 	static const int tg = [] { const char* e = getenv("COMPVHIP_SHT_THETA_PER_GROUP"); return (e && atoi(e) == 2) ? 2 : 4; }(); // tuning knob
 	a.thetaPerGroup = tg;
 	return a;
@@ -545,7 +550,7 @@ static int planShtImpl(compvhip_plan* p, const uint8_t* d_edges, int threshold, 
 	if (d_lines && lineCap) {
 		Stamp s(p, st, "sht_decode_kernel");
 		HIPCHK(ctx, launch_sht_decode(p->keysB, p->lineCounts, p->lineCap, frames, static_cast<int>(p->T), static_cast<int>(p->W + p->H), p->thetaStep, maxLines,
-		                              p->cellBits, d_lines, lineCap, st));
+		                              p->cellBits, p->strengthBits, d_lines, lineCap, st));
 	}
 	if (d_counts) HIPCHK(ctx, hipMemcpyAsync(d_counts, p->lineCounts, sizeof(int32_t) * frames, hipMemcpyDeviceToDevice, st));
 	return COMPVHIP_OK;

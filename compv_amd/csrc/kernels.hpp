@@ -74,6 +74,7 @@ struct ShtArgs {
 	int shards;               // vote workgroups per (frame, theta group)
 	int frames;
 	int cellBits;             // bits of the accumulator cell index in a line key (2^cellBits > R*T)
+	int strengthBits;         // bits of the strength field of a line key (2^strengthBits > 2*max(W,H) >= any cell count)
 	int thetaPerGroup;        // 4 (default) or 2 theta bins per vote workgroup
 };
 hipError_t launch_bytes_to_bits(const uint8_t* edges, int W, int H, int S, size_t frameStride, uint32_t* ebits, int wb, size_t bitsFrameStride,
@@ -82,7 +83,7 @@ hipError_t launch_sht_compact(const ShtArgs& a, int frames, hipStream_t stream);
 hipError_t launch_sht_vote(const ShtArgs& a, int frames, hipStream_t stream);
 hipError_t launch_sht_nms(const ShtArgs& a, int frames, hipStream_t stream);
 hipError_t launch_sht_decode(const uint64_t* keys, const int* counts, size_t lineCap, int frames, int T, int barrier, float thetaStep,
-                             int maxLines, int cellBits, void* lines /*compvhip_line*/, size_t outCap, hipStream_t stream);
+                             int maxLines, int cellBits, int strengthBits, void* lines /*compvhip_line*/, size_t outCap, hipStream_t stream);
 // acc [T][pitch] -> reference layout [R][stride]
 hipError_t launch_sht_acc_transpose(const uint16_t* accT, int R, int T, int accPitch, int32_t* out, size_t outStride, hipStream_t stream);
 size_t sht_vote_lds_bytes(int R, int thetaPerGroup);

@@ -66,11 +66,13 @@ __global__ __launch_bounds__(256) void bytes_to_bits_kernel(const uint8_t* __res
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kCompactThreads = 256;
 constexpr int kCompactWords = 8;
+constexpr int kCompactStage = 2048; // edges a wave can expand through LDS (it owns 64*8*32 = 16384 pixels)
 
 __global__ __launch_bounds__(kCompactThreads) void sht_compact_kernel(ShtArgs a)
 {
 	__shared__ int s_wave[kCompactThreads / 64];
 	__shared__ int s_base;
+	__shared__ uint32_t s_stage[kCompactThreads / 64][kCompactStage];
 	const int frame = blockIdx.y;
 	const size_t nwords = (size_t)a.H * a.wb; // wb is a multiple of 16, so nwords % kCompactWords == 0
 	const size_t w0 = ((size_t)blockIdx.x * kCompactThreads + threadIdx.x) * kCompactWords;
@@ -105,9 +107,33 @@ __global__ __launch_bounds__(kCompactThreads) void sht_compact_kernel(ShtArgs a)
 	if (total == 0) return; // uniform
 	if (threadIdx.x == 0) s_base = atomicAdd(&a.edgeCounts[frame], total);
 	__syncthreads();
+	uint32_t* __restrict__ dst = a.edges + (size_t)frame * a.edgeCap;
+	const int waveTotal = __shfl(incl, 63);
+	if (waveTotal <= kCompactStage) {
+		// usual case: expand into the wave's LDS slice, then copy out with coalesced stores
+		uint32_t* st = s_stage[wave];
+		int lp = incl - cnt;
+#pragma unroll
+		for (int k = 0; k < kCompactWords; ++k) {
+			uint32_t b = bits[k];
+			if (!b) continue;
+			const size_t wi = w0 + k;
+			const int y = (int)(wi / a.wb);
+			const uint32_t yx0 = ((uint32_t)y << 16) | (uint32_t)((int)(wi - (size_t)y * a.wb) * 32);
+			while (b) {
+				const int bit = __ffs(b) - 1;
+				b &= b - 1;
+				st[lp++] = yx0 + (uint32_t)bit;
+			}
+		}
+		__builtin_amdgcn_wave_barrier();
+		const size_t wpos = (size_t)s_base + wbase;
+		for (int i = lane; i < waveTotal; i += 64)
+			if (wpos + i < a.edgeCap) dst[wpos + i] = st[i];
+		return;
+	}
 	size_t pos = (size_t)s_base + wbase + (incl - cnt);
 	if (cnt) {
-		uint32_t* __restrict__ dst = a.edges + (size_t)frame * a.edgeCap;
 #pragma unroll
 		for (int k = 0; k < kCompactWords; ++k) {
 			uint32_t b = bits[k];
@@ -259,57 +285,96 @@ __global__ __launch_bounds__(kShtVoteThreads) void sht_vote_kernel(ShtArgs a)
 // ---------------------------------------------------------------------------------------------------------------
 // NMS + threshold -> line keys.  One workgroup = 1024 consecutive rho rows of one theta column (coalesced along rho in
 // the theta-major accumulator); lines are compacted inside the workgroup and ONE global atomic reserves their slots.
-// key = frameTag << (16+cellBits) | strength << cellBits | (cellMask - cell), cell = row*T + col: unique, and a single
+// key = frameTag << (strengthBits+cellBits) | strength << cellBits | (cellMask - cell), cell = row*T + col: unique, and a single
 // descending radix sort over all frames yields frame-major, strength-descending, (row,col)-ascending order.
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kNmsThreads = 256;
-constexpr int kNmsVec = 2;             // independent 16-byte loads (8 u16 cells each) in flight per thread
-constexpr int kNmsRowsPerThread = 8 * kNmsVec;
+constexpr int kNmsCols = 8;                  // theta columns per block
+constexpr int kNmsRows = kNmsThreads * 8;    // rho rows per block: 8 per thread
+constexpr int kNmsTileRows = kNmsRows + 16;  // + 8 rows of halo either side (keeps every 16-byte load aligned)
 
+// One block owns kNmsCols theta columns x kNmsRows rho rows of the theta-major accumulator. The tile plus a one-cell halo is
+// staged in LDS with 16-byte coalesced loads (each accumulator cell is read (kNmsCols+2)/kNmsCols times), so the 3x3
+// neighbourhood test never issues a scattered global load. Survivors are flagged in a 64-bit mask per thread, slots are
+// reserved with ONE atomic per block, and the keys are rebuilt from the LDS tile.
 __global__ __launch_bounds__(kNmsThreads) void sht_nms_kernel(ShtArgs a)
 {
+	__shared__ __attribute__((aligned(16))) uint16_t s_tile[kNmsCols + 2][kNmsTileRows];
 	__shared__ int s_wave[kNmsThreads / 64];
 	__shared__ int s_base;
 	const int frame = blockIdx.z;
-	const int c = blockIdx.y;
+	const int c0 = blockIdx.y * kNmsCols;
+	const int base = blockIdx.x * kNmsRows;
+	const int t = threadIdx.x;
 	const uint16_t* __restrict__ acc = a.acc + (size_t)frame * a.accFrameStride;
 	const size_t p = a.accPitch;
-	const bool nmsCol = (c >= 1 && c <= a.nmsLastCol);
-	uint64_t keys[kNmsRowsPerThread];
-	int cnt = 0;
-	const uint64_t frameTag = (uint64_t)(a.frames - 1 - frame) << (16 + a.cellBits);
-	const uint32_t cellMask = (1u << a.cellBits) - 1u;
-	// thread t of the block reads rows [base + v*2048 + 8t, +8) for v = 0..kNmsVec-1 (each wave load = 1 KiB contiguous)
-	const int base = blockIdx.x * (kNmsThreads * kNmsRowsPerThread) + threadIdx.x * 8;
-	uint4 v4[kNmsVec];
+	{
+		uint4 v[kNmsCols + 2];
+		uint4 x = make_uint4(0, 0, 0, 0);
+		const int r0 = base - 8 + t * 8;
+		const int xr0 = base - 8 + (kNmsThreads + (t & 1)) * 8; // the two extra 8-row groups: threads 2j, 2j+1 fetch them for tile column j
+		const int xc = c0 - 1 + (t >> 1);
 #pragma unroll
-	for (int v = 0; v < kNmsVec; ++v) {
-		const int r0 = base + v * (kNmsThreads * 8);
-		v4[v] = make_uint4(0, 0, 0, 0);
-		if (r0 < a.accPitch) v4[v] = *reinterpret_cast<const uint4*>(acc + (size_t)c * p + r0); // the pitch tail (>= R) holds zeros
-	}
-#pragma unroll
-	for (int v = 0; v < kNmsVec; ++v) {
-		const uint32_t ww[4] = { v4[v].x, v4[v].y, v4[v].z, v4[v].w };
-#pragma unroll
-		for (int k = 0; k < 8; ++k) {
-			const int r = base + v * (kNmsThreads * 8) + k;
-			const int val = (int)((ww[k >> 1] >> (16 * (k & 1))) & 0xffffu);
-			keys[v * 8 + k] = 0; // 0 = no line in this slot (a real key always has strength > 0)
-			if (r >= a.R || val <= a.threshold) continue;
-			if (nmsCol && r >= 1 && r <= a.R - 2) {
-				const uint16_t* l = acc + (size_t)(c - 1) * p + r;
-				const uint16_t* m = acc + (size_t)c * p + r;
-				const uint16_t* h = acc + (size_t)(c + 1) * p + r;
-				if (l[-1] > val || l[0] > val || l[1] > val || m[-1] > val || m[1] > val || h[-1] > val || h[0] > val || h[1] > val) continue;
-			}
-			const uint32_t cell = (uint32_t)r * (uint32_t)a.T + (uint32_t)c;
-			keys[v * 8 + k] = frameTag | ((uint64_t)(uint32_t)val << a.cellBits) | (uint64_t)(cellMask - cell);
-			++cnt;
+		for (int j = 0; j < kNmsCols + 2; ++j) {
+			const int c = c0 - 1 + j;
+			v[j] = make_uint4(0, 0, 0, 0);
+			if (c >= 0 && c < a.T && r0 >= 0 && r0 < a.accPitch) v[j] = *reinterpret_cast<const uint4*>(acc + (size_t)c * p + r0);
 		}
+		if (t < 2 * (kNmsCols + 2) && xc >= 0 && xc < a.T && xr0 < a.accPitch) x = *reinterpret_cast<const uint4*>(acc + (size_t)xc * p + xr0);
+#pragma unroll
+		for (int j = 0; j < kNmsCols + 2; ++j) *reinterpret_cast<uint4*>(&s_tile[j][t * 8]) = v[j];
+		if (t < 2 * (kNmsCols + 2)) *reinterpret_cast<uint4*>(&s_tile[t >> 1][(kNmsThreads + (t & 1)) * 8]) = x;
 	}
+	__syncthreads();
+
+	// column j of the block = tile column j+1; this thread's rows are tile rows [8+8t, 16+8t), neighbours at 7+8t and 16+8t
+	auto readCol = [&](int tj, int (&x)[10]) {
+		const uint4 w = *reinterpret_cast<const uint4*>(&s_tile[tj][8 + t * 8]);
+		x[0] = s_tile[tj][7 + t * 8];
+		x[1] = w.x & 0xffffu; x[2] = w.x >> 16; x[3] = w.y & 0xffffu; x[4] = w.y >> 16;
+		x[5] = w.z & 0xffffu; x[6] = w.z >> 16; x[7] = w.w & 0xffffu; x[8] = w.w >> 16;
+		x[9] = s_tile[tj][16 + t * 8];
+	};
+	int side[3][8]; // max(x[k], x[k+1], x[k+2]) of tile columns j, j+1, j+2 (ring)
+	int mid[10], nxt[10];
+	{
+		int x[10];
+		readCol(0, x);
+#pragma unroll
+		for (int k = 0; k < 8; ++k) side[0][k] = max(max(x[k], x[k + 1]), x[k + 2]);
+		readCol(1, mid);
+#pragma unroll
+		for (int k = 0; k < 8; ++k) side[1][k] = max(max(mid[k], mid[k + 1]), mid[k + 2]);
+	}
+	uint32_t flags[2] = { 0u, 0u };
+#pragma unroll
+	for (int j = 0; j < kNmsCols; ++j) {
+		readCol(j + 2, nxt);
+		int* sl = side[j % 3];
+		int* sh = side[(j + 2) % 3];
+#pragma unroll
+		for (int k = 0; k < 8; ++k) sh[k] = max(max(nxt[k], nxt[k + 1]), nxt[k + 2]);
+		const int c = c0 + j;
+		const bool nmsCol = (c >= 1 && c <= a.nmsLastCol);
+		if (c < a.T) {
+#pragma unroll
+			for (int k = 0; k < 8; ++k) {
+				const int r = base + t * 8 + k;
+				const int val = mid[k + 1];
+				bool pass = (r < a.R) && (val > a.threshold);
+				if (nmsCol && r >= 1 && r <= a.R - 2) {
+					const int nb = max(max(sl[k], sh[k]), max(mid[k], mid[k + 2]));
+					pass = pass && (nb <= val);
+				}
+				flags[j >> 2] |= (pass ? 1u : 0u) << ((j & 3) * 8 + k);
+			}
+		}
+#pragma unroll
+		for (int k = 0; k < 10; ++k) mid[k] = nxt[k];
+	}
+	const int cnt = __popc(flags[0]) + __popc(flags[1]);
 	int incl = cnt;
-	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+	const int lane = t & 63, wave = t >> 6;
 #pragma unroll
 	for (int o = 1; o < 64; o <<= 1) {
 		const int n = __shfl_up(incl, o);
@@ -320,19 +385,27 @@ __global__ __launch_bounds__(kNmsThreads) void sht_nms_kernel(ShtArgs a)
 	int wbase = 0, total = 0;
 #pragma unroll
 	for (int k = 0; k < kNmsThreads / 64; ++k) {
-		const int t = s_wave[k];
-		if (k < wave) wbase += t;
-		total += t;
+		const int n = s_wave[k];
+		if (k < wave) wbase += n;
+		total += n;
 	}
 	if (total == 0) return; // uniform
-	if (threadIdx.x == 0) s_base = atomicAdd(&a.lineCounts[frame], total);
+	if (t == 0) s_base = atomicAdd(&a.lineCounts[frame], total);
 	__syncthreads();
 	size_t pos = (size_t)s_base + wbase + (incl - cnt);
 	uint64_t* __restrict__ dst = a.lineKeys + (size_t)frame * a.lineCap;
+	const uint64_t frameTag = (uint64_t)(a.frames - 1 - frame) << (a.strengthBits + a.cellBits);
+	const uint32_t cellMask = (1u << a.cellBits) - 1u;
 #pragma unroll
-	for (int k = 0; k < kNmsRowsPerThread; ++k) {
-		if (keys[k]) {
-			if (pos < a.lineCap) dst[pos] = keys[k];
+	for (int h = 0; h < 2; ++h) {
+		uint32_t f = flags[h];
+		while (f) {
+			const int b = __ffs(f) - 1;
+			f &= f - 1;
+			const int j = h * 4 + (b >> 3), k = b & 7;
+			const uint32_t val = s_tile[j + 1][8 + t * 8 + k];
+			const uint32_t cell = (uint32_t)(base + t * 8 + k) * (uint32_t)a.T + (uint32_t)(c0 + j);
+			if (pos < a.lineCap) dst[pos] = frameTag | ((uint64_t)val << a.cellBits) | (uint64_t)(cellMask - cell);
 			++pos;
 		}
 	}
@@ -342,7 +415,7 @@ struct LineOut { float rho; float theta; int32_t strength; int32_t row; int32_t 
 
 // After the global descending sort the lines of frame f start at sum_{g<f} min(count_g, lineCap).
 __global__ __launch_bounds__(256) void sht_decode_kernel(const uint64_t* __restrict__ keys, const int* __restrict__ counts, size_t lineCap, int T, int barrier,
-                                                         float thetaStep, int maxLines, int cellBits, LineOut* __restrict__ lines, size_t outCap)
+                                                         float thetaStep, int maxLines, int cellBits, int strengthBits, LineOut* __restrict__ lines, size_t outCap)
 {
 	const int frame = blockIdx.y;
 	size_t off = 0;
@@ -363,7 +436,7 @@ __global__ __launch_bounds__(256) void sht_decode_kernel(const uint64_t* __restr
 	LineOut o;
 	o.rho = (float)(barrier - row);              // static_cast<float>(barrier - row), houghsht.cxx:661
 	o.theta = __fmul_rn((float)col, thetaStep);  // col * theta (f32), houghsht.cxx:662
-	o.strength = (int32_t)((k >> cellBits) & 0xffffu);
+	o.strength = (int32_t)((k >> cellBits) & ((1u << strengthBits) - 1u));
 	o.row = row; o.col = col;
 	lines[(size_t)frame * outCap + i] = o;
 }
@@ -436,8 +509,7 @@ hipError_t launch_sht_nms(const ShtArgs& a, int frames, hipStream_t stream)
 	// unused key slots must sort last: zero the whole key array
 	e = hipMemsetAsync(a.lineKeys, 0, sizeof(uint64_t) * a.lineCap * frames, stream);
 	if (e != hipSuccess) return e;
-	const int rowsPerBlock = kNmsThreads * kNmsRowsPerThread;
-	dim3 grid((a.R + rowsPerBlock - 1) / rowsPerBlock, a.T, frames);
+	dim3 grid((a.R + kNmsRows - 1) / kNmsRows, (a.T + kNmsCols - 1) / kNmsCols, frames);
 	hipLaunchKernelGGL(sht_nms_kernel, grid, dim3(kNmsThreads), 0, stream, a);
 	return hipGetLastError();
 }
@@ -450,13 +522,13 @@ hipError_t sht_sort_keys(void* temp, size_t& tempBytes, const uint64_t* keysIn, 
 }
 
 hipError_t launch_sht_decode(const uint64_t* keys, const int* counts, size_t lineCap, int frames, int T, int barrier, float thetaStep,
-                             int maxLines, int cellBits, void* lines, size_t outCap, hipStream_t stream)
+                             int maxLines, int cellBits, int strengthBits, void* lines, size_t outCap, hipStream_t stream)
 {
 	size_t n = lineCap < outCap ? lineCap : outCap;
 	if (maxLines > 0 && (size_t)maxLines < n) n = (size_t)maxLines;
 	if (n == 0) return hipSuccess;
 	dim3 grid((unsigned)((n + 255) / 256), frames);
-	hipLaunchKernelGGL(sht_decode_kernel, grid, dim3(256), 0, stream, keys, counts, lineCap, T, barrier, thetaStep, maxLines, cellBits,
+	hipLaunchKernelGGL(sht_decode_kernel, grid, dim3(256), 0, stream, keys, counts, lineCap, T, barrier, thetaStep, maxLines, cellBits, strengthBits,
 	                   reinterpret_cast<LineOut*>(lines), outCap);
 	return hipGetLastError();
 }
