@@ -64,7 +64,7 @@ struct compvhip_plan {
 	// sht
 	bool shtReady = false;
 	size_t R = 0, T = 0; float thetaStep = 0.f; int accPitch = 0;
-	int32_t* sinQ = nullptr; int32_t* cosQ = nullptr;
+	int32_t* sinQ = nullptr; int32_t* cosQ = nullptr; int32_t* groupOrder = nullptr; int thetaPerGroup = 4;
 	uint32_t* edges = nullptr; size_t edgeCap = 0; int* edgeCounts = nullptr;
 	uint16_t* acc = nullptr; size_t accFrameStride = 0;
 	uint64_t* keysA = nullptr; uint64_t* keysB = nullptr; size_t lineCap = 0; int* lineCounts = nullptr;
@@ -211,6 +211,29 @@ int ensureSht(compvhip_plan* p)
 	HIPCHK(ctx, dmalloc(ctx, &p->cosQ, T));
 	HIPCHK(ctx, hipMemcpy(p->sinQ, s.data(), T * sizeof(int32_t), hipMemcpyHostToDevice));
 	HIPCHK(ctx, hipMemcpy(p->cosQ, c.data(), T * sizeof(int32_t), hipMemcpyHostToDevice));
+	{
+		// theta bins per vote workgroup: 2 (two 16-wave workgroups per CU; measured 0.53 ms vs 0.60 ms per 32 4K frames), 4 via the tuning knob
+		const char* e = getenv("COMPVHIP_SHT_THETA_PER_GROUP");
+		p->thetaPerGroup = ((e && atoi(e) == 4) && sht_vote_lds_bytes(static_cast<int>(R), 4) <= 160 * 1024) ? 4 : 2;
+		// Launch order of the theta groups: the bins next to 90 deg (then 0/180 deg) collect the votes of the horizontal (vertical)
+		// structures of man-made scenes in a handful of rho cells, and same-address LDS atomics serialise (2 clk per lane on gfx950),
+		// so those workgroups run longest: dispatch them first instead of leaving them for the tail of the launch.
+		const int tg = p->thetaPerGroup, groups = static_cast<int>((T + tg - 1) / tg);
+		std::vector<int32_t> order(groups);
+		for (int g = 0; g < groups; ++g) order[g] = g;
+		auto axisDist = [&](int g) { // distance (in bins) of the group's nearest bin to 0, T/2 or T
+			double best = 1e30;
+			for (int k = 0; k < tg; ++k) {
+				const double t = g * tg + k;
+				const double d = std::min(std::min(std::fabs(t), std::fabs(t - 0.5 * T)), std::fabs(t - 1.0 * T));
+				best = std::min(best, d);
+			}
+			return best;
+		};
+		std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return axisDist(a) < axisDist(b); });
+		HIPCHK(ctx, dmalloc(ctx, &p->groupOrder, static_cast<size_t>(groups)));
+		HIPCHK(ctx, hipMemcpy(p->groupOrder, order.data(), groups * sizeof(int32_t), hipMemcpyHostToDevice));
+	}
 	p->edgeCap = p->W * p->H;
 	HIPCHK(ctx, dmalloc(ctx, &p->edges, p->edgeCap * p->frames));
 	HIPCHK(ctx, dmalloc(ctx, &p->edgeCounts, p->frames));
@@ -267,8 +290,7 @@ ShtArgs shtArgs(compvhip_plan* p, int threshold)
 	a.shards = p->shards;
 	a.frames = static_cast<int>(p->frames);
 	a.cellBits = p->cellBits; a.strengthBits = p->strengthBits;
-	static const int tg = [] { const char* e = getenv("COMPVHIP_SHT_THETA_PER_GROUP"); return (e && atoi(e) == 2) ? 2 : 4; }(); // tuning knob
-	a.thetaPerGroup = tg;
+	a.thetaPerGroup = p->thetaPerGroup; a.groupOrder = p->groupOrder;
 	return a;
 }
 
@@ -429,7 +451,7 @@ void compvhip_plan_destroy(compvhip_plan* p)
 	timelineClear(p);
 	dfree(ctx, p->ebits); dfree(ctx, p->ubits); dfree(ctx, p->flags); dfree(ctx, p->thrDev); dfree(ctx, p->sums); dfree(ctx, p->tmpOut);
 	if (p->hFlags) (void)hipHostFree(p->hFlags);
-	dfree(ctx, p->sinQ); dfree(ctx, p->cosQ); dfree(ctx, p->edges); dfree(ctx, p->edgeCounts); dfree(ctx, p->acc);
+	dfree(ctx, p->sinQ); dfree(ctx, p->cosQ); dfree(ctx, p->groupOrder); dfree(ctx, p->edges); dfree(ctx, p->edgeCounts); dfree(ctx, p->acc);
 	dfree(ctx, p->keysA); dfree(ctx, p->keysB); dfree(ctx, p->lineCounts);
 	dfree(ctx, p->sortTemp);
 	delete p;

@@ -76,6 +76,7 @@ struct ShtArgs {
 	int cellBits;             // bits of the accumulator cell index in a line key (2^cellBits > R*T)
 	int strengthBits;         // bits of the strength field of a line key (2^strengthBits > 2*max(W,H) >= any cell count)
 	int thetaPerGroup;        // 4 (default) or 2 theta bins per vote workgroup
+	const int32_t* groupOrder; // vote workgroup rank -> theta group, most expensive groups (theta near 90, 0, 180 deg) first
 };
 hipError_t launch_bytes_to_bits(const uint8_t* edges, int W, int H, int S, size_t frameStride, uint32_t* ebits, int wb, size_t bitsFrameStride,
                                 int frames, hipStream_t stream);

@@ -66,13 +66,13 @@ __global__ __launch_bounds__(256) void bytes_to_bits_kernel(const uint8_t* __res
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kCompactThreads = 256;
 constexpr int kCompactWords = 8;
-constexpr int kCompactStage = 2048; // edges a wave can expand through LDS (it owns 64*8*32 = 16384 pixels)
+constexpr int kCompactStage = 8192; // edges a block can expand through LDS (it owns 256*8*32 = 65536 pixels)
 
 __global__ __launch_bounds__(kCompactThreads) void sht_compact_kernel(ShtArgs a)
 {
 	__shared__ int s_wave[kCompactThreads / 64];
 	__shared__ int s_base;
-	__shared__ uint32_t s_stage[kCompactThreads / 64][kCompactStage];
+	__shared__ uint32_t s_stage[kCompactStage + kCompactStage / 64];
 	const int frame = blockIdx.y;
 	const size_t nwords = (size_t)a.H * a.wb; // wb is a multiple of 16, so nwords % kCompactWords == 0
 	const size_t w0 = ((size_t)blockIdx.x * kCompactThreads + threadIdx.x) * kCompactWords;
@@ -108,11 +108,12 @@ __global__ __launch_bounds__(kCompactThreads) void sht_compact_kernel(ShtArgs a)
 	if (threadIdx.x == 0) s_base = atomicAdd(&a.edgeCounts[frame], total);
 	__syncthreads();
 	uint32_t* __restrict__ dst = a.edges + (size_t)frame * a.edgeCap;
-	const int waveTotal = __shfl(incl, 63);
-	if (waveTotal <= kCompactStage) {
-		// usual case: expand into the wave's LDS slice, then copy out with coalesced stores
-		uint32_t* st = s_stage[wave];
-		int lp = incl - cnt;
+	if (total <= kCompactStage) {
+		// usual case: expand into LDS in raster order (pitch 65 per 64 entries), then write the block's slice of the list
+		// TRANSPOSED: the slice is read as a [nr][64] matrix (last row ragged) and emitted column by column, so 64 consecutive
+		// list entries are 64 raster positions apart -- the voting kernel can then hand consecutive entries to the 64 lanes of
+		// one ds_add without piling onto a single rho bin near theta = 90 deg. Stores are coalesced.
+		int lp = wbase + incl - cnt;
 #pragma unroll
 		for (int k = 0; k < kCompactWords; ++k) {
 			uint32_t b = bits[k];
@@ -123,13 +124,20 @@ __global__ __launch_bounds__(kCompactThreads) void sht_compact_kernel(ShtArgs a)
 			while (b) {
 				const int bit = __ffs(b) - 1;
 				b &= b - 1;
-				st[lp++] = yx0 + (uint32_t)bit;
+				s_stage[lp + (lp >> 6)] = yx0 + (uint32_t)bit;
+				++lp;
 			}
 		}
-		__builtin_amdgcn_wave_barrier();
-		const size_t wpos = (size_t)s_base + wbase;
-		for (int i = lane; i < waveTotal; i += 64)
-			if (wpos + i < a.edgeCap) dst[wpos + i] = st[i];
+		__syncthreads();
+		const int nr = (total + 63) >> 6;
+		const int m = total - (nr - 1) * 64; // entries of the last matrix row: columns < m hold nr entries, the others nr-1
+		for (int q = threadIdx.x; q < total; q += kCompactThreads) {
+			int c, r;
+			if (q < m * nr) { c = q / nr; r = q - c * nr; }
+			else { const int q2 = q - m * nr; const int c2 = q2 / (nr - 1); c = m + c2; r = q2 - c2 * (nr - 1); }
+			const size_t pos = (size_t)s_base + q;
+			if (pos < a.edgeCap) dst[pos] = s_stage[r * 65 + c];
+		}
 		return;
 	}
 	size_t pos = (size_t)s_base + wbase + (incl - cnt);
@@ -154,54 +162,53 @@ __global__ __launch_bounds__(kCompactThreads) void sht_compact_kernel(ShtArgs a)
 // ---------------------------------------------------------------------------------------------------------------
 // voting
 // ---------------------------------------------------------------------------------------------------------------
-// LDS: two [Rp] arrays of packed u16 counter pairs + a double-buffered staging area of kStageEdges edges laid out
-// [64][kStageCols+1] (the +1 makes both the coalesced row-major fill and the lane==row reads bank-conflict free).
-constexpr int kVoteWaves = kShtVoteThreads / 64;         // 16
-
-// TG = theta bins per workgroup (4: one 129 KB workgroup per CU; 2: two 65 KB workgroups per CU, twice the edge staging)
-template <int TG> struct VoteCfg {
-	static constexpr int kEdgesPerThread = TG;                       // per stage
-	static constexpr int kStageCols = kVoteWaves * kEdgesPerThread;  // edges per lane-row
-	static constexpr int kStageEdges = 64 * kStageCols;              // edges per stage
-	static constexpr int kStagePitch = kStageCols + 1;
-};
+// LDS: TG/2 arrays [Rp] of packed u16 counter pairs, nothing else. The edge list arrives already decorrelated (see
+// sht_compact_kernel: 64 consecutive entries are 64 raster positions apart), so every wave streams its own 64-edge chunks
+// with plain coalesced loads and the main loop has NO workgroup barrier: the LDS atomic pipe never drains.
+constexpr int kVoteUnroll = 4;                           // 64-edge chunks in flight per wave
 
 size_t sht_vote_lds_bytes(int R, int tg)
 {
-	const size_t pitch = (size_t)kVoteWaves * tg + 1;
-	return ((size_t)((R + 31) & ~31) * (tg / 2) + (size_t)2 * 64 * pitch) * sizeof(uint32_t);
+	return (size_t)((R + 31) & ~31) * (tg / 2) * sizeof(uint32_t);
 }
 
-template <int TG>
+// SC ("scaled"): TG == 2 and W+H < 8192.  The Q16 products are formed with 4*cosQ / 4*sinQ so that the HIGH HALF of the
+// 32-bit sum is the histogram BYTE offset (4 * rho index, < 65536): one v_and_b32 with an SDWA WORD_1 source select replaces
+// the shift + scaled address add -- 4 VALU per vote (2 SDWA v_mul_i32_i24, v_add3, v_and) instead of 5.
+template <int TG, bool SC>
 __global__ __launch_bounds__(kShtVoteThreads) void sht_vote_kernel(ShtArgs a)
 {
 	constexpr int kShtThetaPerGroup = TG;
-	constexpr int kEdgesPerThread = VoteCfg<TG>::kEdgesPerThread;
-	constexpr int kStageCols = VoteCfg<TG>::kStageCols;
-	constexpr int kStageEdges = VoteCfg<TG>::kStageEdges;
-	constexpr int kStagePitch = VoteCfg<TG>::kStagePitch;
 	extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
 	const int R = a.R;
-	// [2][Rp]: pair 0 = thetas (t0,t0+1), pair 1 = (t0+2,t0+3) as u16 halves.  Pair-major so that one ds_add_u32
-	// instruction (fixed pair, 64 different rho) can spread over all 32 banks ([R][2] would only ever touch 16).
+	// [TG/2][Rp]: pair 0 = thetas (t0,t0+1), pair 1 = (t0+2,t0+3) as u16 halves.  Pair-major so that one ds_add_u32
+	// instruction (fixed pair, 64 different rho) can spread over all banks ([R][2] would only ever touch half).
 	const int Rp = (R + 31) & ~31;
 	uint32_t* hist = smem;
-	uint32_t* stage = smem + (TG / 2) * Rp; // [2][64][kStagePitch]
-	const int frame = blockIdx.z;
-	const int shard = blockIdx.y;
-	const int t0 = blockIdx.x * kShtThetaPerGroup;
+	const int frame = blockIdx.x; // frames fastest: the launch walks the theta groups in groupOrder (expensive first) for all frames
+	const int shard = blockIdx.z;
+	const int t0 = a.groupOrder[blockIdx.y] * kShtThetaPerGroup;
 	const int tid = threadIdx.x;
 	const int lane = tid & 63, wave = tid >> 6;
 
-	for (int i = tid; i < (TG / 2) * Rp; i += kShtVoteThreads) hist[i] = 0u;
+	const int nthreads = blockDim.x; // 256..1024 (launch_sht_vote)
+	for (int i = tid; i < (TG / 2) * Rp; i += nthreads) hist[i] = 0u;
 
-	int cq[kShtThetaPerGroup], sq[kShtThetaPerGroup];
+	// hist index of theta k = barrier - ((x*cosQ + y*sinQ) >> 16) = (K - x*cosQ - y*sinQ) >> 16 with K = (barrier << 16) + 65535
+	// (exact: barrier - floor(v/65536) == floor((barrier*65536 + 65535 - v)/65536)): two v_mad_i32_i24, a shift and the address add
+	int ncq[kShtThetaPerGroup], nsq[kShtThetaPerGroup];
+	uint32_t inc[kShtThetaPerGroup];
 #pragma unroll
 	for (int k = 0; k < kShtThetaPerGroup; ++k) {
 		const int t = min(t0 + k, a.T - 1);
-		cq[k] = a.cosQ[t];
-		sq[k] = a.sinQ[t];
+		ncq[k] = -a.cosQ[t] * (SC ? 4 : 1);
+		nsq[k] = -a.sinQ[t] * (SC ? 4 : 1);
+		inc[k] = (t0 + k < a.T) ? ((k & 1) ? 0x10000u : 1u) : 0u; // a theta past T adds nothing (branch-free inner loop)
+		if constexpr (SC) asm volatile("" : "+v"(inc[k])); // keep the addend in a VGPR (ds_add data operand), not re-materialised per vote
 	}
+	// SC: the LDS byte address of hist[0] rides in the high half too, so the masked high half IS the ds_add address
+	const int K = ((a.barrier << 16) + 65535) * (SC ? 4 : 1) + (SC ? (int)(((uint32_t)reinterpret_cast<uintptr_t>(hist) & 0xffffu) << 16) : 0);
+	const uint32_t offMask = 0xfffcu;
 	const int nvalid = min(kShtThetaPerGroup, a.T - t0);
 
 	const int n = min(a.edgeCounts[frame], (int)a.edgeCap);
@@ -209,63 +216,51 @@ __global__ __launch_bounds__(kShtVoteThreads) void sht_vote_kernel(ShtArgs a)
 	const int sEnd = (int)(((long long)n * (shard + 1)) / a.shards);
 	const int cnt = sEnd - sBeg;
 	const uint32_t* __restrict__ edges = a.edges + (size_t)frame * a.edgeCap + sBeg;
-	const int barrier = a.barrier;
-	const int nstages = (cnt + kStageEdges - 1) / kStageEdges;
+	__syncthreads(); // histogram zeroed
 
-	// stage s: element j = k*1024 + tid (k = 0..3) -> coalesced dword loads, parked at [j / kStageCols][j % kStageCols]
-	auto fetch = [&](int s, uint32_t (&e)[kEdgesPerThread]) {
-		const int base = s * kStageEdges + tid;
+	auto fetch = [&](int j0, uint32_t (&e)[kVoteUnroll]) {
 #pragma unroll
-		for (int k = 0; k < kEdgesPerThread; ++k) {
-			const int j = base + k * kShtVoteThreads;
-			e[k] = (j < cnt) ? edges[j] : 0xffffffffu;
+		for (int u = 0; u < kVoteUnroll; ++u) {
+			const int j = j0 + u * nthreads;
+			e[u] = (j < cnt) ? edges[j] : 0xffffffffu;
 		}
 	};
-	auto park = [&](int buf, const uint32_t (&e)[kEdgesPerThread]) {
-		uint32_t* dst = stage + buf * (64 * kStagePitch);
+	auto vote = [&](const uint32_t (&e)[kVoteUnroll]) {
 #pragma unroll
-		for (int k = 0; k < kEdgesPerThread; ++k) {
-			const int j = k * kShtVoteThreads + tid;
-			dst[(j / kStageCols) * kStagePitch + (j % kStageCols)] = e[k];
-		}
-	};
-
-	// software pipeline: while stage s is voted from LDS buffer s&1, stage s+1 is parked into the other buffer and the
-	// global loads of stage s+2 are in flight -- one barrier per stage, a whole stage of latency budget per load
-	uint32_t regs[kEdgesPerThread];
-	if (nstages > 0) { fetch(0, regs); park(0, regs); }
-	if (nstages > 1) fetch(1, regs);
-	__syncthreads(); // histogram zeroed, stage 0 parked
-	for (int s = 0; s < nstages; ++s) {
-		// lane l of wave w votes edges [l][w*4 .. w*4+3]: the 64 lanes of a wave are kStageCols raster positions apart, so
-		// raster neighbours (same rho around theta = 90 deg) never share an instruction
-		const uint32_t* src = stage + (s & 1) * (64 * kStagePitch) + lane * kStagePitch + wave * kEdgesPerThread;
-		uint32_t mine[kEdgesPerThread];
-#pragma unroll
-		for (int i = 0; i < kEdgesPerThread; ++i) mine[i] = src[i];
-		if (s + 1 < nstages) park((s + 1) & 1, regs);
-		if (s + 2 < nstages) fetch(s + 2, regs);
-#pragma unroll
-		for (int i = 0; i < kEdgesPerThread; ++i) {
-			const uint32_t xy = mine[i];
+		for (int u = 0; u < kVoteUnroll; ++u) {
+			const uint32_t xy = e[u];
 			if (xy == 0xffffffffu) continue;
 			const int x = (int)(xy & 0xffffu), y = (int)(xy >> 16);
 #pragma unroll
 			for (int k = 0; k < kShtThetaPerGroup; ++k) {
-				if (k < nvalid) {
-					const int rho = (__mul24(x, cq[k]) + __mul24(y, sq[k])) >> 16;
-					const int idx = barrier - rho;
-					atomicAdd(&hist[(k >> 1) * Rp + idx], (k & 1) ? 0x10000u : 1u);
+				const uint32_t v = (uint32_t)(__mul24(x, ncq[k]) + (__mul24(y, nsq[k]) + K));
+				if constexpr (SC) {
+					uint32_t off;
+					asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(off) : "v"(offMask), "v"(v));
+					asm volatile("ds_add_u32 %0, %1" : : "v"(off), "v"(inc[k]) : "memory");
 				}
+				else atomicAdd(&hist[(k >> 1) * Rp + (v >> 16)], inc[k]);
 			}
 		}
-		__syncthreads();
+	};
+	// wave w of nw owns the 64-edge chunks w, w+nw, w+2nw, ...; kVoteUnroll of them are voted while the next kVoteUnroll load
+	const int kStep = kVoteUnroll * nthreads;
+	uint32_t cur[kVoteUnroll], nxt[kVoteUnroll];
+	int j0 = wave * 64 + lane;
+	fetch(j0, cur);
+	for (; j0 - lane < cnt; j0 += kStep) { // uniform per wave
+		fetch(j0 + kStep, nxt);
+		vote(cur);
+#pragma unroll
+		for (int u = 0; u < kVoteUnroll; ++u) cur[u] = nxt[u];
 	}
+	if constexpr (SC) __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): the asm ds_add are invisible to the compiler's counters
+	__syncthreads();
 
 	// flush: the accumulator is u16 (a cell never exceeds 65535, see above), theta-major; each thread writes two
 	// adjacent rho rows of one theta as one dword (accPitch is even)
 	uint16_t* __restrict__ acc = a.acc + (size_t)frame * a.accFrameStride + (size_t)t0 * a.accPitch;
-	for (int r2 = tid; r2 < Rp / 2; r2 += kShtVoteThreads) {
+	for (int r2 = tid; r2 < Rp / 2; r2 += nthreads) {
 		const int r = 2 * r2;
 		const uint32_t a0 = hist[r], a1 = hist[r + 1];
 		const uint32_t b0 = (TG > 2) ? hist[Rp + r] : 0u, b1 = (TG > 2) ? hist[Rp + r + 1] : 0u;
@@ -481,24 +476,29 @@ hipError_t launch_sht_compact(const ShtArgs& a, int frames, hipStream_t stream)
 
 hipError_t launch_sht_vote(const ShtArgs& a, int frames, hipStream_t stream)
 {
-	static size_t attr_lds[2] = { 0, 0 };
-	const int tg = a.thetaPerGroup == 2 ? 2 : 4;
+	const int tg = a.thetaPerGroup == 4 ? 4 : 2;
+	const bool sc = (tg == 2) && (a.barrier < 8192);
 	const size_t lds = sht_vote_lds_bytes(a.R, tg);
 	if (lds > 160 * 1024) return hipErrorInvalidValue;
-	if (lds > attr_lds[tg == 2]) {
-		hipError_t e = hipFuncSetAttribute(tg == 2 ? reinterpret_cast<const void*>(sht_vote_kernel<2>) : reinterpret_cast<const void*>(sht_vote_kernel<4>),
-		                                   hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+	const void* fn = tg == 4 ? reinterpret_cast<const void*>(sht_vote_kernel<4, false>)
+	               : sc ? reinterpret_cast<const void*>(sht_vote_kernel<2, true>) : reinterpret_cast<const void*>(sht_vote_kernel<2, false>);
+	static size_t attr_lds[3] = { 0, 0, 0 };
+	const int slot = tg == 4 ? 0 : (sc ? 1 : 2);
+	if (lds > attr_lds[slot]) {
+		hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 		if (e != hipSuccess) return e;
-		attr_lds[tg == 2] = lds;
+		attr_lds[slot] = lds;
 	}
 	if (a.shards > 1) {
 		hipError_t e = hipMemsetAsync(a.acc, 0, sizeof(uint16_t) * a.accFrameStride * frames, stream);
 		if (e != hipSuccess) return e;
 	}
 	const int groups = (a.T + tg - 1) / tg;
-	dim3 grid(groups, a.shards, frames);
-	if (tg == 2) hipLaunchKernelGGL(sht_vote_kernel<2>, grid, dim3(kShtVoteThreads), lds, stream, a);
-	else hipLaunchKernelGGL(sht_vote_kernel<4>, grid, dim3(kShtVoteThreads), lds, stream, a);
+	dim3 grid(frames, groups, a.shards);
+	static const int threads = [] { const char* e = getenv("COMPVHIP_SHT_VOTE_THREADS"); const int v = e ? atoi(e) : 0; return (v == 256 || v == 512 || v == 1024) ? v : kShtVoteThreads; }(); // tuning knob
+	if (tg == 4) hipLaunchKernelGGL((sht_vote_kernel<4, false>), grid, dim3(threads), lds, stream, a);
+	else if (sc) hipLaunchKernelGGL((sht_vote_kernel<2, true>), grid, dim3(threads), lds, stream, a);
+	else hipLaunchKernelGGL((sht_vote_kernel<2, false>), grid, dim3(threads), lds, stream, a);
 	return hipGetLastError();
 }
 
