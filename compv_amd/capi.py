@@ -245,8 +245,9 @@ class Plan:
         self.ctx._chk(self.lib.compvhip_plan_edge_counts(self.h, C.byref(p)))
         return p.value
 
-    def set_timing(self, on=True):
-        self.ctx._chk(self.lib.compvhip_plan_set_timing(self.h, 1 if on else 0))
+    def set_timing(self, mode=1):
+        """0/False = off, 1/True = HIP events around every kernel, 2 = only around the two roofline kernels."""
+        self.ctx._chk(self.lib.compvhip_plan_set_timing(self.h, int(mode)))
 
     def get_timing(self, cap=256):
         names = (C.c_char_p * cap)()

@@ -72,7 +72,8 @@ struct compvhip_plan {
 	int cellBits = 0, strengthBits = 16, keyBits = 0;
 	int shards = 1;
 	// timing
-	bool timing = false;
+	int timing = 0; // 0 off, 1 every kernel, 2 roofline kernels only
+	std::vector<hipEvent_t> eventPool;
 	std::vector<TimingEntry> timeline;
 	std::vector<std::string> timingNames; std::vector<float> timingMs;
 };
@@ -161,13 +162,29 @@ void shtTables(float thetaDeg, size_t T, std::vector<int32_t>& sinQ, std::vector
 	}
 }
 
+// timing mode 1 = every kernel; 2 = only the two kernels bench.py prices against the roofline (an event pair costs a few
+// microseconds of stream time, ~0.1 ms per step when wrapped around all ~13 launches of the pipeline)
+static bool stampWanted(const compvhip_plan* p, const char* name)
+{
+	if (p->timing == 1) return true;
+	if (p->timing == 2) return !strcmp(name, "canny_tile_kernel") || !strcmp(name, "sht_vote_kernel");
+	return false;
+}
+
+static bool takeEvent(compvhip_plan* p, hipEvent_t* e)
+{
+	if (!p->eventPool.empty()) { *e = p->eventPool.back(); p->eventPool.pop_back(); return true; }
+	return hipEventCreate(e) == hipSuccess;
+}
+
 struct Stamp {
 	compvhip_plan* p; hipStream_t s; size_t idx; bool on;
-	Stamp(compvhip_plan* plan, hipStream_t stream, const char* name) : p(plan), s(stream), idx(0), on(plan->timing)
+	Stamp(compvhip_plan* plan, hipStream_t stream, const char* name) : p(plan), s(stream), idx(0), on(stampWanted(plan, name))
 	{
 		if (!on) return;
 		TimingEntry t; t.name = name;
-		if (hipEventCreate(&t.a) != hipSuccess || hipEventCreate(&t.b) != hipSuccess) { on = false; return; }
+		if (!takeEvent(p, &t.a)) { on = false; return; }
+		if (!takeEvent(p, &t.b)) { p->eventPool.push_back(t.a); on = false; return; }
 		(void)hipEventRecord(t.a, s);
 		p->timeline.push_back(t);
 		idx = p->timeline.size() - 1;
@@ -177,7 +194,7 @@ struct Stamp {
 
 void timelineClear(compvhip_plan* p)
 {
-	for (auto& t : p->timeline) { (void)hipEventDestroy(t.a); (void)hipEventDestroy(t.b); }
+	for (auto& t : p->timeline) { p->eventPool.push_back(t.a); p->eventPool.push_back(t.b); } // events are reused, not re-created
 	p->timeline.clear();
 }
 
@@ -449,6 +466,7 @@ void compvhip_plan_destroy(compvhip_plan* p)
 	compvhip_ctx* ctx = p->ctx;
 	(void)hipSetDevice(ctx->device);
 	timelineClear(p);
+	for (hipEvent_t e : p->eventPool) (void)hipEventDestroy(e);
 	dfree(ctx, p->ebits); dfree(ctx, p->ubits); dfree(ctx, p->flags); dfree(ctx, p->thrDev); dfree(ctx, p->sums); dfree(ctx, p->tmpOut);
 	if (p->hFlags) (void)hipHostFree(p->hFlags);
 	dfree(ctx, p->sinQ); dfree(ctx, p->cosQ); dfree(ctx, p->groupOrder); dfree(ctx, p->edges); dfree(ctx, p->edgeCounts); dfree(ctx, p->acc);
@@ -460,7 +478,7 @@ void compvhip_plan_destroy(compvhip_plan* p)
 int compvhip_plan_set_timing(compvhip_plan* p, int enabled)
 {
 	if (!p) return COMPVHIP_E_INVALID_PARAMETER;
-	p->timing = enabled != 0;
+	p->timing = (enabled == 2) ? 2 : (enabled != 0 ? 1 : 0);
 	return COMPVHIP_OK;
 }
 
