@@ -141,6 +141,44 @@ def test_houghsht_matches_oracle(hip_ctx, oracle, W, H, tl, th, deg, thr):
         assert _lines_tuple(top) == _orc_tuple(exp[:5])
 
 
+@pytest.mark.parametrize("W,H", [(8000, 191), (8000, 192), (40, 8300), (12000, 48)])
+def test_houghsht_wide_rho_range(hip_ctx, oracle, W, H):
+    """W+H = 8191 is the last size on the scaled 4-VALU vote kernel, 8192 the first on the generic one; 12048 needs a
+    24 097-row LDS histogram (the limit is W+H <= 20479)."""
+    rng = np.random.default_rng(W + H)
+    edges = np.where(rng.random((H, W)) < 0.02, 0xff, 0).astype(np.uint8)
+    edges[H // 2, :] = 0xff
+    edges[:, W // 3] = 0xff
+    acc_exp = oracle.sht_acc(edges, 1.0)
+    exp = oracle.sht_lines_from_acc(acc_exp, W, H, 1.0, 30)
+    lines, acc = hip_ctx.houghsht(edges, 1.0, 30, want_acc=True)
+    assert (acc == acc_exp).all(), int((acc != acc_exp).sum())
+    assert _lines_tuple(lines) == _orc_tuple(exp)
+
+
+def test_houghsht_four_theta_per_workgroup(oracle, monkeypatch):
+    """The 4-theta-bins-per-workgroup variant of the vote kernel (tuning knob) produces the same histogram."""
+    from compv_amd import capi
+    monkeypatch.setenv("COMPVHIP_SHT_THETA_PER_GROUP", "4")
+    ctx = capi.Context(0)
+    try:
+        W, H = 641, 480
+        rc, edges = oracle.canny(synth_frame(W, H), 59., 119.)
+        acc_exp = oracle.sht_acc(edges, 1.0)
+        lines, acc = ctx.houghsht(edges, 1.0, 100, want_acc=True)
+        assert (acc == acc_exp).all()
+        assert _lines_tuple(lines) == _orc_tuple(oracle.sht_lines_from_acc(acc_exp, W, H, 1.0, 100))
+    finally:
+        ctx.close()
+
+
+def test_houghsht_rho_range_limit(hip_ctx):
+    from compv_amd import capi
+    with pytest.raises(capi.CompvHipError) as ex:
+        hip_ctx.houghsht(np.zeros((16, 20480), np.uint8), 1.0, 10)   # 2*(W+H)+1 rho rows no longer fit the 160 KB LDS histogram
+    assert ex.value.code == capi.E_NOT_IMPLEMENTED
+
+
 def test_houghsht_empty_and_full_maps(hip_ctx, oracle):
     W, H = 160, 120
     none = np.zeros((H, W), np.uint8)
