@@ -189,7 +189,6 @@ __global__ __launch_bounds__(kShtVoteThreads) void sht_vote_kernel(ShtArgs a)
 	const int shard = blockIdx.z;
 	const int t0 = a.groupOrder[blockIdx.y] * kShtThetaPerGroup;
 	const int tid = threadIdx.x;
-	const int lane = tid & 63, wave = tid >> 6;
 
 	const int nthreads = blockDim.x; // 256..1024 (launch_sht_vote)
 	for (int i = tid; i < (TG / 2) * Rp; i += nthreads) hist[i] = 0u;
@@ -218,42 +217,46 @@ __global__ __launch_bounds__(kShtVoteThreads) void sht_vote_kernel(ShtArgs a)
 	const uint32_t* __restrict__ edges = a.edges + (size_t)frame * a.edgeCap + sBeg;
 	__syncthreads(); // histogram zeroed
 
-	auto fetch = [&](int j0, uint32_t (&e)[kVoteUnroll]) {
+	auto voteEdge = [&](uint32_t xy) {
+		const int x = (int)(xy & 0xffffu), y = (int)(xy >> 16);
 #pragma unroll
-		for (int u = 0; u < kVoteUnroll; ++u) {
-			const int j = j0 + u * nthreads;
-			e[u] = (j < cnt) ? edges[j] : 0xffffffffu;
+		for (int k = 0; k < kShtThetaPerGroup; ++k) {
+			const uint32_t v = (uint32_t)(__mul24(x, ncq[k]) + (__mul24(y, nsq[k]) + K));
+			if constexpr (SC) {
+				uint32_t off;
+				asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(off) : "v"(offMask), "v"(v));
+				asm volatile("ds_add_u32 %0, %1" : : "v"(off), "v"(inc[k]) : "memory");
+			}
+			else atomicAdd(&hist[(k >> 1) * Rp + (v >> 16)], inc[k]);
 		}
+	};
+	// Main loop: whole steps of kVoteUnroll * nthreads edges, no bounds or sentinel tests (the per-edge bookkeeping would cost as
+	// many VALU cycles as the votes: the kernel sits at ~80 % of BOTH the VALU and the LDS pipe).  The step base is wave-uniform
+	// (scalar pointer arithmetic), the lane offset a constant VGPR; loads of step i+1 are in flight while step i votes; the
+	// two register sets alternate (loop unrolled by two) so no copies are needed.
+	const uint32_t step = (uint32_t)kVoteUnroll * (uint32_t)nthreads;
+	const uint32_t full = (uint32_t)cnt / step;
+	auto fetch = [&](uint32_t it, uint32_t (&e)[kVoteUnroll]) {
+		const uint32_t* __restrict__ base = edges + (size_t)it * step; // uniform
+#pragma unroll
+		for (int u = 0; u < kVoteUnroll; ++u) e[u] = (base + u * nthreads)[(uint32_t)tid];
 	};
 	auto vote = [&](const uint32_t (&e)[kVoteUnroll]) {
 #pragma unroll
-		for (int u = 0; u < kVoteUnroll; ++u) {
-			const uint32_t xy = e[u];
-			if (xy == 0xffffffffu) continue;
-			const int x = (int)(xy & 0xffffu), y = (int)(xy >> 16);
-#pragma unroll
-			for (int k = 0; k < kShtThetaPerGroup; ++k) {
-				const uint32_t v = (uint32_t)(__mul24(x, ncq[k]) + (__mul24(y, nsq[k]) + K));
-				if constexpr (SC) {
-					uint32_t off;
-					asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(off) : "v"(offMask), "v"(v));
-					asm volatile("ds_add_u32 %0, %1" : : "v"(off), "v"(inc[k]) : "memory");
-				}
-				else atomicAdd(&hist[(k >> 1) * Rp + (v >> 16)], inc[k]);
-			}
-		}
+		for (int u = 0; u < kVoteUnroll; ++u) voteEdge(e[u]);
 	};
-	// wave w of nw owns the 64-edge chunks w, w+nw, w+2nw, ...; kVoteUnroll of them are voted while the next kVoteUnroll load
-	const int kStep = kVoteUnroll * nthreads;
-	uint32_t cur[kVoteUnroll], nxt[kVoteUnroll];
-	int j0 = wave * 64 + lane;
-	fetch(j0, cur);
-	for (; j0 - lane < cnt; j0 += kStep) { // uniform per wave
-		fetch(j0 + kStep, nxt);
-		vote(cur);
-#pragma unroll
-		for (int u = 0; u < kVoteUnroll; ++u) cur[u] = nxt[u];
+	uint32_t ra[kVoteUnroll], rb[kVoteUnroll];
+	uint32_t it = 0;
+	if (full > 0) fetch(0, ra);
+	for (; it + 1 < full; it += 2) {
+		fetch(it + 1, rb);
+		vote(ra);
+		if (it + 2 < full) fetch(it + 2, ra);
+		vote(rb);
 	}
+	if (it < full) vote(ra);
+	// tail: fewer than one step left
+	for (int j = (int)(full * step) + tid; j < cnt; j += nthreads) voteEdge(edges[j]);
 	if constexpr (SC) __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): the asm ds_add are invisible to the compiler's counters
 	__syncthreads();
 
