@@ -429,3 +429,118 @@ int orc_sht(const uint8_t* edges, size_t W, size_t H, size_t S, float thetaDeg, 
 	free(sinQ); free(cosQ); free(acc);
 	return err;
 }
+
+/* ================================================================================================================
+ * Caller-side pre-processing.  Restates:
+ *   CompVImageConvToGrayscale::process            base/image/compv_image_conv_to_grayscale.cxx:35-90
+ *   rgb24family_to_y_C / rgb32family_to_y_C       base/image/compv_image_conv_rgbfamily.cxx:93-117, 243-268
+ *   rgb565family_to_y (macro)                     base/image/compv_image_conv_rgbfamily.cxx:403-426
+ *   coefficient tables (RY,GY,BY = 33,65,13)      base/image/compv_image_conv_common.cxx:29-135
+ *   yuyv422_to_y_C / uyvy422_to_y_c               base/image/compv_image_conv_to_grayscale.cxx:233-282
+ *   CompVImageThreshold::otsu                     base/image/compv_image_threshold.cxx:52-114
+ * ================================================================================================================ */
+int orc_fmt_bytes(int fmt)
+{
+	switch (fmt) {
+	case ORC_FMT_RGBA32: case ORC_FMT_ARGB32: case ORC_FMT_BGRA32: return 4;
+	case ORC_FMT_RGB24: case ORC_FMT_BGR24: return 3;
+	case ORC_FMT_RGB565LE: case ORC_FMT_RGB565BE: case ORC_FMT_BGR565LE: case ORC_FMT_BGR565BE: return 2;
+	case ORC_FMT_YUYV422: case ORC_FMT_UYVY422: return 2;
+	case ORC_FMT_Y: return 1;
+	default: return 0;
+	}
+}
+
+static uint8_t orc_luma(int c0, int c1, int c2, int a, int b, int c)
+{
+	/* Y = ((c0*a + c1*b + c2*c) >> 7) + 16, clampPixel8 (never clamps: max 237) */
+	int v = ((c0 * a + c1 * b + c2 * c) >> 7) + 16;
+	return (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+}
+
+int orc_grayscale(const uint8_t* in, int fmt, size_t W, size_t H, size_t S, uint8_t* out, size_t So)
+{
+	const int bpp = orc_fmt_bytes(fmt);
+	if (!bpp || !in || !out || S < W || So < W) return -1;
+	const int RY = 33, GY = 65, BY = 13;
+	for (size_t j = 0; j < H; ++j) {
+		const uint8_t* p = in + j * S * (size_t)bpp;
+		uint8_t* o = out + j * So;
+		for (size_t i = 0; i < W; ++i, p += bpp) {
+			switch (fmt) {
+			case ORC_FMT_RGBA32: o[i] = orc_luma(RY, GY, BY, p[0], p[1], p[2]); break;
+			case ORC_FMT_ARGB32: o[i] = orc_luma(RY, GY, BY, p[1], p[2], p[3]); break;
+			case ORC_FMT_BGRA32: o[i] = orc_luma(BY, GY, RY, p[0], p[1], p[2]); break;
+			case ORC_FMT_RGB24: o[i] = orc_luma(RY, GY, BY, p[0], p[1], p[2]); break;
+			case ORC_FMT_BGR24: o[i] = orc_luma(BY, GY, RY, p[0], p[1], p[2]); break;
+			case ORC_FMT_RGB565LE: case ORC_FMT_RGB565BE: case ORC_FMT_BGR565LE: case ORC_FMT_BGR565BE: {
+				const int be = (fmt == ORC_FMT_RGB565BE || fmt == ORC_FMT_BGR565BE);
+				const int bgr = (fmt == ORC_FMT_BGR565LE || fmt == ORC_FMT_BGR565BE);
+				/* the sample is read as a native (little-endian) u16; big-endian input is byte-swapped first */
+				uint16_t k = (uint16_t)(p[0] | (p[1] << 8));
+				if (be) k = (uint16_t)((k << 8) | (k >> 8));
+				uint16_t r = (uint16_t)((k & 0xF800) >> 8); r |= (uint16_t)(r >> 5);
+				uint16_t g = (uint16_t)((k & 0x07E0) >> 3); g |= (uint16_t)(g >> 6);
+				uint16_t b = (uint16_t)((k & 0x001F) << 3); b |= (uint16_t)(b >> 5);
+				o[i] = bgr ? orc_luma(BY, GY, RY, r, g, b) : orc_luma(RY, GY, BY, r, g, b);
+				break;
+			}
+			case ORC_FMT_YUYV422: o[i] = p[0]; break;
+			case ORC_FMT_UYVY422: o[i] = p[1]; break;
+			default: o[i] = p[0]; break;
+			}
+		}
+	}
+	return 0;
+}
+
+void orc_hist256(const uint8_t* in, size_t W, size_t H, size_t S, uint32_t* hist)
+{
+	memset(hist, 0, 256 * sizeof(uint32_t));
+	for (size_t j = 0; j < H; ++j)
+		for (size_t i = 0; i < W; ++i) hist[in[j * S + i]]++;
+}
+
+int orc_otsu_from_hist(const uint32_t* hist, size_t Npx)
+{
+	/* compv_image_threshold.cxx:64-105: u32 sums (wrap like the reference), f32 arithmetic in source order */
+	uint32_t sumA256[256], sum32 = 0;
+	for (int i = 0; i < 256; ++i) { sumA256[i] = (uint32_t)i * hist[i]; sum32 += sumA256[i]; }
+	const float sumf = (float)sum32;
+	const int N = (int)Npx;
+	float sumB = 0.f, varMax = 0.f;
+	int q1 = 0, q2 = 0, thr = 0;
+	for (int i = 0; i < 256; ++i) {
+		q1 += (int)hist[i];
+		if (q1) {
+			q2 = N - q1;
+			if (!q2) break;
+			const float q1f = (float)q1, q2f = (float)q2;
+			sumB += (float)sumA256[i];
+			const float mf = (sumB / q1f) - ((sumf - sumB) / q2f);
+			const float varB = q1f * q2f * mf * mf;
+			if (varB > varMax) { varMax = varB; thr = i; }
+		}
+	}
+	return thr;
+}
+
+int orc_otsu(const uint8_t* in, size_t W, size_t H, size_t S)
+{
+	uint32_t hist[256];
+	orc_hist256(in, W, H, S, hist);
+	return orc_otsu_from_hist(hist, W * H);
+}
+
+void orc_otsu_canny_thresholds(int t, float fLowFactor, float fHighFactor, int* tLow, int* tHigh)
+{
+	/* samples/hough_lines/main.cxx:104-105: setFloat32(LOW, static_cast<float>(threshold * 0.5)), HIGH = static_cast<float>(threshold) */
+	const float fLow = (float)((double)t * (double)fLowFactor);
+	const float fHigh = (float)((double)t * (double)fHighFactor);
+	uint16_t lo = 1, hi = 3;
+	/* t == 0 (or factors that give LOW >= HIGH): the reference's set() rejects a threshold <= 0 (canny_dete.cxx:86-99) and
+	 * process() rejects tLow >= tHigh (:126) -- the sample then skips the frame.  A batched device path cannot skip: it uses the
+	 * smallest legal pair (1,3) and reports the Otsu value so the caller can tell. */
+	if (fLow > 0.f && fHigh > 0.f && fLow < fHigh) orc_canny_thresholds(fLow, fHigh, 0, 0, 1, 1, &lo, &hi);
+	*tLow = lo; *tHigh = hi;
+}

@@ -58,6 +58,23 @@ int orc_sht_lines(const int32_t* acc, size_t R, size_t T, size_t accStride, int3
 int orc_sht(const uint8_t* edges, size_t W, size_t H, size_t S, float thetaDeg, int32_t threshold, int maxLines,
             orc_line* lines, size_t cap, size_t* n);
 
+/* ---- caller-side pre-processing of the samples (samples/hough_lines/main.cxx:102-105) ---- */
+/* Pixel formats, numbered as compvhip_pixfmt in include/compv_hip.h. */
+enum { ORC_FMT_RGBA32 = 0, ORC_FMT_ARGB32, ORC_FMT_BGRA32, ORC_FMT_RGB24, ORC_FMT_BGR24, ORC_FMT_RGB565LE, ORC_FMT_RGB565BE,
+       ORC_FMT_BGR565LE, ORC_FMT_BGR565BE, ORC_FMT_YUYV422, ORC_FMT_UYVY422, ORC_FMT_Y, ORC_FMT_COUNT };
+/* bytes per sample (pixel) of a packed format, 0 if invalid */
+int orc_fmt_bytes(int fmt);
+/* CompVImage::convertGrayscale: in = H rows of S samples (S * orc_fmt_bytes bytes per row), out = H rows at stride So. */
+int orc_grayscale(const uint8_t* in, int fmt, size_t W, size_t H, size_t S, uint8_t* out, size_t So);
+/* CompVMathHistogram::build on a u8 plane (cols only). */
+void orc_hist256(const uint8_t* in, size_t W, size_t H, size_t S, uint32_t* hist);
+/* CompVImageThreshold::otsu from a histogram / from an image; N = W*H. Returns the threshold 0..255. */
+int orc_otsu_from_hist(const uint32_t* hist, size_t N);
+int orc_otsu(const uint8_t* in, size_t W, size_t H, size_t S);
+/* thresholds the sample derives from the Otsu value t for Canny: LOW = (float)(t*0.5), HIGH = (float)t, then the
+ * COMPARE_TO_GRADIENT rule of orc_canny_thresholds. */
+void orc_otsu_canny_thresholds(int t, float fLowFactor, float fHighFactor, int* tLow, int* tHigh);
+
 #ifdef __cplusplus
 }
 #endif

@@ -234,4 +234,31 @@ double refshim_bench_pipeline(const uint8_t* in, size_t W, size_t H, size_t S, s
 	return t1 - t0;
 }
 
+// CompVImage::convertGrayscale (samples/hough_lines/main.cxx:102). fmt: index into the table below (the numbering of
+// include/compv_hip.h, compvhip_pixfmt). in: H rows of S samples (S*bpp bytes per row). out: H rows of W bytes at stride So.
+int refshim_grayscale(const uint8_t* in, int fmt, size_t W, size_t H, size_t S, uint8_t* out, size_t So)
+{
+	static const COMPV_SUBTYPE kFmt[] = {
+		COMPV_SUBTYPE_PIXELS_RGBA32, COMPV_SUBTYPE_PIXELS_ARGB32, COMPV_SUBTYPE_PIXELS_BGRA32, COMPV_SUBTYPE_PIXELS_RGB24, COMPV_SUBTYPE_PIXELS_BGR24,
+		COMPV_SUBTYPE_PIXELS_RGB565LE, COMPV_SUBTYPE_PIXELS_RGB565BE, COMPV_SUBTYPE_PIXELS_BGR565LE, COMPV_SUBTYPE_PIXELS_BGR565BE,
+		COMPV_SUBTYPE_PIXELS_YUYV422, COMPV_SUBTYPE_PIXELS_UYVY422, COMPV_SUBTYPE_PIXELS_Y };
+	if (fmt < 0 || fmt >= (int)(sizeof(kFmt) / sizeof(kFmt[0]))) return -1;
+	CompVMatPtr img, gray;
+	if (COMPV_ERROR_CODE_IS_NOK(CompVImage::wrap(kFmt[fmt], in, W, H, S, &img))) return -2;
+	if (COMPV_ERROR_CODE_IS_NOK(CompVImage::convertGrayscale(img, &gray))) return -3;
+	fromMat(gray, out, So);
+	return 0;
+}
+
+// CompVImage::thresholdOtsu (samples/hough_lines/main.cxx:103)
+int refshim_otsu(const uint8_t* in, size_t W, size_t H, size_t S, double* threshold)
+{
+	CompVMatPtr img;
+	if (COMPV_ERROR_CODE_IS_NOK(toMat(in, W, H, S, &img))) return -1;
+	double t = 0.0;
+	if (COMPV_ERROR_CODE_IS_NOK(CompVImage::thresholdOtsu(img, t))) return -3;
+	*threshold = t;
+	return 0;
+}
+
 } // extern "C"

@@ -117,6 +117,44 @@ class Oracle:
         self.lib.orc_synth_frame(_p(out), W, H, W, seed)
         return out
 
+    # ---- caller-side pre-processing ----
+    def fmt_bytes(self, fmt):
+        return self.lib.orc_fmt_bytes(fmt)
+
+    def grayscale(self, packed, fmt, W):
+        """packed: (H, S*bpp) uint8 rows of S samples; returns (H, W) luma."""
+        H = packed.shape[0]
+        bpp = self.fmt_bytes(fmt)
+        S = packed.shape[1] // bpp
+        out = np.zeros((H, W), np.uint8)
+        L = self.lib
+        L.orc_grayscale.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t]
+        assert L.orc_grayscale(_p(packed), fmt, W, H, S, _p(out), W) == 0
+        return out
+
+    def hist256(self, img):
+        H, W = img.shape
+        h = np.zeros(256, np.uint32)
+        L = self.lib
+        L.orc_hist256.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p]
+        L.orc_hist256.restype = None
+        L.orc_hist256(_p(img), W, H, img.strides[0], _p(h))
+        return h
+
+    def otsu(self, img):
+        H, W = img.shape
+        L = self.lib
+        L.orc_otsu.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t]
+        return L.orc_otsu(_p(img), W, H, img.strides[0])
+
+    def otsu_canny_thresholds(self, t, flow=0.5, fhigh=1.0):
+        L = self.lib
+        L.orc_otsu_canny_thresholds.argtypes = [C.c_int, C.c_float, C.c_float, C.c_void_p, C.c_void_p]
+        L.orc_otsu_canny_thresholds.restype = None
+        lo = C.c_int(0); hi = C.c_int(0)
+        L.orc_otsu_canny_thresholds(t, flow, fhigh, C.byref(lo), C.byref(hi))
+        return lo.value, hi.value
+
     def convlt_8u(self, img, vt, hz):
         H, W = img.shape
         vt = np.ascontiguousarray(vt, np.int16); hz = np.ascontiguousarray(hz, np.int16)
@@ -233,6 +271,24 @@ class RefShim:
     def reinit(self, threads):
         assert self.lib.refshim_init(threads) == 0
         self.threads = self.lib.refshim_threads()
+
+    def grayscale(self, packed, fmt, W, bpp):
+        H = packed.shape[0]
+        S = packed.shape[1] // bpp
+        out = np.zeros((H, W), np.uint8)
+        L = self.lib
+        L.refshim_grayscale.argtypes = [C.c_void_p, C.c_int, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t]
+        r = L.refshim_grayscale(_p(packed), fmt, W, H, S, _p(out), W)
+        assert r == 0, r
+        return out
+
+    def otsu(self, img):
+        H, W = img.shape
+        L = self.lib
+        L.refshim_otsu.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p]
+        t = C.c_double(0)
+        assert L.refshim_otsu(_p(img), W, H, img.strides[0], C.byref(t)) == 0
+        return t.value
 
     def sobel(self, img):
         H, W = img.shape
