@@ -23,7 +23,10 @@ E_OUT_OF_BOUND = -6
 E_HIP = -7
 
 OP_SOBEL, OP_SCHARR, OP_PREWITT = 0, 2, 3
-THRESHOLD_COMPARE_TO_GRADIENT, THRESHOLD_PERCENT_OF_MEAN = 0, 1
+THRESHOLD_COMPARE_TO_GRADIENT, THRESHOLD_PERCENT_OF_MEAN, THRESHOLD_OTSU = 0, 1, 2
+(FMT_RGBA32, FMT_ARGB32, FMT_BGRA32, FMT_RGB24, FMT_BGR24, FMT_RGB565LE, FMT_RGB565BE, FMT_BGR565LE, FMT_BGR565BE,
+ FMT_YUYV422, FMT_UYVY422, FMT_Y) = range(12)
+FMT_BYTES = [4, 4, 4, 3, 3, 2, 2, 2, 2, 2, 2, 1]
 
 # every symbol include/compv_hip.h declares (checked by tests/test_abi.py)
 EXPORTS = [
@@ -32,7 +35,7 @@ EXPORTS = [
     "compvhip_houghsht_dims", "compvhip_plan_create", "compvhip_plan_destroy", "compvhip_plan_canny",
     "compvhip_plan_houghsht", "compvhip_plan_pipeline", "compvhip_plan_acc", "compvhip_plan_edge_counts",
     "compvhip_plan_set_timing", "compvhip_plan_get_timing", "compvhip_plan_acc_export", "compvhip_plan_edge_dete",
-    "compvhip_houghkht_u8",
+    "compvhip_houghkht_u8", "compvhip_grayscale_u8", "compvhip_otsu_u8", "compvhip_plan_grayscale", "compvhip_plan_otsu",
 ]
 
 
@@ -97,6 +100,10 @@ def load():
     L.compvhip_plan_canny.argtypes = [vp, vp, C.c_float, C.c_float, i32, i32, vp, vp]
     L.compvhip_plan_houghsht.argtypes = [vp, vp, i32, i32, vp, sz, vp, vp]
     L.compvhip_plan_edge_dete.argtypes = [vp, vp, i32, vp, vp]
+    L.compvhip_grayscale_u8.argtypes = [vp, vp, i32, sz, sz, sz, vp, sz]
+    L.compvhip_otsu_u8.argtypes = [vp, vp, sz, sz, sz, C.POINTER(C.c_double)]
+    L.compvhip_plan_grayscale.argtypes = [vp, vp, i32, vp, vp]
+    L.compvhip_plan_otsu.argtypes = [vp, vp, vp, vp]
     L.compvhip_plan_pipeline.argtypes = [vp, vp, C.c_float, C.c_float, i32, i32, vp, vp, sz, vp, vp]
     L.compvhip_plan_acc.argtypes = [vp, sz, C.POINTER(vp), C.POINTER(sz), C.POINTER(sz), C.POINTER(sz)]
     L.compvhip_plan_acc_export.argtypes = [vp, sz, vp, sz, vp]
@@ -149,6 +156,22 @@ class Context:
         out = np.empty((H, W), np.uint8)
         self._chk(self.lib.compvhip_edge_dete_u8(self.h, _ptr(img), W, H, img.strides[0], op, _ptr(out), W))
         return out
+
+    def grayscale(self, packed, pixfmt, W):
+        """packed: (H, S*bpp) uint8 array, rows of S samples; returns the (H, W) luma plane (CompVImage::convertGrayscale)."""
+        H = packed.shape[0]
+        bpp = FMT_BYTES[pixfmt]
+        S = packed.strides[0] // bpp
+        out = np.empty((H, W), np.uint8)
+        self._chk(self.lib.compvhip_grayscale_u8(self.h, _ptr(packed), pixfmt, W, H, S, _ptr(out), W))
+        return out
+
+    def otsu(self, img):
+        """CompVImage::thresholdOtsu: the Otsu level (a double holding an integer, like the reference)."""
+        H, W = img.shape
+        t = C.c_double(0)
+        self._chk(self.lib.compvhip_otsu_u8(self.h, _ptr(img), W, H, img.strides[0], C.byref(t)))
+        return t.value
 
     def canny(self, img, tLow, tHigh, ksize=3, threshold_type=THRESHOLD_COMPARE_TO_GRADIENT, out=None):
         H, W = img.shape
@@ -224,6 +247,12 @@ class Plan:
 
     def edge_dete(self, d_in, op, d_out, stream=0):
         self.ctx._chk(self.lib.compvhip_plan_edge_dete(self.h, d_in, op, d_out, stream))
+
+    def grayscale(self, d_in, pixfmt, d_gray, stream=0):
+        self.ctx._chk(self.lib.compvhip_plan_grayscale(self.h, d_in, pixfmt, d_gray, stream))
+
+    def otsu(self, d_gray, d_thresholds, stream=0):
+        self.ctx._chk(self.lib.compvhip_plan_otsu(self.h, d_gray, d_thresholds, stream))
 
     def houghsht(self, d_edges, threshold, max_lines, d_lines, line_cap, d_counts, stream=0):
         self.ctx._chk(self.lib.compvhip_plan_houghsht(self.h, d_edges, threshold, max_lines, d_lines, line_cap, d_counts, stream))

@@ -36,6 +36,8 @@ struct compvhip_ctx {
 	uint8_t* dIn = nullptr;            // device staging of the host entry points
 	uint8_t* dOut = nullptr;
 	size_t dInBytes = 0, dOutBytes = 0;
+	uint8_t* dPacked = nullptr; size_t dPackedBytes = 0; // packed-pixel staging of compvhip_grayscale_u8
+	uint32_t* dHist = nullptr;                             // [256] histogram + 1 result word of compvhip_otsu_u8
 	compvhip_line* dLines = nullptr; size_t dLinesCap = 0;
 	int32_t* dCounts = nullptr;
 	int32_t* dAccOut = nullptr; size_t dAccOutElems = 0;
@@ -64,6 +66,7 @@ struct compvhip_plan {
 	// sht
 	bool shtReady = false;
 	size_t R = 0, T = 0; float thetaStep = 0.f; int accPitch = 0;
+	uint32_t* hist = nullptr; int32_t* otsu = nullptr; // pre-processing scratch: partial histograms, [frames] Otsu level
 	int32_t* sinQ = nullptr; int32_t* cosQ = nullptr; int32_t* groupOrder = nullptr; int thetaPerGroup = 4;
 	uint32_t* edges = nullptr; size_t edgeCap = 0; int* edgeCounts = nullptr;
 	uint16_t* acc = nullptr; size_t accFrameStride = 0;
@@ -312,18 +315,33 @@ ShtArgs shtArgs(compvhip_plan* p, int threshold)
 }
 
 // Enqueue canny tiles + `rounds` speculative resolve rounds starting at p->roundsUsed.
-int enqueueCanny(compvhip_plan* p, const uint8_t* d_in, uint8_t* d_out, int tLow, int tHigh, int ksize, bool meanMode, float fLow, float fHigh, hipStream_t st)
+int ensurePreproc(compvhip_plan* p)
+{
+	compvhip_ctx* ctx = p->ctx;
+	if (!p->hist) HIPCHK(ctx, dmalloc(ctx, &p->hist, static_cast<size_t>(256) * kOtsuMaxChunks * p->frames));
+	if (!p->otsu) HIPCHK(ctx, dmalloc(ctx, &p->otsu, p->frames));
+	return COMPVHIP_OK;
+}
+
+// thrMode: COMPVHIP_CANNY_THRESHOLD_* (per-frame device thresholds for PERCENT_OF_MEAN and OTSU)
+int enqueueCanny(compvhip_plan* p, const uint8_t* d_in, uint8_t* d_out, int tLow, int tHigh, int ksize, int thrMode, float fLow, float fHigh, hipStream_t st)
 {
 	compvhip_ctx* ctx = p->ctx;
 	CannyArgs a;
-	a.in = d_in; a.out = d_out; a.ebits = p->ebits; a.ubits = p->ubits; a.thrDev = meanMode ? p->thrDev : nullptr;
+	a.in = d_in; a.out = d_out; a.ebits = p->ebits; a.ubits = p->ubits; a.thrDev = (thrMode != COMPVHIP_CANNY_THRESHOLD_COMPARE_TO_GRADIENT) ? p->thrDev : nullptr;
 	a.inFrameStride = p->S * p->H; a.outFrameStride = p->S * p->H; a.bitsFrameStride = p->bitsFrameStride;
 	a.W = static_cast<int>(p->W); a.H = static_cast<int>(p->H); a.S = static_cast<int>(p->S); a.So = static_cast<int>(p->S);
 	a.wb = p->wb; a.tilesX = p->tilesX; a.tilesY = p->tilesY; a.tLow = tLow; a.tHigh = tHigh; a.ksize = ksize;
 	cannyCoverage(p->W, &a.simdEnd, &a.cStart);
 	// coverage [1,simdEnd) U [cStart,W-1) equals the whole interior unless the two pieces leave a hole (W = 1 mod 16 ...)
 	const bool gap = !((a.simdEnd >= a.W - 1) || (a.cStart <= a.simdEnd));
-	if (meanMode) {
+	if (thrMode == COMPVHIP_CANNY_THRESHOLD_OTSU) {
+		int rc = ensurePreproc(p);
+		if (rc) return rc;
+		Stamp s(p, st, "otsu_kernels");
+		HIPCHK(ctx, launch_otsu(d_in, a.W, a.H, a.S, a.inFrameStride, static_cast<int>(p->frames), fLow, fHigh, p->hist, p->otsu, p->thrDev, st));
+	}
+	if (thrMode == COMPVHIP_CANNY_THRESHOLD_PERCENT_OF_MEAN) {
 		Stamp s(p, st, "canny_mean_thresholds");
 		HIPCHK(ctx, launch_mean_thresholds(d_in, a.W, a.H, a.S, a.inFrameStride, static_cast<int>(p->frames), fLow, fHigh, p->sums, p->thrDev, st));
 	}
@@ -366,8 +384,9 @@ int resolveConverged(compvhip_plan* p, hipStream_t st, bool* done)
 int validateCannyParams(compvhip_ctx* ctx, float tLow, float tHigh, int ksize, int type, int* lo, int* hi)
 {
 	if (ksize != 3 && ksize != 5) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "kernel size must be 3 or 5"); // canny_dete.cxx:101
-	if (type != COMPVHIP_CANNY_THRESHOLD_COMPARE_TO_GRADIENT && type != COMPVHIP_CANNY_THRESHOLD_PERCENT_OF_MEAN)
+	if (type != COMPVHIP_CANNY_THRESHOLD_COMPARE_TO_GRADIENT && type != COMPVHIP_CANNY_THRESHOLD_PERCENT_OF_MEAN && type != COMPVHIP_CANNY_THRESHOLD_OTSU)
 		return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "invalid threshold type"); // :83
+	if (type == COMPVHIP_CANNY_THRESHOLD_OTSU && !(tLow > 0.f)) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "Otsu threshold factors must be > 0");
 	if (tLow >= tHigh) return fail(ctx, COMPVHIP_E_INVALID_STATE, "tLow >= tHigh"); // :126
 	*lo = 0; *hi = 0;
 	if (type == COMPVHIP_CANNY_THRESHOLD_COMPARE_TO_GRADIENT) {
@@ -376,6 +395,7 @@ int validateCannyParams(compvhip_ctx* ctx, float tLow, float tHigh, int ksize, i
 		// artefact regime (g <= 24480) that this implementation rejects instead of reproducing
 		if (*hi > 32767) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "thresholds above 32767 are not supported");
 	}
+	else if (type == COMPVHIP_CANNY_THRESHOLD_OTSU) { if (!(tHigh * 255.f < 32767.f)) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "thresholds above 32767 are not supported"); }
 	else if (!(tHigh * 255.f < 32767.f)) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "thresholds above 32767 are not supported");
 	return COMPVHIP_OK;
 }
@@ -414,6 +434,7 @@ void compvhip_ctx_destroy(compvhip_ctx* ctx)
 	if (!ctx) return;
 	(void)hipSetDevice(ctx->device);
 	if (ctx->hostPlan) compvhip_plan_destroy(ctx->hostPlan);
+	dfree(ctx, ctx->dPacked); dfree(ctx, ctx->dHist);
 	dfree(ctx, ctx->dIn); dfree(ctx, ctx->dOut); dfree(ctx, ctx->dLines); dfree(ctx, ctx->dCounts); dfree(ctx, ctx->dAccOut);
 	dfree(ctx, ctx->khtCounts); dfree(ctx, ctx->khtParams); dfree(ctx, ctx->khtCells); dfree(ctx, ctx->khtCellCount);
 	if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -469,6 +490,7 @@ void compvhip_plan_destroy(compvhip_plan* p)
 	for (hipEvent_t e : p->eventPool) (void)hipEventDestroy(e);
 	dfree(ctx, p->ebits); dfree(ctx, p->ubits); dfree(ctx, p->flags); dfree(ctx, p->thrDev); dfree(ctx, p->sums); dfree(ctx, p->tmpOut);
 	if (p->hFlags) (void)hipHostFree(p->hFlags);
+	dfree(ctx, p->hist); dfree(ctx, p->otsu);
 	dfree(ctx, p->sinQ); dfree(ctx, p->cosQ); dfree(ctx, p->groupOrder); dfree(ctx, p->edges); dfree(ctx, p->edgeCounts); dfree(ctx, p->acc);
 	dfree(ctx, p->keysA); dfree(ctx, p->keysB); dfree(ctx, p->lineCounts);
 	dfree(ctx, p->sortTemp);
@@ -510,8 +532,7 @@ static int planCannyImpl(compvhip_plan* p, const uint8_t* d_in, float tLow, floa
 		out = p->tmpOut;
 	}
 	if (p->W < static_cast<size_t>(ksize) || p->H < static_cast<size_t>(ksize)) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "image smaller than the kernel"); // compv_math_convlt.h:100
-	const bool mean = (type == COMPVHIP_CANNY_THRESHOLD_PERCENT_OF_MEAN);
-	rc = enqueueCanny(p, d_in, out, lo, hi, ksize, mean, tLow, tHigh, st);
+	rc = enqueueCanny(p, d_in, out, lo, hi, ksize, type, tLow, tHigh, st);
 	if (rc) return rc;
 	rc = enqueueResolve(p, out, kSpecRounds, st);
 	if (rc) return rc;
@@ -534,6 +555,46 @@ int compvhip_plan_canny(compvhip_plan* p, const uint8_t* d_in, float tLow, float
 {
 	if (!p) return COMPVHIP_E_INVALID_PARAMETER;
 	return planCannyImpl(p, d_in, tLow, tHigh, ksize, type, d_edges, static_cast<hipStream_t>(stream), true);
+}
+
+static int pixfmtBytes(int fmt)
+{
+	if (fmt < COMPVHIP_FMT_RGBA32 || fmt > COMPVHIP_FMT_Y) return 0;
+	return fmt <= COMPVHIP_FMT_BGRA32 ? 4 : (fmt <= COMPVHIP_FMT_BGR24 ? 3 : (fmt == COMPVHIP_FMT_Y ? 1 : 2));
+}
+
+int compvhip_plan_grayscale(compvhip_plan* p, const uint8_t* d_in, int pixfmt, uint8_t* d_gray, void* stream)
+{
+	if (!p) return COMPVHIP_E_INVALID_PARAMETER;
+	compvhip_ctx* ctx = p->ctx;
+	if (!d_in || !d_gray) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "null frame pointer");
+	if (!pixfmtBytes(pixfmt)) return fail(ctx, COMPVHIP_E_NOT_IMPLEMENTED, "pixel format without a grayscale conversion"); // conv_to_grayscale.cxx:86-88
+	if ((pixfmt == COMPVHIP_FMT_YUYV422 || pixfmt == COMPVHIP_FMT_UYVY422) && (p->W & 1))
+		return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "packed 4:2:2 needs an even width");
+	HIPCHK(ctx, hipSetDevice(ctx->device));
+	hipStream_t st = static_cast<hipStream_t>(stream);
+	if (p->timing) timelineClear(p);
+	GrayArgs a;
+	a.in = d_in; a.out = d_gray; a.W = static_cast<int>(p->W); a.H = static_cast<int>(p->H); a.S = static_cast<int>(p->S); a.So = static_cast<int>(p->S);
+	Stamp s(p, st, "gray_kernel");
+	HIPCHK(ctx, launch_gray(a, pixfmt, static_cast<int>(p->frames), st));
+	return COMPVHIP_OK;
+}
+
+int compvhip_plan_otsu(compvhip_plan* p, const uint8_t* d_gray, int32_t* d_thresholds, void* stream)
+{
+	if (!p) return COMPVHIP_E_INVALID_PARAMETER;
+	compvhip_ctx* ctx = p->ctx;
+	if (!d_gray || !d_thresholds) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "null pointer");
+	HIPCHK(ctx, hipSetDevice(ctx->device));
+	int rc = ensurePreproc(p);
+	if (rc) return rc;
+	hipStream_t st = static_cast<hipStream_t>(stream);
+	if (p->timing) timelineClear(p);
+	Stamp s(p, st, "otsu_kernels");
+	HIPCHK(ctx, launch_otsu(d_gray, static_cast<int>(p->W), static_cast<int>(p->H), static_cast<int>(p->S), p->S * p->H, static_cast<int>(p->frames), 0.5f, 1.f,
+	                        p->hist, d_thresholds, nullptr, st));
+	return COMPVHIP_OK;
 }
 
 int compvhip_plan_edge_dete(compvhip_plan* p, const uint8_t* d_in, int op, uint8_t* d_out, void* stream)
@@ -725,6 +786,46 @@ int compvhip_edge_dete_u8(compvhip_ctx* ctx, const uint8_t* in, size_t W, size_t
 	HIPCHK(ctx, launch_edge_dete(a, op, 1, ctx->stream));
 	HIPCHK(ctx, hipMemcpy2DAsync(out, So, ctx->dOut, p->S, W, H, hipMemcpyDeviceToHost, ctx->stream));
 	HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+	return COMPVHIP_OK;
+}
+
+int compvhip_grayscale_u8(compvhip_ctx* ctx, const uint8_t* in, int pixfmt, size_t W, size_t H, size_t S, uint8_t* out, size_t So)
+{
+	if (!ctx) return COMPVHIP_E_INVALID_PARAMETER;
+	if (!in || !out || S < W || So < W || !W || !H || W > 32767 || H > 32767) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "null image, stride < width or size out of range");
+	const int bpp = pixfmtBytes(pixfmt);
+	if (!bpp) return fail(ctx, COMPVHIP_E_NOT_IMPLEMENTED, "pixel format without a grayscale conversion"); // conv_to_grayscale.cxx:86-88
+	if ((pixfmt == COMPVHIP_FMT_YUYV422 || pixfmt == COMPVHIP_FMT_UYVY422) && (W & 1)) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "packed 4:2:2 needs an even width");
+	HIPCHK(ctx, hipSetDevice(ctx->device));
+	const size_t Sd = alignUp(W, 64);
+	const size_t inBytes = Sd * H * bpp, outBytes = Sd * H;
+	if (ctx->dPackedBytes < inBytes) { dfree(ctx, ctx->dPacked); HIPCHK(ctx, dmalloc(ctx, &ctx->dPacked, inBytes)); ctx->dPackedBytes = inBytes; }
+	if (ctx->dOutBytes < outBytes) { dfree(ctx, ctx->dOut); HIPCHK(ctx, dmalloc(ctx, &ctx->dOut, outBytes)); ctx->dOutBytes = outBytes; }
+	HIPCHK(ctx, hipMemcpy2DAsync(ctx->dPacked, Sd * bpp, in, S * bpp, W * bpp, H, hipMemcpyHostToDevice, ctx->stream));
+	GrayArgs a;
+	a.in = ctx->dPacked; a.out = ctx->dOut; a.W = static_cast<int>(W); a.H = static_cast<int>(H); a.S = static_cast<int>(Sd); a.So = static_cast<int>(Sd);
+	HIPCHK(ctx, launch_gray(a, pixfmt, 1, ctx->stream));
+	HIPCHK(ctx, hipMemcpy2DAsync(out, So, ctx->dOut, Sd, W, H, hipMemcpyDeviceToHost, ctx->stream));
+	HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+	return COMPVHIP_OK;
+}
+
+int compvhip_otsu_u8(compvhip_ctx* ctx, const uint8_t* in, size_t W, size_t H, size_t S, double* threshold)
+{
+	if (!ctx) return COMPVHIP_E_INVALID_PARAMETER;
+	if (!in || !threshold || S < W || !W || !H || W > 32767 || H > 32767) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "null image, stride < width or size out of range"); // threshold.cxx:54
+	HIPCHK(ctx, hipSetDevice(ctx->device));
+	const size_t Sd = alignUp(W, 64);
+	const size_t bytes = Sd * H;
+	if (ctx->dInBytes < bytes) { dfree(ctx, ctx->dIn); HIPCHK(ctx, dmalloc(ctx, &ctx->dIn, bytes)); ctx->dInBytes = bytes; }
+	if (!ctx->dHist) HIPCHK(ctx, dmalloc(ctx, &ctx->dHist, static_cast<size_t>(256) * kOtsuMaxChunks + 1));
+	HIPCHK(ctx, hipMemcpy2DAsync(ctx->dIn, Sd, in, S, W, H, hipMemcpyHostToDevice, ctx->stream));
+	int32_t* dT = reinterpret_cast<int32_t*>(ctx->dHist + static_cast<size_t>(256) * kOtsuMaxChunks);
+	HIPCHK(ctx, launch_otsu(ctx->dIn, static_cast<int>(W), static_cast<int>(H), static_cast<int>(Sd), bytes, 1, 0.5f, 1.f, ctx->dHist, dT, nullptr, ctx->stream));
+	int32_t t = 0;
+	HIPCHK(ctx, hipMemcpyAsync(&t, dT, sizeof(t), hipMemcpyDeviceToHost, ctx->stream));
+	HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+	*threshold = static_cast<double>(t);
 	return COMPVHIP_OK;
 }
 

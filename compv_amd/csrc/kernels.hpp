@@ -4,6 +4,8 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include "../../include/compv_hip.h" // compvhip_pixfmt
+
 namespace compvhip {
 
 // ---- Canny ------------------------------------------------------------------------------------------------
@@ -54,6 +56,18 @@ struct EdgeDeteArgs {
 	int blockRows, groups;    // filled by the launcher (XCD-aware map)
 };
 hipError_t launch_edge_dete(const EdgeDeteArgs& a, int op, int frames, hipStream_t stream);
+
+// ---- pre-processing (grayscale, Otsu) -----------------------------------------------------------------------
+struct GrayArgs {
+	const uint8_t* in;        // [frames][H][S samples of bpp bytes]
+	uint8_t* out;             // [frames][H][So]
+	int W, H, S, So;
+};
+hipError_t launch_gray(const GrayArgs& a, int fmt, int frames, hipStream_t stream);
+constexpr int kOtsuMaxChunks = 128; // row chunks (= workgroups) per frame of the histogram kernel
+// hist: [frames][kOtsuMaxChunks][256] u32 scratch (partial histograms); otsu: int32 per frame (or null); thr: int2 {tLow,tHigh} per frame (or null)
+hipError_t launch_otsu(const uint8_t* in, int W, int H, int S, size_t frameStride, int frames, float fLowFactor, float fHighFactor, uint32_t* hist,
+                       int32_t* otsu, void* thr, hipStream_t stream);
 
 // ---- Hough SHT ---------------------------------------------------------------------------------------------
 constexpr int kShtVoteThreads = 1024;

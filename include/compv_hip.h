@@ -55,8 +55,18 @@ enum { /* gradient operator of the edge detector; ids mirror COMPV_SOBEL_ID / _S
 };
 enum { /* COMPV_CANNY_THRESHOLD_TYPE_* (compv_features.h:80-81) */
 	COMPVHIP_CANNY_THRESHOLD_COMPARE_TO_GRADIENT = 0,
-	COMPVHIP_CANNY_THRESHOLD_PERCENT_OF_MEAN = 1
+	COMPVHIP_CANNY_THRESHOLD_PERCENT_OF_MEAN = 1,
+	/* plan API only -- the sample's per-frame sequence fused on the device (samples/hough_lines/main.cxx:103-105):
+	 * t = thresholdOtsu(frame); LOW = (float)(t * tLow); HIGH = (float)(t * tHigh); then COMPARE_TO_GRADIENT.
+	 * The sample uses the factors tLow = 0.5, tHigh = 1.0. */
+	COMPVHIP_CANNY_THRESHOLD_OTSU = 2
 };
+typedef enum compvhip_pixfmt { /* packed input formats of CompVImage::convertGrayscale (COMPV_SUBTYPE_PIXELS_*, compv_common.h:347-367) */
+	COMPVHIP_FMT_RGBA32 = 0, COMPVHIP_FMT_ARGB32 = 1, COMPVHIP_FMT_BGRA32 = 2, COMPVHIP_FMT_RGB24 = 3, COMPVHIP_FMT_BGR24 = 4,
+	COMPVHIP_FMT_RGB565LE = 5, COMPVHIP_FMT_RGB565BE = 6, COMPVHIP_FMT_BGR565LE = 7, COMPVHIP_FMT_BGR565BE = 8,
+	COMPVHIP_FMT_YUYV422 = 9, COMPVHIP_FMT_UYVY422 = 10,
+	COMPVHIP_FMT_Y = 11 /* the Y plane of Y / NV12 / NV21 / YUV420P / YVU420P / YUV422P / YUV444P: a copy */
+} compvhip_pixfmt;
 
 /* One Hough line.  rho/theta/strength are CompVHoughLine's fields (compv_common.h:686-693); row/col are the
  * accumulator cell (rho = barrier - row, theta = col * thetaStepRad) and define the canonical tie order. */
@@ -94,6 +104,16 @@ COMPVHIP_API int compvhip_edge_dete_u8(compvhip_ctx* ctx, const uint8_t* in, siz
  * thresholdType COMPVHIP_CANNY_THRESHOLD_*.  out = {0,0xff}; in and out may alias (samples/edges_canny/main.cxx:72). */
 COMPVHIP_API int compvhip_canny_u8(compvhip_ctx* ctx, const uint8_t* in, size_t W, size_t H, size_t S,
                                    float tLow, float tHigh, int ksize, int thresholdType, uint8_t* out, size_t So);
+
+/* CompVImage::convertGrayscale (base/image/compv_image_conv_to_grayscale.cxx:35-90, called at samples/hough_lines/main.cxx:102):
+ * packed RGB-family / YUV 4:2:2 frame -> luma plane, Y = ((33 R + 65 G + 13 B) >> 7) + 16 (compv_image_conv_rgbfamily.cxx:108).
+ * in: H rows of S samples (S * bytes-per-sample bytes per row, S >= W as in CompVMat); out: H rows of W bytes at stride So. */
+COMPVHIP_API int compvhip_grayscale_u8(compvhip_ctx* ctx, const uint8_t* in, int pixfmt, size_t W, size_t H, size_t S,
+                                       uint8_t* out, size_t So);
+
+/* CompVImage::thresholdOtsu (base/image/compv_image_threshold.cxx:52-114, called at samples/hough_lines/main.cxx:103):
+ * 256-bin histogram of the W x H plane + the reference's f32 scan; *threshold = the integer level as a double. */
+COMPVHIP_API int compvhip_otsu_u8(compvhip_ctx* ctx, const uint8_t* in, size_t W, size_t H, size_t S, double* threshold);
 
 /* CompVHoughSht::process (core/features/hough/compv_core_feature_houghsht.cxx:96-262).  rho must be 1 (:306-316),
  * thetaDeg in degrees, threshold > 0 is the NMS/line threshold, maxLines <= 0 keeps every line.
@@ -135,6 +155,12 @@ COMPVHIP_API void compvhip_plan_destroy(compvhip_plan* plan);
  * (a hipStream_t; NULL = default stream) except for the hysteresis convergence check, which polls a device flag. */
 COMPVHIP_API int compvhip_plan_canny(compvhip_plan* plan, const uint8_t* d_in, float tLow, float tHigh, int ksize,
                                      int thresholdType, uint8_t* d_edges, void* stream);
+
+/* compvhip_grayscale_u8 on `frames` device frames: d_in = [frames][H][S samples], d_gray = [frames][H][S].  Asynchronous. */
+COMPVHIP_API int compvhip_plan_grayscale(compvhip_plan* plan, const uint8_t* d_in, int pixfmt, uint8_t* d_gray, void* stream);
+
+/* compvhip_otsu_u8 on `frames` device frames: d_thresholds[f] = Otsu level of frame f (device array).  Asynchronous. */
+COMPVHIP_API int compvhip_plan_otsu(compvhip_plan* plan, const uint8_t* d_gray, int32_t* d_thresholds, void* stream);
 
 /* Sobel / Scharr / Prewitt detector (compvhip_edge_dete_u8 semantics) on `frames` device frames; d_in and d_out must
  * not alias.  Fully asynchronous on `stream`. */

@@ -1,9 +1,19 @@
 """Oracle (oracle/compv_oracle.c) vs the compiled reference for the samples' caller-side pre-processing
 (SURVEY 8f row 1): CompVImage::convertGrayscale and CompVImage::thresholdOtsu (samples/hough_lines/main.cxx:102-105)."""
+import hashlib
+import json
+import os
+import sys
+
 import numpy as np
 import pytest
 
 from oracle_bindings import synth_frame
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+from make_golden_preproc import otsu_input, packed_input  # noqa: E402  (input generators only; no reference needed)
+
+GOLDEN_PREPROC = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_preproc.json")))
 
 FMT_NAMES = ["RGBA32", "ARGB32", "BGRA32", "RGB24", "BGR24", "RGB565LE", "RGB565BE", "BGR565LE", "BGR565BE", "YUYV422", "UYVY422", "Y"]
 
@@ -54,3 +64,16 @@ def test_otsu_hist_and_canny_thresholds(oracle):
     assert oracle.otsu_canny_thresholds(0) == (1, 3)
     assert oracle.otsu_canny_thresholds(1) == (1, 3)
     assert oracle.otsu_canny_thresholds(255) == (127, 255)
+
+
+# ---- committed fixtures generated from the compiled reference (tests/golden/make_golden_preproc.py): these run on any box ----
+@pytest.mark.parametrize("case", GOLDEN_PREPROC["grayscale"], ids=lambda c: "%s_%dx%d" % (c["name"], c["W"], c["H"]))
+def test_grayscale_oracle_matches_golden(oracle, case):
+    data = packed_input(case["fmt"], case["W"], case["H"], case["S"], case["seed"])
+    g = oracle.grayscale(data, case["fmt"], case["W"])
+    assert hashlib.md5(np.ascontiguousarray(g).tobytes()).hexdigest() == case["md5"]
+
+
+@pytest.mark.parametrize("case", [c for c in GOLDEN_PREPROC["otsu"] if c["W"] <= 1920], ids=lambda c: "%s_%dx%d" % (c["kind"], c["W"], c["H"]))
+def test_otsu_oracle_matches_golden(oracle, case):
+    assert oracle.otsu(otsu_input(case["kind"], case["W"], case["H"], case["seed"])) == case["threshold"]
