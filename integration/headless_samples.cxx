@@ -28,6 +28,7 @@
 using namespace compv;
 
 extern "C" int compv_hip_plugin_register(void);
+#include "../include/compv_hip.h" // the pre-processing calls are static CompVImage functions, not factories: called through the C ABI
 
 // SURVEY.md 8(d) synthetic frame
 static void synthFrame(CompVMatPtr img, uint32_t seed)
@@ -147,6 +148,39 @@ static COMPV_ERROR_CODE runSamples(size_t W, size_t H, uint32_t seed, Result& r)
 	return COMPV_ERROR_CODE_S_OK;
 }
 
+// samples/hough_lines/main.cxx:102-105 on a packed RGB24 camera frame: convertGrayscale -> thresholdOtsu -> Canny thresholds.
+// CompVImage::convertGrayscale / thresholdOtsu are static functions (no factory to swap), so the HIP side is the C ABI a
+// maintainer would call from inside them: both results must be identical.
+static int checkPreproc(size_t W, size_t H, uint32_t seed)
+{
+	std::vector<uint8_t> rgb(W * H * 3);
+	uint32_t s = seed;
+	for (size_t j = 0; j < H; ++j)
+		for (size_t i = 0; i < W; ++i) {
+			s = s * 1664525u + 1013904223u;
+			const uint32_t v = 40u + ((((uint32_t)(i / 64) + (uint32_t)(j / 64)) & 1u) * 150u) + (s >> 28);
+			uint8_t* p = &rgb[(j * W + i) * 3];
+			p[0] = (uint8_t)v; p[1] = (uint8_t)(255u - v); p[2] = (uint8_t)((v * 3u) >> 2);
+		}
+	CompVMatPtr image, gray;
+	double tCpu = -1.0;
+	if (COMPV_ERROR_CODE_IS_NOK(CompVImage::wrap(COMPV_SUBTYPE_PIXELS_RGB24, rgb.data(), W, H, W, &image))) return 1;
+	if (COMPV_ERROR_CODE_IS_NOK(CompVImage::convertGrayscale(image, &gray))) return 1;
+	if (COMPV_ERROR_CODE_IS_NOK(CompVImage::thresholdOtsu(gray, tCpu))) return 1;
+	compvhip_ctx* ctx = nullptr;
+	if (compvhip_ctx_create(&ctx, -1) != COMPVHIP_OK) return 2;
+	std::vector<uint8_t> g(W * H);
+	double tHip = -2.0;
+	int rc = compvhip_grayscale_u8(ctx, rgb.data(), COMPVHIP_FMT_RGB24, W, H, W, g.data(), W);
+	if (rc == COMPVHIP_OK) rc = compvhip_otsu_u8(ctx, g.data(), W, H, W, &tHip);
+	compvhip_ctx_destroy(ctx);
+	if (rc != COMPVHIP_OK) return 2;
+	bool same = true;
+	for (size_t j = 0; j < H && same; ++j) same = memcmp(gray->ptr<const uint8_t>(j), &g[j * W], W) == 0;
+	printf("pre-processing (%zux%zu RGB24): grayscale %s, Otsu %s [CompV %.0f, HIP %.0f]\n", W, H, same ? "==" : "DIFF", tCpu == tHip ? "==" : "DIFF", tCpu, tHip);
+	return (same && tCpu == tHip) ? 0 : 3;
+}
+
 int main(int argc, char** argv)
 {
 	const size_t W = argc > 2 ? (size_t)atoi(argv[1]) : 1280, H = argc > 2 ? (size_t)atoi(argv[2]) : 720;
@@ -176,6 +210,7 @@ int main(int argc, char** argv)
 		bad += !(okS && okC && okM && okL && okX && okK);
 	}
 	resetObjects();
+	bad += checkPreproc(W, H, 4242u) != 0;
 	printf(bad ? "DROP-IN PARITY FAILED\n" : "DROP-IN PARITY OK\n");
 	return bad ? 1 : 0;
 }
