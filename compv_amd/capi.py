@@ -36,6 +36,7 @@ EXPORTS = [
     "compvhip_plan_houghsht", "compvhip_plan_pipeline", "compvhip_plan_acc", "compvhip_plan_edge_counts",
     "compvhip_plan_set_timing", "compvhip_plan_get_timing", "compvhip_plan_acc_export", "compvhip_plan_edge_dete",
     "compvhip_houghkht_u8", "compvhip_grayscale_u8", "compvhip_otsu_u8", "compvhip_plan_grayscale", "compvhip_plan_otsu",
+    "compvhip_gauss_kernel_fixedpoint", "compvhip_convlt1_fixedpoint_u8", "compvhip_plan_convlt1_fixedpoint",
 ]
 
 
@@ -104,6 +105,9 @@ def load():
     L.compvhip_otsu_u8.argtypes = [vp, vp, sz, sz, sz, C.POINTER(C.c_double)]
     L.compvhip_plan_grayscale.argtypes = [vp, vp, i32, vp, vp]
     L.compvhip_plan_otsu.argtypes = [vp, vp, vp, vp]
+    L.compvhip_gauss_kernel_fixedpoint.argtypes = [sz, C.c_float, vp]
+    L.compvhip_convlt1_fixedpoint_u8.argtypes = [vp, vp, sz, sz, sz, vp, vp, sz, vp, sz]
+    L.compvhip_plan_convlt1_fixedpoint.argtypes = [vp, vp, vp, vp, sz, vp, vp]
     L.compvhip_plan_pipeline.argtypes = [vp, vp, C.c_float, C.c_float, i32, i32, vp, vp, sz, vp, vp]
     L.compvhip_plan_acc.argtypes = [vp, sz, C.POINTER(vp), C.POINTER(sz), C.POINTER(sz), C.POINTER(sz)]
     L.compvhip_plan_acc_export.argtypes = [vp, sz, vp, sz, vp]
@@ -164,6 +168,14 @@ class Context:
         S = packed.strides[0] // bpp
         out = np.empty((H, W), np.uint8)
         self._chk(self.lib.compvhip_grayscale_u8(self.h, _ptr(packed), pixfmt, W, H, S, _ptr(out), W))
+        return out
+
+    def convlt_fixedpoint(self, img, vt, hz):
+        """CompVMathConvlt::convlt1FixedPoint (vt/hz: uint16 Q16 weights)."""
+        H, W = img.shape
+        vt = np.ascontiguousarray(vt, np.uint16); hz = np.ascontiguousarray(hz, np.uint16)
+        out = np.empty((H, W), np.uint8)
+        self._chk(self.lib.compvhip_convlt1_fixedpoint_u8(self.h, _ptr(img), W, H, img.strides[0], _ptr(vt), _ptr(hz), len(vt), _ptr(out), W))
         return out
 
     def otsu(self, img):
@@ -251,6 +263,10 @@ class Plan:
     def grayscale(self, d_in, pixfmt, d_gray, stream=0):
         self.ctx._chk(self.lib.compvhip_plan_grayscale(self.h, d_in, pixfmt, d_gray, stream))
 
+    def convlt_fixedpoint(self, d_in, vt, hz, d_out, stream=0):
+        vt = np.ascontiguousarray(vt, np.uint16); hz = np.ascontiguousarray(hz, np.uint16)
+        self.ctx._chk(self.lib.compvhip_plan_convlt1_fixedpoint(self.h, d_in, _ptr(vt), _ptr(hz), len(vt), d_out, stream))
+
     def otsu(self, d_gray, d_thresholds, stream=0):
         self.ctx._chk(self.lib.compvhip_plan_otsu(self.h, d_gray, d_thresholds, stream))
 
@@ -283,3 +299,12 @@ class Plan:
         ms = (C.c_float * cap)()
         n = self.lib.compvhip_plan_get_timing(self.h, names, ms, cap)
         return [(names[i].decode(), ms[i]) for i in range(max(n, 0))]
+
+
+def gauss_kernel_fixedpoint(size, sigma):
+    """CompVMathGauss::kernelDim1FixedPoint (host arithmetic, no GPU needed)."""
+    k = np.zeros(size, np.uint16)
+    rc = load().compvhip_gauss_kernel_fixedpoint(size, sigma, _ptr(k))
+    if rc != OK:
+        raise CompvHipError(rc, "invalid Gaussian kernel parameters")
+    return k

@@ -66,6 +66,7 @@ struct compvhip_plan {
 	// sht
 	bool shtReady = false;
 	size_t R = 0, T = 0; float thetaStep = 0.f; int accPitch = 0;
+	uint8_t* blurTmp = nullptr;                       // u8 intermediate of the fixed-point convolution
 	uint32_t* hist = nullptr; int32_t* otsu = nullptr; // pre-processing scratch: partial histograms, [frames] Otsu level
 	int32_t* sinQ = nullptr; int32_t* cosQ = nullptr; int32_t* groupOrder = nullptr; int thetaPerGroup = 4;
 	uint32_t* edges = nullptr; size_t edgeCap = 0; int* edgeCounts = nullptr;
@@ -490,7 +491,7 @@ void compvhip_plan_destroy(compvhip_plan* p)
 	for (hipEvent_t e : p->eventPool) (void)hipEventDestroy(e);
 	dfree(ctx, p->ebits); dfree(ctx, p->ubits); dfree(ctx, p->flags); dfree(ctx, p->thrDev); dfree(ctx, p->sums); dfree(ctx, p->tmpOut);
 	if (p->hFlags) (void)hipHostFree(p->hFlags);
-	dfree(ctx, p->hist); dfree(ctx, p->otsu);
+	dfree(ctx, p->hist); dfree(ctx, p->otsu); dfree(ctx, p->blurTmp);
 	dfree(ctx, p->sinQ); dfree(ctx, p->cosQ); dfree(ctx, p->groupOrder); dfree(ctx, p->edges); dfree(ctx, p->edgeCounts); dfree(ctx, p->acc);
 	dfree(ctx, p->keysA); dfree(ctx, p->keysB); dfree(ctx, p->lineCounts);
 	dfree(ctx, p->sortTemp);
@@ -594,6 +595,31 @@ int compvhip_plan_otsu(compvhip_plan* p, const uint8_t* d_gray, int32_t* d_thres
 	Stamp s(p, st, "otsu_kernels");
 	HIPCHK(ctx, launch_otsu(d_gray, static_cast<int>(p->W), static_cast<int>(p->H), static_cast<int>(p->S), p->S * p->H, static_cast<int>(p->frames), 0.5f, 1.f,
 	                        p->hist, d_thresholds, nullptr, st));
+	return COMPVHIP_OK;
+}
+
+static int checkFxpKernel(compvhip_ctx* ctx, size_t W, size_t H, const uint16_t* vt, const uint16_t* hz, size_t k)
+{
+	if (!vt || !hz || !(k & 1) || W < k || H < k) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "convolution kernel: null, even size or larger than the image"); // compv_math_convlt.h:100
+	if (k < 3 || k > static_cast<size_t>(kFxpMaxTaps)) return fail(ctx, COMPVHIP_E_NOT_IMPLEMENTED, "fixed-point convolution supports kernel sizes 3..15");
+	return COMPVHIP_OK;
+}
+
+int compvhip_plan_convlt1_fixedpoint(compvhip_plan* p, const uint8_t* d_in, const uint16_t* vtKern, const uint16_t* hzKern, size_t kernSize, uint8_t* d_out,
+                                     void* stream)
+{
+	if (!p) return COMPVHIP_E_INVALID_PARAMETER;
+	compvhip_ctx* ctx = p->ctx;
+	if (!d_in || !d_out) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "null frame pointer");
+	int rc = checkFxpKernel(ctx, p->W, p->H, vtKern, hzKern, kernSize);
+	if (rc) return rc;
+	HIPCHK(ctx, hipSetDevice(ctx->device));
+	if (!p->blurTmp) HIPCHK(ctx, dmalloc(ctx, &p->blurTmp, p->S * p->H * p->frames));
+	hipStream_t st = static_cast<hipStream_t>(stream);
+	if (p->timing) timelineClear(p);
+	Stamp s(p, st, "convlt_fxp_kernels");
+	HIPCHK(ctx, launch_convlt_fxp(d_in, p->blurTmp, d_out, static_cast<int>(p->W), static_cast<int>(p->H), static_cast<int>(p->S), p->S * p->H,
+	                              static_cast<int>(p->frames), vtKern, hzKern, static_cast<int>(kernSize), st));
 	return COMPVHIP_OK;
 }
 
@@ -785,6 +811,46 @@ int compvhip_edge_dete_u8(compvhip_ctx* ctx, const uint8_t* in, size_t W, size_t
 	a.tilesX = p->tilesX; a.tilesY = p->tilesY;
 	HIPCHK(ctx, launch_edge_dete(a, op, 1, ctx->stream));
 	HIPCHK(ctx, hipMemcpy2DAsync(out, So, ctx->dOut, p->S, W, H, hipMemcpyDeviceToHost, ctx->stream));
+	HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+	return COMPVHIP_OK;
+}
+
+int compvhip_gauss_kernel_fixedpoint(size_t size, float sigma, uint16_t* kernel)
+{
+	// compv_math_gauss.h:24-55 with T = float (note the float/double mix), then compv_math_convlt.h:88
+	if (!kernel || !(size & 1) || size > 255 || !(sigma > 0.f)) return COMPVHIP_E_INVALID_PARAMETER;
+	float f[255];
+	const size_t half = size >> 1;
+	const float sigma2_times2 = static_cast<float>(2 * (sigma * sigma));
+	const float a = static_cast<float>(1 / std::sqrt(3.14159265358979323846 * sigma2_times2));
+	float sum = a;
+	f[half] = a;
+	for (size_t x = 1; x <= half; ++x) {
+		const float k = static_cast<float>(a * std::exp(-static_cast<double>((x * x) / sigma2_times2)));
+		f[x + half] = k; f[half - x] = k;
+		sum += (k + k);
+	}
+	sum = 1 / sum;
+	for (size_t x = 0; x < size; ++x) { f[x] *= sum; kernel[x] = static_cast<uint16_t>(f[x] * 0xffff); }
+	return COMPVHIP_OK;
+}
+
+int compvhip_convlt1_fixedpoint_u8(compvhip_ctx* ctx, const uint8_t* in, size_t W, size_t H, size_t S, const uint16_t* vtKern, const uint16_t* hzKern,
+                                   size_t kernSize, uint8_t* out, size_t So)
+{
+	if (!ctx) return COMPVHIP_E_INVALID_PARAMETER;
+	if (!in || !out || S < W || So < W || !W || !H || W > 32767 || H > 32767) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "null image, stride < width or size out of range");
+	int rc = checkFxpKernel(ctx, W, H, vtKern, hzKern, kernSize);
+	if (rc) return rc;
+	HIPCHK(ctx, hipSetDevice(ctx->device));
+	const size_t Sd = alignUp(W, 64), bytes = Sd * H;
+	if (ctx->dInBytes < bytes) { dfree(ctx, ctx->dIn); HIPCHK(ctx, dmalloc(ctx, &ctx->dIn, bytes)); ctx->dInBytes = bytes; }
+	if (ctx->dOutBytes < bytes) { dfree(ctx, ctx->dOut); HIPCHK(ctx, dmalloc(ctx, &ctx->dOut, bytes)); ctx->dOutBytes = bytes; }
+	HIPCHK(ctx, hipMemcpy2DAsync(ctx->dIn, Sd, in, S, W, H, hipMemcpyHostToDevice, ctx->stream));
+	// horizontal pass dIn -> dOut, vertical pass dOut -> dIn
+	HIPCHK(ctx, launch_convlt_fxp(ctx->dIn, ctx->dOut, ctx->dIn, static_cast<int>(W), static_cast<int>(H), static_cast<int>(Sd), bytes, 1, vtKern, hzKern,
+	                              static_cast<int>(kernSize), ctx->stream));
+	HIPCHK(ctx, hipMemcpy2DAsync(out, So, ctx->dIn, Sd, W, H, hipMemcpyDeviceToHost, ctx->stream));
 	HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
 	return COMPVHIP_OK;
 }

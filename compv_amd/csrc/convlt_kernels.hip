@@ -1,0 +1,116 @@
+// convlt_kernels.hip -- separable fixed-point (Q16) convolution u8 -> u8, the optional Gaussian pre-blur of SURVEY.md 8f row 2.
+//
+// Replaces, behind compvhip_convlt1_fixedpoint_u8 / compvhip_plan_convlt1_fixedpoint:
+//   CompVMathConvlt::convlt1FixedPoint       base/include/compv/base/math/compv_math_convlt.h:31-33 (entry), 98-173 (hz pass, then vt
+//                                            pass through a temporary, zero OUTPUT border of kernSize/2), 386-405 (the leaf:
+//                                            sum_k ((in[k] * kern[k]) >> 16), saturated to u8)
+// with kernels from CompVMathGauss::kernelDim1FixedPoint (base/math/compv_math_gauss.cxx:11-17), computed on the HOST (libm exp).
+//
+// Two streaming passes with a u8 intermediate, exactly the reference's data flow (the intermediate rounding to u8 is part of the
+// result). Per tap: v_mul_u32_u24 + add of the product's high half -- the passes are VALU-bound (2K instructions per pixel pair of
+// passes), not HBM-bound; each reads and writes 1 B/px.
+#include "kernels.hpp"
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace compvhip {
+
+__device__ __forceinline__ uint32_t byteOf(const uint32_t (&w)[6], int i) { return (w[i >> 2] >> (8 * (i & 3))) & 0xffu; }
+
+// horizontal pass: one thread = 8 adjacent pixels of one row; bytes x0-8 .. x0+15 come from three 8-byte loads whose addresses
+// are clamped into the row (anything a clamp falsifies only feeds columns < r or >= W-r, which are forced to zero)
+template <int K>
+__global__ __launch_bounds__(256) void convlt_fxp_hz_kernel(FxpArgs a)
+{
+	constexpr int r = K / 2;
+	const int x0 = (blockIdx.x * 256 + threadIdx.x) * 8, y = blockIdx.y, frame = blockIdx.z;
+	if (x0 >= a.W) return;
+	const uint8_t* __restrict__ row = a.in + (size_t)frame * a.inFrameStride + (size_t)y * a.S;
+	const int xl = max(x0 - 8, 0), xr = min(x0 + 8, a.S - 8);
+	const uint2 L = *reinterpret_cast<const uint2*>(row + xl), M = *reinterpret_cast<const uint2*>(row + x0), Rr = *reinterpret_cast<const uint2*>(row + xr);
+	const uint32_t w[6] = { L.x, L.y, M.x, M.y, Rr.x, Rr.y };
+	uint32_t o[8];
+#pragma unroll
+	for (int j = 0; j < 8; ++j) {
+		uint32_t sum = 0;
+#pragma unroll
+		for (int t = 0; t < K; ++t) sum += __umul24(byteOf(w, 8 + j - r + t), a.kern[t]) >> 16;
+		const int x = x0 + j;
+		o[j] = (x < r || x >= a.W - r) ? 0u : min(sum, 255u);
+	}
+	uint2 q;
+	q.x = o[0] | (o[1] << 8) | (o[2] << 16) | (o[3] << 24);
+	q.y = o[4] | (o[5] << 8) | (o[6] << 16) | (o[7] << 24);
+	*reinterpret_cast<uint2*>(a.out + (size_t)frame * a.outFrameStride + (size_t)y * a.So + x0) = q;
+}
+
+// vertical pass: one thread = 8 adjacent columns, marching down kFxpRows output rows with the last K input rows in registers
+constexpr int kFxpRows = 64;
+
+template <int K>
+__global__ __launch_bounds__(256) void convlt_fxp_vt_kernel(FxpArgs a)
+{
+	constexpr int r = K / 2;
+	const int x0 = (blockIdx.x * 256 + threadIdx.x) * 8, y0 = blockIdx.y * kFxpRows, frame = blockIdx.z;
+	if (x0 >= a.W) return;
+	const uint8_t* __restrict__ src = a.in + (size_t)frame * a.inFrameStride + x0;
+	uint8_t* __restrict__ dst = a.out + (size_t)frame * a.outFrameStride + x0;
+	uint2 ring[K]; // ring[t] = input row yo - r + t of the output row yo being produced
+#pragma unroll
+	for (int t = 0; t < K; ++t) ring[t] = make_uint2(0u, 0u);
+	for (int i = 0; i < kFxpRows + K - 1; ++i) {
+		const int yin = y0 - r + i;
+#pragma unroll
+		for (int t = 0; t + 1 < K; ++t) ring[t] = ring[t + 1];
+		ring[K - 1] = *reinterpret_cast<const uint2*>(src + (size_t)min(max(yin, 0), a.H - 1) * a.S); // clamped rows only feed border outputs
+		const int yo = yin - r;
+		if (i < K - 1 || yo >= a.H) continue;
+		uint2 q = make_uint2(0u, 0u);
+		if (yo >= r && yo < a.H - r) {
+			uint32_t o[8];
+#pragma unroll
+			for (int j = 0; j < 8; ++j) {
+				uint32_t sum = 0;
+#pragma unroll
+				for (int t = 0; t < K; ++t) sum += __umul24(((j < 4 ? ring[t].x : ring[t].y) >> (8 * (j & 3))) & 0xffu, a.kern[t]) >> 16;
+				o[j] = min(sum, 255u);
+			}
+			q.x = o[0] | (o[1] << 8) | (o[2] << 16) | (o[3] << 24);
+			q.y = o[4] | (o[5] << 8) | (o[6] << 16) | (o[7] << 24);
+		}
+		*reinterpret_cast<uint2*>(dst + (size_t)yo * a.So) = q;
+	}
+}
+
+template <int K>
+static hipError_t launchK(const FxpArgs& hz, const FxpArgs& vt, int frames, hipStream_t stream)
+{
+	const int groups = (hz.W + 7) / 8;
+	hipLaunchKernelGGL((convlt_fxp_hz_kernel<K>), dim3((groups + 255) / 256, hz.H, frames), dim3(256), 0, stream, hz);
+	hipLaunchKernelGGL((convlt_fxp_vt_kernel<K>), dim3((groups + 255) / 256, (vt.H + kFxpRows - 1) / kFxpRows, frames), dim3(256), 0, stream, vt);
+	return hipGetLastError();
+}
+
+// in -> tmp (horizontal, hzKern) -> out (vertical, vtKern); in may alias out
+hipError_t launch_convlt_fxp(const uint8_t* in, uint8_t* tmp, uint8_t* out, int W, int H, int S, size_t frameStride, int frames, const uint16_t* vtKern,
+                             const uint16_t* hzKern, int K, hipStream_t stream)
+{
+	if (K < 3 || K > kFxpMaxTaps || !(K & 1)) return hipErrorInvalidValue;
+	FxpArgs hz, vt;
+	hz.in = in; hz.out = tmp; vt.in = tmp; vt.out = out;
+	hz.W = vt.W = W; hz.H = vt.H = H; hz.S = vt.S = hz.So = vt.So = S;
+	hz.inFrameStride = hz.outFrameStride = vt.inFrameStride = vt.outFrameStride = frameStride;
+	for (int t = 0; t < kFxpMaxTaps; ++t) { hz.kern[t] = t < K ? hzKern[t] : 0u; vt.kern[t] = t < K ? vtKern[t] : 0u; }
+	switch (K) {
+	case 3: return launchK<3>(hz, vt, frames, stream);
+	case 5: return launchK<5>(hz, vt, frames, stream);
+	case 7: return launchK<7>(hz, vt, frames, stream);
+	case 9: return launchK<9>(hz, vt, frames, stream);
+	case 11: return launchK<11>(hz, vt, frames, stream);
+	case 13: return launchK<13>(hz, vt, frames, stream);
+	default: return launchK<15>(hz, vt, frames, stream);
+	}
+}
+
+} // namespace compvhip

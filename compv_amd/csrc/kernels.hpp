@@ -69,6 +69,18 @@ constexpr int kOtsuMaxChunks = 128; // row chunks (= workgroups) per frame of th
 hipError_t launch_otsu(const uint8_t* in, int W, int H, int S, size_t frameStride, int frames, float fLowFactor, float fHighFactor, uint32_t* hist,
                        int32_t* otsu, void* thr, hipStream_t stream);
 
+// ---- fixed-point separable convolution (Gaussian pre-blur) ---------------------------------------------------
+constexpr int kFxpMaxTaps = 15;
+struct FxpArgs {
+	const uint8_t* in;
+	uint8_t* out;
+	size_t inFrameStride, outFrameStride;
+	int W, H, S, So;
+	uint32_t kern[kFxpMaxTaps]; // Q16 weights of this pass
+};
+hipError_t launch_convlt_fxp(const uint8_t* in, uint8_t* tmp, uint8_t* out, int W, int H, int S, size_t frameStride, int frames, const uint16_t* vtKern,
+                             const uint16_t* hzKern, int K, hipStream_t stream);
+
 // ---- Hough SHT ---------------------------------------------------------------------------------------------
 constexpr int kShtVoteThreads = 1024;
 

@@ -115,6 +115,18 @@ COMPVHIP_API int compvhip_grayscale_u8(compvhip_ctx* ctx, const uint8_t* in, int
  * 256-bin histogram of the W x H plane + the reference's f32 scan; *threshold = the integer level as a double. */
 COMPVHIP_API int compvhip_otsu_u8(compvhip_ctx* ctx, const uint8_t* in, size_t W, size_t H, size_t S, double* threshold);
 
+/* CompVMathGauss::kernelDim1FixedPoint (base/math/compv_math_gauss.cxx:11-17: kernelDim1<float> of compv_math_gauss.h:24-55, then
+ * CompVMathConvlt::fixedPointKernel, compv_math_convlt.h:77-92): `size` (odd) Q16 weights of a normalised 1-D Gaussian.  Host
+ * arithmetic only (libm exp/sqrt in the reference's float/double mix); no GPU involved. */
+COMPVHIP_API int compvhip_gauss_kernel_fixedpoint(size_t size, float sigma, uint16_t* kernel);
+
+/* CompVMathConvlt::convlt1FixedPoint (base/include/compv/base/math/compv_math_convlt.h:31-33,98-173,386-405): separable Q16
+ * convolution u8 -> u8, horizontal pass with hzKern then vertical pass with vtKern through a u8 temporary, each
+ * out = min(255, sum_k ((in[k] * kern[k]) >> 16)), zero OUTPUT border of kernSize/2.  kernSize odd, 3..15 (larger:
+ * COMPVHIP_E_NOT_IMPLEMENTED), W,H >= kernSize.  The optional Gaussian pre-blur in front of Canny.  in and out may alias. */
+COMPVHIP_API int compvhip_convlt1_fixedpoint_u8(compvhip_ctx* ctx, const uint8_t* in, size_t W, size_t H, size_t S,
+                                                const uint16_t* vtKern, const uint16_t* hzKern, size_t kernSize, uint8_t* out, size_t So);
+
 /* CompVHoughSht::process (core/features/hough/compv_core_feature_houghsht.cxx:96-262).  rho must be 1 (:306-316),
  * thetaDeg in degrees, threshold > 0 is the NMS/line threshold, maxLines <= 0 keeps every line.
  * lines: caller-allocated, capacity cap; *n receives the number of lines found (after the maxLines cut); if *n > cap
@@ -161,6 +173,11 @@ COMPVHIP_API int compvhip_plan_grayscale(compvhip_plan* plan, const uint8_t* d_i
 
 /* compvhip_otsu_u8 on `frames` device frames: d_thresholds[f] = Otsu level of frame f (device array).  Asynchronous. */
 COMPVHIP_API int compvhip_plan_otsu(compvhip_plan* plan, const uint8_t* d_gray, int32_t* d_thresholds, void* stream);
+
+/* compvhip_convlt1_fixedpoint_u8 on `frames` device frames (vtKern/hzKern are HOST arrays of kernSize weights); d_in and
+ * d_out may alias.  Asynchronous. */
+COMPVHIP_API int compvhip_plan_convlt1_fixedpoint(compvhip_plan* plan, const uint8_t* d_in, const uint16_t* vtKern, const uint16_t* hzKern,
+                                                  size_t kernSize, uint8_t* d_out, void* stream);
 
 /* Sobel / Scharr / Prewitt detector (compvhip_edge_dete_u8 semantics) on `frames` device frames; d_in and d_out must
  * not alias.  Fully asynchronous on `stream`. */

@@ -544,3 +544,64 @@ void orc_otsu_canny_thresholds(int t, float fLowFactor, float fHighFactor, int* 
 	if (fLow > 0.f && fHigh > 0.f && fLow < fHigh) orc_canny_thresholds(fLow, fHigh, 0, 0, 1, 1, &lo, &hi);
 	*tLow = lo; *tHigh = hi;
 }
+
+/* ================================================================================================================
+ * Optional Gaussian pre-blur: CompVMathGauss::kernelDim1FixedPoint + CompVMathConvlt::convlt1FixedPoint
+ * ================================================================================================================ */
+int orc_gauss_kernel_f32(size_t size, float sigma, float* kernel)
+{
+	/* compv_math_gauss.h:24-55, T = float: note which sub-expressions are float and which are double */
+	if (!kernel || !(size & 1)) return ORC_E_INVALID_PARAMETER;
+	const size_t half = size >> 1;
+	const float sigma2_times2 = (float)(2 * (sigma * sigma));
+	const float a = (float)(1 / sqrt(3.14159265358979323846 * sigma2_times2)); /* COMPV_MATH_PI is a double literal */
+	float sum = a;
+	kernel[half] = a;
+	for (size_t x = 1; x <= half; ++x) {
+		const float k = (float)(a * exp(-(double)((x * x) / sigma2_times2)));
+		kernel[x + half] = k;
+		kernel[half - x] = k;
+		sum += (k + k);
+	}
+	sum = 1 / sum;
+	for (size_t x = 0; x < size; ++x) kernel[x] *= sum;
+	return ORC_OK;
+}
+
+int orc_gauss_kernel_fixedpoint(size_t size, float sigma, uint16_t* kernel)
+{
+	if (!kernel || !(size & 1) || size > 255) return ORC_E_INVALID_PARAMETER;
+	float f[255];
+	int err = orc_gauss_kernel_f32(size, sigma, f);
+	if (err) return err;
+	for (size_t i = 0; i < size; ++i) kernel[i] = (uint16_t)(f[i] * 0xffff); /* compv_math_convlt.h:88 */
+	return ORC_OK;
+}
+
+static void fxp_pass(const uint8_t* in, size_t W, size_t H, size_t S, const uint16_t* kern, size_t k, uint8_t* out, int vertical)
+{
+	const size_t r = k >> 1;
+	for (size_t y = 0; y < H; ++y) {
+		for (size_t x = 0; x < W; ++x) {
+			const int border = vertical ? (y < r || y >= H - r) : (x < r || x >= W - r);
+			if (border) { out[y * S + x] = 0; continue; }
+			unsigned int sum = 0;
+			for (size_t t = 0; t < k; ++t) {
+				const unsigned int v = vertical ? in[(y - r + t) * S + x] : in[y * S + x - r + t];
+				sum += (v * (unsigned int)kern[t]) >> 16; /* compv_math_convlt.h:393-396: per-tap mulhi, then saturate */
+			}
+			out[y * S + x] = (uint8_t)(sum > 255 ? 255 : sum);
+		}
+	}
+}
+
+int orc_convlt1_fixedpoint(const uint8_t* in, size_t W, size_t H, size_t S, const uint16_t* vt, const uint16_t* hz, size_t k, uint8_t* out)
+{
+	if (!in || W < k || H < k || S < W || !vt || !hz || !(k & 1) || !out) return ORC_E_INVALID_PARAMETER; /* compv_math_convlt.h:100 */
+	uint8_t* tmp = (uint8_t*)calloc(S * H, 1);
+	if (!tmp) return ORC_E_OUT_OF_MEMORY;
+	fxp_pass(in, W, H, S, hz, k, tmp, 0);
+	fxp_pass(tmp, W, H, S, vt, k, out, 1);
+	free(tmp);
+	return ORC_OK;
+}

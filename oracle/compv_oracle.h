@@ -75,6 +75,15 @@ int orc_otsu(const uint8_t* in, size_t W, size_t H, size_t S);
  * COMPARE_TO_GRADIENT rule of orc_canny_thresholds. */
 void orc_otsu_canny_thresholds(int t, float fLowFactor, float fHighFactor, int* tLow, int* tHigh);
 
+/* ---- optional Gaussian pre-blur ---- */
+/* CompVMathGauss::kernelDim1<float> followed by CompVMathConvlt::fixedPointKernel (base/include/compv/base/math/compv_math_gauss.h:24-55,
+ * base/include/compv/base/math/compv_math_convlt.h:77-92): size odd, kernel receives `size` Q16 weights. */
+int orc_gauss_kernel_f32(size_t size, float sigma, float* kernel);
+int orc_gauss_kernel_fixedpoint(size_t size, float sigma, uint16_t* kernel);
+/* CompVMathConvlt::convlt1FixedPoint (compv_math_convlt.h:31-33,98-173,386-405): hz pass then vt pass, each
+ * out = clip255(sum_k ((in[k] * kern[k]) >> 16)), zero OUTPUT border of kernSize/2, u8 intermediate. out has stride S. */
+int orc_convlt1_fixedpoint(const uint8_t* in, size_t W, size_t H, size_t S, const uint16_t* vt, const uint16_t* hz, size_t k, uint8_t* out);
+
 #ifdef __cplusplus
 }
 #endif

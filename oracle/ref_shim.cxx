@@ -19,6 +19,7 @@
 #include <compv/base/compv_mem.h>
 #include <compv/base/image/compv_image.h>
 #include <compv/base/math/compv_math_convlt.h>
+#include <compv/base/math/compv_math_gauss.h>
 #include <compv/base/parallel/compv_parallel.h>
 #include <compv/core/compv_core.h>
 #include <compv/core/features/hough/intrin/x86/compv_core_feature_houghsht_intrin_sse41.h>
@@ -258,6 +259,34 @@ int refshim_otsu(const uint8_t* in, size_t W, size_t H, size_t S, double* thresh
 	double t = 0.0;
 	if (COMPV_ERROR_CODE_IS_NOK(CompVImage::thresholdOtsu(img, t))) return -3;
 	*threshold = t;
+	return 0;
+}
+
+// CompVMathGauss::kernelDim1 (float) / kernelDim1FixedPoint and CompVMathConvlt::convlt1FixedPoint
+int refshim_gauss_kernel_f32(size_t size, float sigma, float* kernel)
+{
+	CompVMatPtr k;
+	if (COMPV_ERROR_CODE_IS_NOK(CompVMathGauss::kernelDim1<compv_float32_t>(&k, size, sigma))) return -1;
+	memcpy(kernel, k->ptr<const compv_float32_t>(), size * sizeof(float));
+	return 0;
+}
+int refshim_gauss_kernel_fixedpoint(size_t size, float sigma, uint16_t* kernel)
+{
+	CompVMatPtr k;
+	if (COMPV_ERROR_CODE_IS_NOK(CompVMathGauss::kernelDim1FixedPoint(&k, size, sigma))) return -1;
+	memcpy(kernel, k->ptr<const uint16_t>(), size * sizeof(uint16_t));
+	return 0;
+}
+int refshim_convlt1_fixedpoint(const uint8_t* in, size_t W, size_t H, size_t S, const uint16_t* vt, const uint16_t* hz, size_t k, uint8_t* out)
+{
+	// aligned copies, as the reference's callers hold CompVMat data
+	CompVMatPtr src, dst;
+	if (COMPV_ERROR_CODE_IS_NOK(CompVMat::newObjAligned<uint8_t>(&src, H, W, S))) return -1;
+	if (COMPV_ERROR_CODE_IS_NOK(CompVMat::newObjAligned<uint8_t>(&dst, H, W, S))) return -1;
+	for (size_t j = 0; j < H; ++j) memcpy(src->ptr<uint8_t>(j), in + j * S, W);
+	uint8_t* o = dst->ptr<uint8_t>();
+	if (COMPV_ERROR_CODE_IS_NOK(CompVMathConvlt::convlt1FixedPoint(src->ptr<const uint8_t>(), W, H, src->stride(), vt, hz, k, o))) return -2;
+	for (size_t j = 0; j < H; ++j) memcpy(out + j * S, dst->ptr<const uint8_t>(j), W);
 	return 0;
 }
 

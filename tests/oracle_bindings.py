@@ -117,6 +117,31 @@ class Oracle:
         self.lib.orc_synth_frame(_p(out), W, H, W, seed)
         return out
 
+    # ---- optional Gaussian pre-blur ----
+    def gauss_kernel_f32(self, size, sigma):
+        k = np.zeros(size, np.float32)
+        L = self.lib
+        L.orc_gauss_kernel_f32.argtypes = [C.c_size_t, C.c_float, C.c_void_p]
+        assert L.orc_gauss_kernel_f32(size, sigma, _p(k)) == 0
+        return k
+
+    def gauss_kernel_fxp(self, size, sigma):
+        k = np.zeros(size, np.uint16)
+        L = self.lib
+        L.orc_gauss_kernel_fixedpoint.argtypes = [C.c_size_t, C.c_float, C.c_void_p]
+        assert L.orc_gauss_kernel_fixedpoint(size, sigma, _p(k)) == 0
+        return k
+
+    def convlt_fxp(self, img, vt, hz):
+        H, W = img.shape
+        S = img.strides[0]
+        out = np.zeros((H, S), np.uint8)
+        vt = np.ascontiguousarray(vt, np.uint16); hz = np.ascontiguousarray(hz, np.uint16)
+        L = self.lib
+        L.orc_convlt1_fixedpoint.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        r = L.orc_convlt1_fixedpoint(_p(img), W, H, S, _p(vt), _p(hz), len(vt), _p(out))
+        return r, out[:, :W]
+
     # ---- caller-side pre-processing ----
     def fmt_bytes(self, fmt):
         return self.lib.orc_fmt_bytes(fmt)
@@ -271,6 +296,30 @@ class RefShim:
     def reinit(self, threads):
         assert self.lib.refshim_init(threads) == 0
         self.threads = self.lib.refshim_threads()
+
+    def gauss_kernel_f32(self, size, sigma):
+        k = np.zeros(size, np.float32)
+        L = self.lib
+        L.refshim_gauss_kernel_f32.argtypes = [C.c_size_t, C.c_float, C.c_void_p]
+        assert L.refshim_gauss_kernel_f32(size, sigma, _p(k)) == 0
+        return k
+
+    def gauss_kernel_fxp(self, size, sigma):
+        k = np.zeros(size, np.uint16)
+        L = self.lib
+        L.refshim_gauss_kernel_fixedpoint.argtypes = [C.c_size_t, C.c_float, C.c_void_p]
+        assert L.refshim_gauss_kernel_fixedpoint(size, sigma, _p(k)) == 0
+        return k
+
+    def convlt_fxp(self, img, vt, hz):
+        H, W = img.shape
+        S = img.strides[0]
+        out = np.zeros((H, S), np.uint8)
+        vt = np.ascontiguousarray(vt, np.uint16); hz = np.ascontiguousarray(hz, np.uint16)
+        L = self.lib
+        L.refshim_convlt1_fixedpoint.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_size_t, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+        r = L.refshim_convlt1_fixedpoint(_p(img), W, H, S, _p(vt), _p(hz), len(vt), _p(out))
+        return r, out[:, :W]
 
     def grayscale(self, packed, fmt, W, bpp):
         H = packed.shape[0]

@@ -46,5 +46,21 @@ for _ in range(10):
 plan.set_timing(0)
 t = float(np.median(ms))
 res["otsu (memset + hist256 + scan)"] = {"ms": round(t, 4), "GB/s": round(F * W * H / (t * 1e-3) / 1e9, 1)}
+for K, sigma in ((5, 1.0), (7, 2.0), (15, 4.0)):
+    kern = capi.gauss_kernel_fixedpoint(K, sigma)
+    d_out = torch.empty_like(d_gray)
+    for _ in range(3):
+        plan.convlt_fixedpoint(d_gray.data_ptr(), kern, kern, d_out.data_ptr())
+    torch.cuda.synchronize()
+    plan.set_timing(1)
+    ms = []
+    for _ in range(10):
+        plan.convlt_fixedpoint(d_gray.data_ptr(), kern, kern, d_out.data_ptr())
+        torch.cuda.synchronize()
+        ms += [m for n, m in plan.get_timing() if n == "convlt_fxp_kernels"]
+    plan.set_timing(0)
+    t = float(np.median(ms))
+    # algorithmic bytes: 1 B/px read + 1 B/px written (the u8 intermediate of the two passes is implementation traffic)
+    res["gauss_fxp_K%d (hz + vt pass)" % K] = {"ms": round(t, 4), "GB/s": round(F * W * H * 2 / (t * 1e-3) / 1e9, 1)}
 print(json.dumps(res))
 plan.close(); ctx.close()
