@@ -614,7 +614,9 @@ int compvhip_plan_convlt1_fixedpoint(compvhip_plan* p, const uint8_t* d_in, cons
 	int rc = checkFxpKernel(ctx, p->W, p->H, vtKern, hzKern, kernSize);
 	if (rc) return rc;
 	HIPCHK(ctx, hipSetDevice(ctx->device));
-	if (!p->blurTmp) HIPCHK(ctx, dmalloc(ctx, &p->blurTmp, p->S * p->H * p->frames));
+	const size_t span = p->S * p->H * p->frames;
+	const bool alias = (d_in < d_out + span) && (d_out < d_in + span);
+	if (alias && !p->blurTmp) HIPCHK(ctx, dmalloc(ctx, &p->blurTmp, span)); // only the in-place call needs the two-pass path
 	hipStream_t st = static_cast<hipStream_t>(stream);
 	if (p->timing) timelineClear(p);
 	Stamp s(p, st, "convlt_fxp_kernels");
@@ -847,10 +849,10 @@ int compvhip_convlt1_fixedpoint_u8(compvhip_ctx* ctx, const uint8_t* in, size_t 
 	if (ctx->dInBytes < bytes) { dfree(ctx, ctx->dIn); HIPCHK(ctx, dmalloc(ctx, &ctx->dIn, bytes)); ctx->dInBytes = bytes; }
 	if (ctx->dOutBytes < bytes) { dfree(ctx, ctx->dOut); HIPCHK(ctx, dmalloc(ctx, &ctx->dOut, bytes)); ctx->dOutBytes = bytes; }
 	HIPCHK(ctx, hipMemcpy2DAsync(ctx->dIn, Sd, in, S, W, H, hipMemcpyHostToDevice, ctx->stream));
-	// horizontal pass dIn -> dOut, vertical pass dOut -> dIn
-	HIPCHK(ctx, launch_convlt_fxp(ctx->dIn, ctx->dOut, ctx->dIn, static_cast<int>(W), static_cast<int>(H), static_cast<int>(Sd), bytes, 1, vtKern, hzKern,
+	// dIn -> dOut with the fused kernel (no intermediate: the two staging buffers never alias)
+	HIPCHK(ctx, launch_convlt_fxp(ctx->dIn, nullptr, ctx->dOut, static_cast<int>(W), static_cast<int>(H), static_cast<int>(Sd), bytes, 1, vtKern, hzKern,
 	                              static_cast<int>(kernSize), ctx->stream));
-	HIPCHK(ctx, hipMemcpy2DAsync(out, So, ctx->dIn, Sd, W, H, hipMemcpyDeviceToHost, ctx->stream));
+	HIPCHK(ctx, hipMemcpy2DAsync(out, So, ctx->dOut, Sd, W, H, hipMemcpyDeviceToHost, ctx->stream));
 	HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
 	return COMPVHIP_OK;
 }

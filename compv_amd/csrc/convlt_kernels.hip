@@ -83,10 +83,75 @@ __global__ __launch_bounds__(256) void convlt_fxp_vt_kernel(FxpArgs a)
 	}
 }
 
+// Fused version (used when in and out do not alias): the thread filters each incoming row horizontally on the fly and pushes the
+// u8 result into the vertical ring, so the intermediate never goes to memory: 1 B/px read (+ the 2r/64 row halo and the 8-byte
+// column halos, which hit in L1/L2) and 1 B/px written, instead of 2 + 2.  Same arithmetic, same u8 rounding between the passes.
 template <int K>
-static hipError_t launchK(const FxpArgs& hz, const FxpArgs& vt, int frames, hipStream_t stream)
+__global__ __launch_bounds__(256) void convlt_fxp_fused_kernel(FxpArgs a, FxpArgs v)
+{
+	constexpr int r = K / 2;
+	const int x0 = (blockIdx.x * 256 + threadIdx.x) * 8, y0 = blockIdx.y * kFxpRows, frame = blockIdx.z;
+	if (x0 >= a.W) return;
+	const uint8_t* __restrict__ src = a.in + (size_t)frame * a.inFrameStride;
+	uint8_t* __restrict__ dst = a.out + (size_t)frame * a.outFrameStride + x0;
+	const int xl = max(x0 - 8, 0), xr = min(x0 + 8, a.S - 8);
+	auto loadRow = [&](int yin, uint2& L, uint2& M, uint2& Rr) {
+		const uint8_t* row = src + (size_t)min(max(yin, 0), a.H - 1) * a.S;
+		L = *reinterpret_cast<const uint2*>(row + xl); M = *reinterpret_cast<const uint2*>(row + x0); Rr = *reinterpret_cast<const uint2*>(row + xr);
+	};
+	uint32_t colok = 0; // bit j: column x0+j is inside [r, W-r)
+#pragma unroll
+	for (int j = 0; j < 8; ++j) colok |= ((x0 + j >= r && x0 + j < a.W - r) ? 1u : 0u) << j;
+	uint2 ring[K];
+#pragma unroll
+	for (int t = 0; t < K; ++t) ring[t] = make_uint2(0u, 0u);
+	uint2 nL, nM, nR;
+	loadRow(y0 - r, nL, nM, nR);
+	for (int i = 0; i < kFxpRows + 2 * r; ++i) {
+		const int yin = y0 - r + i; // input row filtered and pushed now; with K rows in the ring it completes output row yin - r
+		const uint32_t w[6] = { nL.x, nL.y, nM.x, nM.y, nR.x, nR.y };
+		loadRow(yin + 1, nL, nM, nR); // prefetch: in flight while this row is filtered
+		uint32_t o[8];
+#pragma unroll
+		for (int j = 0; j < 8; ++j) {
+			uint32_t sum = 0;
+#pragma unroll
+			for (int t = 0; t < K; ++t) sum += __umul24(byteOf(w, 8 + j - r + t), a.kern[t]) >> 16;
+			o[j] = ((colok >> j) & 1u) ? min(sum, 255u) : 0u;
+		}
+#pragma unroll
+		for (int t = 0; t + 1 < K; ++t) ring[t] = ring[t + 1];
+		ring[K - 1].x = o[0] | (o[1] << 8) | (o[2] << 16) | (o[3] << 24);
+		ring[K - 1].y = o[4] | (o[5] << 8) | (o[6] << 16) | (o[7] << 24);
+		const int yo = yin - r;
+		if (i < 2 * r || yo >= a.H) continue;
+		uint2 q = make_uint2(0u, 0u);
+		if (yo >= r && yo < a.H - r) {
+			uint32_t p[8];
+#pragma unroll
+			for (int j = 0; j < 8; ++j) {
+				uint32_t sum = 0;
+#pragma unroll
+				for (int t = 0; t < K; ++t) sum += __umul24(((j < 4 ? ring[t].x : ring[t].y) >> (8 * (j & 3))) & 0xffu, v.kern[t]) >> 16;
+				p[j] = min(sum, 255u);
+			}
+			q.x = p[0] | (p[1] << 8) | (p[2] << 16) | (p[3] << 24);
+			q.y = p[4] | (p[5] << 8) | (p[6] << 16) | (p[7] << 24);
+		}
+		*reinterpret_cast<uint2*>(dst + (size_t)yo * a.So) = q;
+	}
+}
+
+template <int K>
+static hipError_t launchK(const FxpArgs& hz, const FxpArgs& vt, int frames, bool fused, hipStream_t stream)
 {
 	const int groups = (hz.W + 7) / 8;
+	if (fused) {
+		FxpArgs f = hz;
+		f.out = vt.out; f.outFrameStride = vt.outFrameStride; f.So = vt.So;
+		hipLaunchKernelGGL((convlt_fxp_fused_kernel<K>), dim3((groups + 255) / 256, (hz.H + kFxpRows - 1) / kFxpRows, frames), dim3(256), 0, stream, f, vt);
+		return hipGetLastError();
+	}
 	hipLaunchKernelGGL((convlt_fxp_hz_kernel<K>), dim3((groups + 255) / 256, hz.H, frames), dim3(256), 0, stream, hz);
 	hipLaunchKernelGGL((convlt_fxp_vt_kernel<K>), dim3((groups + 255) / 256, (vt.H + kFxpRows - 1) / kFxpRows, frames), dim3(256), 0, stream, vt);
 	return hipGetLastError();
@@ -102,14 +167,17 @@ hipError_t launch_convlt_fxp(const uint8_t* in, uint8_t* tmp, uint8_t* out, int 
 	hz.W = vt.W = W; hz.H = vt.H = H; hz.S = vt.S = hz.So = vt.So = S;
 	hz.inFrameStride = hz.outFrameStride = vt.inFrameStride = vt.outFrameStride = frameStride;
 	for (int t = 0; t < kFxpMaxTaps; ++t) { hz.kern[t] = t < K ? hzKern[t] : 0u; vt.kern[t] = t < K ? vtKern[t] : 0u; }
+	// the fused kernel reads input rows that other workgroups may already have overwritten when in == out: two passes then
+	const size_t span = frameStride * (size_t)frames;
+	const bool fused = !((in < out + span) && (out < in + span));
 	switch (K) {
-	case 3: return launchK<3>(hz, vt, frames, stream);
-	case 5: return launchK<5>(hz, vt, frames, stream);
-	case 7: return launchK<7>(hz, vt, frames, stream);
-	case 9: return launchK<9>(hz, vt, frames, stream);
-	case 11: return launchK<11>(hz, vt, frames, stream);
-	case 13: return launchK<13>(hz, vt, frames, stream);
-	default: return launchK<15>(hz, vt, frames, stream);
+	case 3: return launchK<3>(hz, vt, frames, fused, stream);
+	case 5: return launchK<5>(hz, vt, frames, fused, stream);
+	case 7: return launchK<7>(hz, vt, frames, fused, stream);
+	case 9: return launchK<9>(hz, vt, frames, fused, stream);
+	case 11: return launchK<11>(hz, vt, frames, fused, stream);
+	case 13: return launchK<13>(hz, vt, frames, fused, stream);
+	default: return launchK<15>(hz, vt, frames, fused, stream);
 	}
 }
 

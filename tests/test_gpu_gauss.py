@@ -65,7 +65,11 @@ def test_plan_blur_then_canny_batch(hip_ctx, oracle):
     d_edges = torch.empty_like(d)
     plan = capi.Plan(hip_ctx, W, H, S, F, 1.0)
     try:
-        plan.convlt_fixedpoint(d.data_ptr(), kern, kern, d.data_ptr())     # in place
+        d_blur = torch.empty_like(d)
+        plan.convlt_fixedpoint(d.data_ptr(), kern, kern, d_blur.data_ptr())   # out of place: fused single-kernel path
+        plan.convlt_fixedpoint(d.data_ptr(), kern, kern, d.data_ptr())        # in place: two passes through the plan's scratch
+        torch.cuda.synchronize()
+        assert torch.equal(d_blur, d)
         plan.canny(d.data_ptr(), 30.0, 70.0, d_edges.data_ptr())
         torch.cuda.synchronize()
         b = d.cpu().numpy(); e = d_edges.cpu().numpy()

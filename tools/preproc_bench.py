@@ -61,6 +61,6 @@ for K, sigma in ((5, 1.0), (7, 2.0), (15, 4.0)):
     plan.set_timing(0)
     t = float(np.median(ms))
     # algorithmic bytes: 1 B/px read + 1 B/px written (the u8 intermediate of the two passes is implementation traffic)
-    res["gauss_fxp_K%d (hz + vt pass)" % K] = {"ms": round(t, 4), "GB/s": round(F * W * H * 2 / (t * 1e-3) / 1e9, 1)}
+    res["gauss_fxp_K%d (fused hz+vt kernel)" % K] = {"ms": round(t, 4), "GB/s": round(F * W * H * 2 / (t * 1e-3) / 1e9, 1)}
 print(json.dumps(res))
 plan.close(); ctx.close()
