@@ -36,7 +36,7 @@ EXPORTS = [
     "compvhip_plan_houghsht", "compvhip_plan_pipeline", "compvhip_plan_acc", "compvhip_plan_edge_counts",
     "compvhip_plan_set_timing", "compvhip_plan_get_timing", "compvhip_plan_acc_export", "compvhip_plan_edge_dete",
     "compvhip_houghkht_u8", "compvhip_grayscale_u8", "compvhip_otsu_u8", "compvhip_plan_grayscale", "compvhip_plan_otsu",
-    "compvhip_gauss_kernel_fixedpoint", "compvhip_convlt1_fixedpoint_u8", "compvhip_plan_convlt1_fixedpoint",
+    "compvhip_gauss_kernel_fixedpoint", "compvhip_convlt1_fixedpoint_u8", "compvhip_plan_convlt1_fixedpoint", "compvhip_plan_to_cartesian",
 ]
 
 
@@ -105,6 +105,7 @@ def load():
     L.compvhip_otsu_u8.argtypes = [vp, vp, sz, sz, sz, C.POINTER(C.c_double)]
     L.compvhip_plan_grayscale.argtypes = [vp, vp, i32, vp, vp]
     L.compvhip_plan_otsu.argtypes = [vp, vp, vp, vp]
+    L.compvhip_plan_to_cartesian.argtypes = [vp, vp, vp, sz, vp, vp]
     L.compvhip_gauss_kernel_fixedpoint.argtypes = [sz, C.c_float, vp]
     L.compvhip_convlt1_fixedpoint_u8.argtypes = [vp, vp, sz, sz, sz, vp, vp, sz, vp, sz]
     L.compvhip_plan_convlt1_fixedpoint.argtypes = [vp, vp, vp, vp, sz, vp, vp]
@@ -266,6 +267,9 @@ class Plan:
     def convlt_fixedpoint(self, d_in, vt, hz, d_out, stream=0):
         vt = np.ascontiguousarray(vt, np.uint16); hz = np.ascontiguousarray(hz, np.uint16)
         self.ctx._chk(self.lib.compvhip_plan_convlt1_fixedpoint(self.h, d_in, _ptr(vt), _ptr(hz), len(vt), d_out, stream))
+
+    def to_cartesian(self, d_lines, d_counts, line_cap, d_cart, stream=0):
+        self.ctx._chk(self.lib.compvhip_plan_to_cartesian(self.h, d_lines, d_counts, line_cap, d_cart, stream))
 
     def otsu(self, d_gray, d_thresholds, stream=0):
         self.ctx._chk(self.lib.compvhip_plan_otsu(self.h, d_gray, d_thresholds, stream))

@@ -68,6 +68,7 @@ struct compvhip_plan {
 	size_t R = 0, T = 0; float thetaStep = 0.f; int accPitch = 0;
 	uint8_t* blurTmp = nullptr;                       // u8 intermediate of the fixed-point convolution
 	uint32_t* hist = nullptr; int32_t* otsu = nullptr; // pre-processing scratch: partial histograms, [frames] Otsu level
+	float* cosT = nullptr; float* invSinT = nullptr; // toCartesian tables: cosf(theta_col), 1/sinf(theta_col)
 	int32_t* sinQ = nullptr; int32_t* cosQ = nullptr; int32_t* groupOrder = nullptr; int thetaPerGroup = 4;
 	uint32_t* edges = nullptr; size_t edgeCap = 0; int* edgeCounts = nullptr;
 	uint16_t* acc = nullptr; size_t accFrameStride = 0;
@@ -113,6 +114,10 @@ void dfree(compvhip_ctx* ctx, T*& p)
 size_t alignUp(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // ---- thresholds: core/features/edges/compv_core_feature_canny_dete.cxx:251-266 (COMPARE_TO_GRADIENT branch) ----
+// cosf / sinf exactly as the reference's scalar calls resolve them (never merged into sincosf)
+__attribute__((noinline, optnone)) float libmCosf(float x) { return cosf(x); }
+__attribute__((noinline, optnone)) float libmSinf(float x) { return sinf(x); }
+
 void gradientThresholds(float fLow, float fHigh, int* tLow, int* tHigh)
 {
 	const float l = fLow < 1.f ? 1.f : (fLow > 65535.f ? 65535.f : fLow);
@@ -161,8 +166,8 @@ void shtTables(float thetaDeg, size_t T, std::vector<int32_t>& sinQ, std::vector
 	sinQ.resize(T); cosQ.resize(T);
 	float tt = 0.f;
 	for (size_t t = 0; t < T; ++t, tt += fTheta) {
-		sinQ[t] = static_cast<int32_t>((std::sin(tt) * fRho) * 65535.f);
-		cosQ[t] = static_cast<int32_t>((std::cos(tt) * fRho) * 65535.f);
+		sinQ[t] = static_cast<int32_t>((libmSinf(tt) * fRho) * 65535.f);
+		cosQ[t] = static_cast<int32_t>((libmCosf(tt) * fRho) * 65535.f);
 	}
 }
 
@@ -232,6 +237,20 @@ int ensureSht(compvhip_plan* p)
 	HIPCHK(ctx, dmalloc(ctx, &p->cosQ, T));
 	HIPCHK(ctx, hipMemcpy(p->sinQ, s.data(), T * sizeof(int32_t), hipMemcpyHostToDevice));
 	HIPCHK(ctx, hipMemcpy(p->cosQ, c.data(), T * sizeof(int32_t), hipMemcpyHostToDevice));
+	{
+		// toCartesian (houghsht.cxx:582): a = std::cos(theta), b = 1.f / std::sin(theta) with theta = col * thetaStep in f32
+		// (separate libm calls: a compiler that fuses them into sincosf() changes cos by an ulp for some arguments)
+		std::vector<float> ct(T), ist(T);
+		for (size_t t = 0; t < T; ++t) {
+			const float theta = static_cast<float>(t) * step;
+			ct[t] = libmCosf(theta);
+			ist[t] = 1.f / libmSinf(theta);
+		}
+		HIPCHK(ctx, dmalloc(ctx, &p->cosT, T));
+		HIPCHK(ctx, dmalloc(ctx, &p->invSinT, T));
+		HIPCHK(ctx, hipMemcpy(p->cosT, ct.data(), T * sizeof(float), hipMemcpyHostToDevice));
+		HIPCHK(ctx, hipMemcpy(p->invSinT, ist.data(), T * sizeof(float), hipMemcpyHostToDevice));
+	}
 	{
 		// theta bins per vote workgroup: 2 (two 16-wave workgroups per CU; measured 0.53 ms vs 0.60 ms per 32 4K frames), 4 via the tuning knob
 		const char* e = getenv("COMPVHIP_SHT_THETA_PER_GROUP");
@@ -492,6 +511,7 @@ void compvhip_plan_destroy(compvhip_plan* p)
 	dfree(ctx, p->ebits); dfree(ctx, p->ubits); dfree(ctx, p->flags); dfree(ctx, p->thrDev); dfree(ctx, p->sums); dfree(ctx, p->tmpOut);
 	if (p->hFlags) (void)hipHostFree(p->hFlags);
 	dfree(ctx, p->hist); dfree(ctx, p->otsu); dfree(ctx, p->blurTmp);
+	dfree(ctx, p->cosT); dfree(ctx, p->invSinT);
 	dfree(ctx, p->sinQ); dfree(ctx, p->cosQ); dfree(ctx, p->groupOrder); dfree(ctx, p->edges); dfree(ctx, p->edgeCounts); dfree(ctx, p->acc);
 	dfree(ctx, p->keysA); dfree(ctx, p->keysB); dfree(ctx, p->lineCounts);
 	dfree(ctx, p->sortTemp);
@@ -720,6 +740,20 @@ int compvhip_plan_pipeline(compvhip_plan* p, const uint8_t* d_in, float tLow, fl
 		} while (!done);
 		if (alias) HIPCHK(ctx, hipMemcpyAsync(d_edges, out, bytes, hipMemcpyDeviceToDevice, st));
 	}
+	return COMPVHIP_OK;
+}
+
+int compvhip_plan_to_cartesian(compvhip_plan* p, const compvhip_line* d_lines, const int32_t* d_counts, size_t lineCap, float* d_cart, void* stream)
+{
+	if (!p) return COMPVHIP_E_INVALID_PARAMETER;
+	compvhip_ctx* ctx = p->ctx;
+	if (!d_lines || !d_counts || !d_cart) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "null pointer");
+	HIPCHK(ctx, hipSetDevice(ctx->device));
+	int rc = ensureSht(p);
+	if (rc) return rc;
+	const float widthF = static_cast<float>(p->W), heightF = static_cast<float>(p->H);
+	const float r = std::sqrt((widthF * widthF) + (heightF * heightF)); // houghsht.cxx:570
+	HIPCHK(ctx, launch_sht_cartesian(d_lines, d_counts, lineCap, static_cast<int>(p->frames), p->cosT, p->invSinT, widthF, r, d_cart, static_cast<hipStream_t>(stream)));
 	return COMPVHIP_OK;
 }
 

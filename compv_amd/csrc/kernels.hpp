@@ -112,6 +112,8 @@ hipError_t launch_sht_nms(const ShtArgs& a, int frames, hipStream_t stream);
 hipError_t launch_sht_decode(const uint64_t* keys, const int* counts, size_t lineCap, int frames, int T, int barrier, float thetaStep,
                              int maxLines, int cellBits, int strengthBits, void* lines /*compvhip_line*/, size_t outCap, hipStream_t stream);
 // acc [T][pitch] -> reference layout [R][stride]
+hipError_t launch_sht_cartesian(const void* lines /*compvhip_line*/, const int* counts, size_t lineCap, int frames, const float* cosT, const float* invSinT,
+                                float widthF, float r, float* out /*[frames][lineCap][4]*/, hipStream_t stream);
 hipError_t launch_sht_acc_transpose(const uint16_t* accT, int R, int T, int accPitch, int32_t* out, size_t outStride, hipStream_t stream);
 size_t sht_vote_lds_bytes(int R, int thetaPerGroup);
 // one descending radix sort over the (unique) 64-bit line keys of all frames; temp == nullptr queries tempBytes

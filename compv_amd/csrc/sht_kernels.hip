@@ -439,6 +439,29 @@ __global__ __launch_bounds__(256) void sht_decode_kernel(const uint64_t* __restr
 	lines[(size_t)frame * outCap + i] = o;
 }
 
+// CompVHoughSht::toCartesian (houghsht.cxx:566-589) on the device line arrays.  cos(theta) and 1/sin(theta) come from HOST
+// tables indexed by the line's theta column (libm cosf/sinf, as the reference; device trig would not be bit-identical);
+// the kernel only multiplies and subtracts, with single correctly-rounded operations.
+__global__ __launch_bounds__(256) void sht_cartesian_kernel(const LineOut* __restrict__ lines, const int* __restrict__ counts, size_t lineCap, const float* __restrict__ cosT,
+                                                            const float* __restrict__ invSinT, float widthF, float r, float4* __restrict__ out)
+{
+	// rho - W*a must stay a rounded product followed by a rounded subtraction, as on the CPU: the library is built with
+	// -ffp-contract=off (the __f*_rn intrinsics are plain operators that a later FMA contraction would still fuse)
+	const int frame = blockIdx.y;
+	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+	size_t n = (size_t)max(counts[frame], 0);
+	if (n > lineCap) n = lineCap;
+	if (i >= n) return;
+	const LineOut l = lines[(size_t)frame * lineCap + i];
+	float4 o;
+	if (l.theta == 0.f) o = make_float4(l.rho, r, l.rho, -r); // perfect vertical line
+	else {
+		const float a = cosT[l.col], b = invSinT[l.col];
+		o = make_float4(0.f, __fmul_rn(l.rho, b), widthF, __fmul_rn(__fsub_rn(l.rho, __fmul_rn(widthF, a)), b));
+	}
+	out[(size_t)frame * lineCap + i] = o;
+}
+
 __global__ __launch_bounds__(256) void sht_acc_transpose_kernel(const uint16_t* __restrict__ accT, int R, int T, int accPitch, int32_t* __restrict__ out, size_t outStride)
 {
 	__shared__ int32_t tile[32][33];
@@ -533,6 +556,16 @@ hipError_t launch_sht_decode(const uint64_t* keys, const int* counts, size_t lin
 	dim3 grid((unsigned)((n + 255) / 256), frames);
 	hipLaunchKernelGGL(sht_decode_kernel, grid, dim3(256), 0, stream, keys, counts, lineCap, T, barrier, thetaStep, maxLines, cellBits, strengthBits,
 	                   reinterpret_cast<LineOut*>(lines), outCap);
+	return hipGetLastError();
+}
+
+hipError_t launch_sht_cartesian(const void* lines, const int* counts, size_t lineCap, int frames, const float* cosT, const float* invSinT, float widthF,
+                                float r, float* out, hipStream_t stream)
+{
+	if (!lineCap) return hipSuccess;
+	dim3 grid((unsigned)((lineCap + 255) / 256), frames);
+	hipLaunchKernelGGL(sht_cartesian_kernel, grid, dim3(256), 0, stream, reinterpret_cast<const LineOut*>(lines), counts, lineCap, cosT, invSinT, widthF, r,
+	                   reinterpret_cast<float4*>(out));
 	return hipGetLastError();
 }
 

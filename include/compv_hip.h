@@ -179,6 +179,12 @@ COMPVHIP_API int compvhip_plan_otsu(compvhip_plan* plan, const uint8_t* d_gray, 
 COMPVHIP_API int compvhip_plan_convlt1_fixedpoint(compvhip_plan* plan, const uint8_t* d_in, const uint16_t* vtKern, const uint16_t* hzKern,
                                                   size_t kernSize, uint8_t* d_out, void* stream);
 
+/* CompVHoughSht::toCartesian (core/features/hough/compv_core_feature_houghsht.cxx:264-304,566-589) on the device line arrays a
+ * compvhip_plan_houghsht / _pipeline call produced: d_cart[f][i] = {a.x, a.y, b.x, b.y} of line i of frame f (a.z = b.z = 1), for
+ * i < min(d_counts[f], lineCap).  Asynchronous. */
+COMPVHIP_API int compvhip_plan_to_cartesian(compvhip_plan* plan, const compvhip_line* d_lines, const int32_t* d_counts, size_t lineCap,
+                                            float* d_cart, void* stream);
+
 /* Sobel / Scharr / Prewitt detector (compvhip_edge_dete_u8 semantics) on `frames` device frames; d_in and d_out must
  * not alias.  Fully asynchronous on `stream`. */
 COMPVHIP_API int compvhip_plan_edge_dete(compvhip_plan* plan, const uint8_t* d_in, int op, uint8_t* d_out, void* stream);

@@ -605,3 +605,20 @@ int orc_convlt1_fixedpoint(const uint8_t* in, size_t W, size_t H, size_t S, cons
 	free(tmp);
 	return ORC_OK;
 }
+
+/* CompVHoughSht::toCartesian, core/features/hough/compv_core_feature_houghsht.cxx:566-589 (the "#if 1" branch) */
+void orc_sht_to_cartesian(size_t W, size_t H, const orc_line* lines, size_t n, float* out)
+{
+	const float widthF = (float)W, heightF = (float)H;
+	const float r = sqrtf((widthF * widthF) + (heightF * heightF));
+	for (size_t i = 0; i < n; ++i) {
+		const float theta = lines[i].theta, rho = lines[i].rho;
+		float* o = out + 4 * i;
+		if (theta == 0.f) { o[0] = rho; o[1] = r; o[2] = rho; o[3] = -r; }
+		else {
+			const float a = cosf(theta), b = (1.f / sinf(theta));
+			o[0] = 0.f; o[1] = (rho * b);
+			o[2] = widthF; o[3] = ((rho - (widthF * a)) * b);
+		}
+	}
+}

@@ -84,6 +84,9 @@ int orc_gauss_kernel_fixedpoint(size_t size, float sigma, uint16_t* kernel);
  * out = clip255(sum_k ((in[k] * kern[k]) >> 16)), zero OUTPUT border of kernSize/2, u8 intermediate. out has stride S. */
 int orc_convlt1_fixedpoint(const uint8_t* in, size_t W, size_t H, size_t S, const uint16_t* vt, const uint16_t* hz, size_t k, uint8_t* out);
 
+/* CompVHoughSht::toCartesian (core/features/hough/compv_core_feature_houghsht.cxx:566-589): out[4*i..] = a.x, a.y, b.x, b.y */
+void orc_sht_to_cartesian(size_t W, size_t H, const orc_line* lines, size_t n, float* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -117,6 +117,19 @@ class Oracle:
         self.lib.orc_synth_frame(_p(out), W, H, W, seed)
         return out
 
+    def sht_to_cartesian(self, W, H, lines):
+        """lines: iterable of (rho, theta, ...) -> (n, 4) float32 array a.x, a.y, b.x, b.y (CompVHoughSht::toCartesian)."""
+        n = len(lines)
+        buf = (OrcLine * max(n, 1))()
+        for i, l in enumerate(lines):
+            buf[i].rho = l[0]; buf[i].theta = l[1]
+        out = np.zeros((max(n, 1), 4), np.float32)
+        L = self.lib
+        L.orc_sht_to_cartesian.argtypes = [C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
+        L.orc_sht_to_cartesian.restype = None
+        L.orc_sht_to_cartesian(W, H, buf, n, _p(out))
+        return out[:n]
+
     # ---- optional Gaussian pre-blur (SURVEY 8f row 2) ----
     def gauss_kernel_f32(self, size, sigma):
         k = np.zeros(size, np.float32)
@@ -296,6 +309,17 @@ class RefShim:
     def reinit(self, threads):
         assert self.lib.refshim_init(threads) == 0
         self.threads = self.lib.refshim_threads()
+
+    def sht_to_cartesian(self, W, H, lines):
+        n = len(lines)
+        buf = (RefLine * max(n, 1))()
+        for i, l in enumerate(lines):
+            buf[i].rho = l[0]; buf[i].theta = l[1]; buf[i].strength = 1
+        out = np.zeros((max(n, 1), 4), np.float32)
+        L = self.lib
+        L.refshim_sht_to_cartesian.argtypes = [C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
+        assert L.refshim_sht_to_cartesian(W, H, buf, n, _p(out)) == 0
+        return out[:n]
 
     def gauss_kernel_f32(self, size, sigma):
         k = np.zeros(size, np.float32)

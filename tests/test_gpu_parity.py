@@ -400,3 +400,40 @@ def test_houghkht_empty_and_errors(hip_ctx):
     with pytest.raises(capi.CompvHipError) as ex:
         hip_ctx.houghkht(e, rho=1.5)                           # rho must be in (0,1] (houghkht.cxx:491)
     assert ex.value.code == capi.E_INVALID_PARAMETER
+
+
+def test_plan_to_cartesian_on_device(hip_ctx, oracle):
+    """CompVHoughSht::toCartesian on the device line arrays (samples/hough_lines/main.cxx:108) vs the oracle, 2 frames; one frame
+    holds a perfectly vertical line (theta == 0 branch)."""
+    import torch
+    from compv_amd import capi
+    W, H, F, cap = 640, 480, 2, 4096
+    frames = np.stack([synth_frame(W, H, 99), np.full((H, W), 30, np.uint8)])
+    frames[1][:, 300:304] = 250                      # vertical bar -> theta = 0 lines
+    dev = torch.device("cuda:0")
+    d_in = torch.from_numpy(frames).to(dev)
+    d_edges = torch.empty_like(d_in)
+    d_lines = torch.zeros((F, cap, 5), dtype=torch.int32, device=dev)
+    d_counts = torch.zeros(F, dtype=torch.int32, device=dev)
+    d_cart = torch.full((F, cap, 4), float("nan"), dtype=torch.float32, device=dev)
+    plan = capi.Plan(hip_ctx, W, H, W, F, 1.0)
+    try:
+        plan.pipeline(d_in.data_ptr(), 59.0, 119.0, 60, 0, d_edges.data_ptr(), d_lines.data_ptr(), cap, d_counts.data_ptr())
+        plan.to_cartesian(d_lines.data_ptr(), d_counts.data_ptr(), cap, d_cart.data_ptr())
+        torch.cuda.synchronize()
+        counts = d_counts.cpu().numpy()
+        lines = d_lines.cpu().numpy().view(np.uint8).reshape(F, cap, 20)
+        cart = d_cart.cpu().numpy()
+        saw_vertical = False
+        for f in range(F):
+            n = int(counts[f])
+            assert 0 < n <= cap
+            rec = np.frombuffer(lines[f][:n].tobytes(), dtype=capi.LINE_DTYPE)
+            polar = [(float(r["rho"]), float(r["theta"])) for r in rec]
+            saw_vertical |= any(t == 0.0 for _, t in polar)
+            exp = oracle.sht_to_cartesian(W, H, polar)
+            assert cart[f][:n].view(np.uint32).tolist() == exp.view(np.uint32).tolist()
+            assert np.isnan(cart[f][n:]).all()      # nothing written past the line count
+        assert saw_vertical
+    finally:
+        plan.close()

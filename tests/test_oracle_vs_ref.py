@@ -62,3 +62,14 @@ def test_canny_5x5_sobel(oracle, refshim, W, H):
             rc2, b = refshim.canny(img, tl, th, 5)
             assert rc == 0 and rc2 == 0
             assert (a == b).all(), (W, H, tl, th, int((a != b).sum()))
+
+
+def test_sht_to_cartesian_matches_reference(oracle, refshim):
+    """CompVHoughSht::toCartesian (houghsht.cxx:566-589) incl. the theta == 0 special case."""
+    import math
+    step = np.float32(math.pi / 180.0)
+    lines = [(float(rho), float(np.float32(col) * step)) for col in range(0, 180, 7) for rho in (-1500.0, -3.0, 0.0, 17.0, 2400.0)]
+    for (W, H) in ((640, 480), (3840, 2160)):
+        exp = refshim.sht_to_cartesian(W, H, lines)
+        got = oracle.sht_to_cartesian(W, H, lines)
+        assert got.view(np.uint32).tolist() == exp.view(np.uint32).tolist()
