@@ -437,3 +437,39 @@ def test_plan_to_cartesian_on_device(hip_ctx, oracle):
         assert saw_vertical
     finally:
         plan.close()
+
+
+def test_random_shape_sweep(hip_ctx, oracle):
+    """Seeded sweep over odd sizes / thresholds / operators: Sobel-family detector, Canny (3x3 and 5x5, both threshold modes) and
+    SHT (accumulator + line set) against the oracle.  Catches tile-edge and ragged-tail cases no hand-picked size covers."""
+    from compv_amd import capi
+    rng = np.random.default_rng(20240926)
+    for it in range(40):
+        W = int(rng.integers(5, 1100)); H = int(rng.integers(5, 300))
+        kind = it % 4
+        if kind == 0:
+            img = synth_frame(W, H, 1000 + it)
+        elif kind == 1:
+            img = rng.integers(0, 256, size=(H, W), dtype=np.uint8)
+        elif kind == 2:
+            img = (np.add.outer(np.arange(H) * 3, np.arange(W) * 2) % 256).astype(np.uint8)
+            img[rng.random((H, W)) < 0.02] = 255
+        else:
+            img = np.zeros((H, W), np.uint8)
+            img[H // 3: 2 * H // 3 + 1, W // 4: 3 * W // 4 + 1] = int(rng.integers(60, 256))
+        op = [0, 2, 3][it % 3]
+        assert (hip_ctx.edge_dete(img, op) == oracle.edge_dete(img, op)[0]).all(), (it, W, H, op)
+        tl = float(rng.uniform(5, 120)); th = tl * float(rng.uniform(1.2, 3.0))
+        ks = 5 if (it % 5 == 0 and W >= 5 and H >= 5) else 3
+        rc, exp = oracle.canny(img, tl, th, ks)
+        got = hip_ctx.canny(img, tl, th, ksize=ks)
+        assert rc == 0 and (got == exp).all(), (it, W, H, tl, th, ks, int((got != exp).sum()))
+        rc, exp_m = oracle.canny(img, 0.6, 1.3, 3, 1)
+        got_m = hip_ctx.canny(img, 0.6, 1.3, threshold_type=capi.THRESHOLD_PERCENT_OF_MEAN)
+        assert rc == 0 and (got_m == exp_m).all(), (it, W, H, "mean")
+        deg = [1.0, 0.5, 2.0, 1.5][it % 4]
+        thr = int(rng.integers(5, 60))
+        acc_exp = oracle.sht_acc(exp, deg)
+        lines, acc = hip_ctx.houghsht(exp, deg, thr, want_acc=True)
+        assert (acc == acc_exp).all(), (it, W, H, deg)
+        assert _lines_tuple(lines) == _orc_tuple(oracle.sht_lines_from_acc(acc_exp, W, H, deg, thr)), (it, W, H, deg, thr)
