@@ -11,7 +11,7 @@
 //
 // Kernel 1 (canny_tile_kernel): one wave per 512x64 tile.  Streams rows through registers (stencil.hpp), applies the
 //   NMS rule to the *unsuppressed* g (gather/apply split of the reference), classifies weak (g_nms > tLow) / strong
-//   (g_nms > tHigh) per pixel, collects the per-row lane masks with v_writelane into a lane==row layout, and then
+//   (g_nms > tHigh) per pixel, collects per-lane mask bytes (v_alignbit on difference signs) into LDS rows (lane == row), and then
 //   floods strong -> weak inside the tile to a fixed point with 512-bit carry-propagate adds (horizontal runs in one
 //   step) + cross-lane row exchange (vertical/diagonal steps).  Pixels resolved inside the tile are final; weak
 //   pixels the tile cannot resolve go to the U mask.
@@ -33,22 +33,6 @@ __device__ __forceinline__ uint32_t spread4(uint32_t nib)
 {
 	// bit j of the nibble -> bit 8*j
 	return __umul24(nib, 0x00204081u) & 0x01010101u;
-}
-
-// planes (bit i of lo[p]/hi[p] = pixel 8*i+p / 8*(i+32)+p of this lane's row) -> 8 x u64 in pixel order
-__device__ __forceinline__ void planes_to_row(const uint32_t (&lo)[8], const uint32_t (&hi)[8], uint64_t (&row)[8])
-{
-#pragma unroll
-	for (int k = 0; k < 16; ++k) {
-		uint32_t d = 0;
-#pragma unroll
-		for (int p = 0; p < 8; ++p) {
-			const uint32_t src = (k < 8) ? lo[p] : hi[p];
-			const uint32_t nib = (src >> (4 * (k & 7))) & 0xfu;
-			d |= spread4(nib) << p;
-		}
-		if (k & 1) row[k >> 1] |= (uint64_t)d << 32; else row[k >> 1] = d;
-	}
 }
 
 // S |= every run of W that contains a bit of S, towards higher bit positions (512-bit carry chain)
@@ -84,10 +68,15 @@ __device__ __forceinline__ void flood_down(const uint64_t (&W)[8], uint64_t (&S)
 	}
 }
 
-// The 8 weak + 8 strong lane masks (64 bit each) of one tile row are gathered into lanes 0..31 of ONE VGPR with
-// v_writelane_b32 (constant lane selects), then stored with a single ds_write_b32: row r of the wave's LDS slab holds
-// dwords [wlo0 whi0 wlo1 whi1 ... | slo0 shi0 ...].  After the row loop every lane reads back "its" row (lane == row).
-#define COMPV_WRITELANE(vdst, sval, LANE) asm volatile("v_writelane_b32 %0, %1, " #LANE : "+v"(vdst) : "s"(sval))
+// max(a, b, c) with c wave-uniform, as ONE v_max3_i32 that is always executed: written as volatile asm because the compiler
+// otherwise sinks the four neighbour maxima of the NMS into divergent branches on the direction class (s_and_saveexec /
+// s_cbranch_execz / s_or per pixel) -- more instructions than the work it skips, and the kernel is bound by instruction issue.
+__device__ __forceinline__ int max3i(int a, int b, int sc)
+{
+	int d;
+	asm volatile("v_max3_i32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(sc));
+	return d;
+}
 
 // ---------------------------------------------------------------------------------------------------------------
 // Kernel 1
@@ -166,7 +155,8 @@ __global__ __launch_bounds__(kCannyWaves * 64) void canny_tile_kernel(CannyArgs 
 		constexpr int aNew = PH % 2, aMid = (PH + 1) % 2;
 		const int yin = y0 - 1 - R + it;
 		const RowBytes rb = nextRow;
-		// software prefetch: the next row's loads are in flight while this row is processed
+		// software prefetch: the next row's loads are in flight while this row is processed (a distance of two rows was measured:
+		// no gain -- the kernel is bound by instruction issue, not by load latency)
 		nextRow = load_row(in + (size_t)min(max(yin + 1, 0), H - 1) * S, x0, S);
 		int (&gD)[10] = gr[gNew];
 		const int (&gC)[10] = gr[gMid];
@@ -189,9 +179,11 @@ __global__ __launch_bounds__(kCannyWaves * 64) void canny_tile_kernel(CannyArgs 
 		// NMS + classification of row yo = yc-1 (rows gU = yo-1, gC = yo, gD = yo+1)
 		const int rr = yc - 1 - y0;
 		if (rr >= 0 && rr < kTileH) {
-			uint32_t rowv = 0;
+			// Per-lane mask bytes instead of wave ballots: bit p of accNW = "pixel p is NOT weak", of accH = "g > tHigh", collected
+			// with one v_alignbit per pixel from the sign of a difference (pixels are visited 7..0 so that pixel 0 ends in bit 0).
+			uint32_t accNW = 0, accH = 0;
 #pragma unroll
-			for (int p = 0; p < 8; ++p) {
+			for (int p = 7; p >= 0; --p) {
 				const int gi = p + 1;
 				const int gc = gC[gi];
 				// direction class (constants canny_dete.h:58-61: tan(pi/8), tan(3pi/8) in Q16; 158217 = 27145 + 2^17)
@@ -200,33 +192,22 @@ __global__ __launch_bounds__(kCannyWaves * 64) void canny_tile_kernel(CannyArgs 
 				const uint32_t t1 = __umul24(ax, 27145u);
 				const bool k1 = ays < t1;
 				const bool k2 = ays < t1 + (ax << 17);
-				const int mh = max(gC[gi - 1], gC[gi + 1]);
-				const int mv = max(gU[gi], gD[gi]);
-				const int md1 = max(gU[gi - 1], gD[gi + 1]);
-				const int md2 = max(gD[gi - 1], gU[gi + 1]);
+				// neighbour maxima with tLow+1 folded in (v_max3): weak = g > tLow && g >= m  <=>  g >= max(m, tLow+1)
+				const int mh = max3i(gC[gi - 1], gC[gi + 1], tLow1);
+				const int mv = max3i(gU[gi], gD[gi], tLow1);
+				const int md1 = max3i(gU[gi - 1], gD[gi + 1], tLow1);
+				const int md2 = max3i(gD[gi - 1], gU[gi + 1], tLow1);
 				int m = k1 ? mh : (k2 ? (ngr[aMid][p] ? md2 : md1) : mv);
-				bool seedok = true;
-				if (GAP) {
-					seedok = (cov >> p) & 1u;
-					m = seedok ? m : 0;
-				}
-				// weak = g > tLow && g >= m  <=>  g >= max(m, tLow+1);  strong = weak && g > tHigh [&& covered]
-				const uint64_t wm = mask_ge_i32(gc, max(m, tLow1));
-				uint64_t sm = wm & mask_gt_i32_s(gc, tHigh);
-				if (GAP) sm &= __builtin_amdgcn_ballot_w64(seedok);
-				const uint32_t w0 = (uint32_t)wm, w1 = (uint32_t)(wm >> 32), s0 = (uint32_t)sm, s1 = (uint32_t)(sm >> 32);
-				switch (p) { // lane selects must be literal
-				case 0: COMPV_WRITELANE(rowv, w0, 0); COMPV_WRITELANE(rowv, w1, 1); COMPV_WRITELANE(rowv, s0, 16); COMPV_WRITELANE(rowv, s1, 17); break;
-				case 1: COMPV_WRITELANE(rowv, w0, 2); COMPV_WRITELANE(rowv, w1, 3); COMPV_WRITELANE(rowv, s0, 18); COMPV_WRITELANE(rowv, s1, 19); break;
-				case 2: COMPV_WRITELANE(rowv, w0, 4); COMPV_WRITELANE(rowv, w1, 5); COMPV_WRITELANE(rowv, s0, 20); COMPV_WRITELANE(rowv, s1, 21); break;
-				case 3: COMPV_WRITELANE(rowv, w0, 6); COMPV_WRITELANE(rowv, w1, 7); COMPV_WRITELANE(rowv, s0, 22); COMPV_WRITELANE(rowv, s1, 23); break;
-				case 4: COMPV_WRITELANE(rowv, w0, 8); COMPV_WRITELANE(rowv, w1, 9); COMPV_WRITELANE(rowv, s0, 24); COMPV_WRITELANE(rowv, s1, 25); break;
-				case 5: COMPV_WRITELANE(rowv, w0, 10); COMPV_WRITELANE(rowv, w1, 11); COMPV_WRITELANE(rowv, s0, 26); COMPV_WRITELANE(rowv, s1, 27); break;
-				case 6: COMPV_WRITELANE(rowv, w0, 12); COMPV_WRITELANE(rowv, w1, 13); COMPV_WRITELANE(rowv, s0, 28); COMPV_WRITELANE(rowv, s1, 29); break;
-				default: COMPV_WRITELANE(rowv, w0, 14); COMPV_WRITELANE(rowv, w1, 15); COMPV_WRITELANE(rowv, s0, 30); COMPV_WRITELANE(rowv, s1, 31); break;
-				}
+				if (GAP) m = ((cov >> p) & 1u) ? m : tLow1; // outside the NMS coverage (quirk Q3): thresholded only
+				accNW = __builtin_amdgcn_alignbit(accNW, (uint32_t)(gc - m), 31);     // sign(g - max(m, tLow+1)) = not weak
+				accH = __builtin_amdgcn_alignbit(accH, (uint32_t)(tHigh - gc), 31);   // sign(tHigh - g) = g > tHigh
 			}
-			if (lane < 32) maskRows[rr * kMaskPitch + lane] = rowv;
+			const uint32_t wbyte = ~accNW & 0xffu;
+			uint32_t sbyte = wbyte & accH;
+			if (GAP) sbyte &= cov; // seeds are only scanned inside the coverage
+			uint8_t* mrow = reinterpret_cast<uint8_t*>(maskRows + rr * kMaskPitch);
+			mrow[lane] = (uint8_t)wbyte;        // row rr: 64 weak bytes (512 px in pixel order) ...
+			mrow[64 + lane] = (uint8_t)sbyte;   // ... then 64 strong bytes
 		}
 	};
 
@@ -255,21 +236,19 @@ __global__ __launch_bounds__(kCannyWaves * 64) void canny_tile_kernel(CannyArgs 
 		}
 	}
 
-	// lane == row: fetch this lane's row of masks (rows beyond the image are all-zero: g was forced to 0 there)
-	uint32_t wlo[8], whi[8], slo[8], shi[8];
+	// lane == row: fetch this lane's row of masks (rows beyond the image are all-zero: g was forced to 0 there).  The rows are
+	// already in pixel order: dword k of a row = pixels 32k .. 32k+31.
+	uint64_t Wm[8], Em[8];
 	{
 		const uint32_t* mr = maskRows + lane * kMaskPitch;
 #pragma unroll
-		for (int p = 0; p < 8; ++p) {
-			wlo[p] = mr[2 * p]; whi[p] = mr[2 * p + 1];
-			slo[p] = mr[16 + 2 * p]; shi[p] = mr[16 + 2 * p + 1];
+		for (int m = 0; m < 8; ++m) {
+			Wm[m] = (uint64_t)mr[2 * m] | ((uint64_t)mr[2 * m + 1] << 32);
+			Em[m] = (uint64_t)mr[16 + 2 * m] | ((uint64_t)mr[16 + 2 * m + 1] << 32);
 		}
 	}
 
 	// ---- lane == row: flood strong into weak inside the tile ----
-	uint64_t Wm[8], Em[8];
-	planes_to_row(wlo, whi, Wm);
-	planes_to_row(slo, shi, Em);
 	for (;;) {
 		flood_up(Wm, Em);
 		flood_down(Wm, Em);
