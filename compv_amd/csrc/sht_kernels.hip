@@ -281,8 +281,7 @@ __global__ __launch_bounds__(kShtVoteThreads) void sht_vote_kernel(ShtArgs a)
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// NMS + threshold -> line keys.  One workgroup = 1024 consecutive rho rows of one theta column (coalesced along rho in
-// the theta-major accumulator); lines are compacted inside the workgroup and ONE global atomic reserves their slots.
+// NMS + threshold -> line keys (sht_nms_kernel below: LDS-tiled 3x3 test, one global atomic per workgroup for the key slots).
 // key = frameTag << (strengthBits+cellBits) | strength << cellBits | (cellMask - cell), cell = row*T + col: unique, and a single
 // descending radix sort over all frames yields frame-major, strength-descending, (row,col)-ascending order.
 // ---------------------------------------------------------------------------------------------------------------
