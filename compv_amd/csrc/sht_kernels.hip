@@ -72,7 +72,7 @@ __global__ __launch_bounds__(kCompactThreads) void sht_compact_kernel(ShtArgs a)
 {
 	__shared__ int s_wave[kCompactThreads / 64];
 	__shared__ int s_base;
-	__shared__ uint32_t s_stage[kCompactStage + kCompactStage / 64];
+	__shared__ uint32_t s_stage[kCompactStage];
 	const int frame = blockIdx.y;
 	const size_t nwords = (size_t)a.H * a.wb; // wb is a multiple of 16, so nwords % kCompactWords == 0
 	const size_t w0 = ((size_t)blockIdx.x * kCompactThreads + threadIdx.x) * kCompactWords;
@@ -108,35 +108,34 @@ __global__ __launch_bounds__(kCompactThreads) void sht_compact_kernel(ShtArgs a)
 	if (threadIdx.x == 0) s_base = atomicAdd(&a.edgeCounts[frame], total);
 	__syncthreads();
 	uint32_t* __restrict__ dst = a.edges + (size_t)frame * a.edgeCap;
+	// all kCompactWords words of a thread lie in one image row (wb % 8 == 0): one division per thread
+	const uint32_t row = (uint32_t)(w0 / a.wb);
+	const uint32_t yx00 = (row << 16) | (((uint32_t)w0 - row * (uint32_t)a.wb) * 32u);
 	if (total <= kCompactStage) {
-		// usual case: expand into LDS in raster order (pitch 65 per 64 entries), then write the block's slice of the list
-		// TRANSPOSED: the slice is read as a [nr][64] matrix (last row ragged) and emitted column by column, so 64 consecutive
-		// list entries are 64 raster positions apart -- the voting kernel can then hand consecutive entries to the 64 lanes of
-		// one ds_add without piling onto a single rho bin near theta = 90 deg. Stores are coalesced.
+		// usual case: expand into LDS, then copy the block's slice of the list out with coalesced stores.  The slice is stored
+		// TRANSPOSED: raster entry i = 64 r + c of the block (a [nr][64] matrix whose last row holds m entries) goes to list
+		// position c (nr-1) + min(c, m) + r, i.e. the matrix is emitted column by column, so 64 consecutive list entries are
+		// 64 raster positions apart -- the voting kernel can then hand consecutive entries to the 64 lanes of one ds_add
+		// without piling onto a single rho bin near theta = 90 deg.  (Computed per raster entry: no division.)
+		const int nr = (total + 63) >> 6;
+		const int m = total - (nr - 1) * 64;
 		int lp = wbase + incl - cnt;
 #pragma unroll
 		for (int k = 0; k < kCompactWords; ++k) {
 			uint32_t b = bits[k];
-			if (!b) continue;
-			const size_t wi = w0 + k;
-			const int y = (int)(wi / a.wb);
-			const uint32_t yx0 = ((uint32_t)y << 16) | (uint32_t)((int)(wi - (size_t)y * a.wb) * 32);
+			const uint32_t yx0 = yx00 + 32u * k;
 			while (b) {
 				const int bit = __ffs(b) - 1;
 				b &= b - 1;
-				s_stage[lp + (lp >> 6)] = yx0 + (uint32_t)bit;
+				const int c = lp & 63, r = lp >> 6;
+				s_stage[c * (nr - 1) + min(c, m) + r] = yx0 + (uint32_t)bit;
 				++lp;
 			}
 		}
 		__syncthreads();
-		const int nr = (total + 63) >> 6;
-		const int m = total - (nr - 1) * 64; // entries of the last matrix row: columns < m hold nr entries, the others nr-1
 		for (int q = threadIdx.x; q < total; q += kCompactThreads) {
-			int c, r;
-			if (q < m * nr) { c = q / nr; r = q - c * nr; }
-			else { const int q2 = q - m * nr; const int c2 = q2 / (nr - 1); c = m + c2; r = q2 - c2 * (nr - 1); }
 			const size_t pos = (size_t)s_base + q;
-			if (pos < a.edgeCap) dst[pos] = s_stage[r * 65 + c];
+			if (pos < a.edgeCap) dst[pos] = s_stage[q];
 		}
 		return;
 	}
@@ -145,14 +144,11 @@ __global__ __launch_bounds__(kCompactThreads) void sht_compact_kernel(ShtArgs a)
 #pragma unroll
 		for (int k = 0; k < kCompactWords; ++k) {
 			uint32_t b = bits[k];
-			if (!b) continue;
-			const size_t wi = w0 + k;
-			const int y = (int)(wi / a.wb);
-			const int x0 = (int)(wi - (size_t)y * a.wb) * 32;
+			const uint32_t yx0 = yx00 + 32u * k;
 			while (b) {
 				const int bit = __ffs(b) - 1;
 				b &= b - 1;
-				if (pos < a.edgeCap) dst[pos] = ((uint32_t)y << 16) | (uint32_t)(x0 + bit);
+				if (pos < a.edgeCap) dst[pos] = yx0 + (uint32_t)bit;
 				++pos;
 			}
 		}
