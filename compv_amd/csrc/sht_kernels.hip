@@ -284,7 +284,7 @@ __global__ __launch_bounds__(kShtVoteThreads) void sht_vote_kernel(ShtArgs a)
 // key = frameTag << (strengthBits+cellBits) | strength << cellBits | (cellMask - cell), cell = row*T + col: unique, and a single
 // descending radix sort over all frames yields frame-major, strength-descending, (row,col)-ascending order.
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int kNmsThreads = 256;
+constexpr int kNmsThreads = 128;
 constexpr int kNmsCols = 8;                  // theta columns per block
 constexpr int kNmsRows = kNmsThreads * 8;    // rho rows per block: 8 per thread
 constexpr int kNmsTileRows = kNmsRows + 16;  // + 8 rows of halo either side (keeps every 16-byte load aligned)
