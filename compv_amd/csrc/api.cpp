@@ -222,6 +222,9 @@ int ensureSht(compvhip_plan* p)
 {
 	if (p->shtReady) return COMPVHIP_OK;
 	compvhip_ctx* ctx = p->ctx;
+	// a previous attempt may have failed half way (out of memory): start from a clean slate instead of leaking its buffers
+	dfree(ctx, p->sinQ); dfree(ctx, p->cosQ); dfree(ctx, p->cosT); dfree(ctx, p->invSinT); dfree(ctx, p->groupOrder);
+	dfree(ctx, p->edges); dfree(ctx, p->edgeCounts); dfree(ctx, p->acc); dfree(ctx, p->lineCounts);
 	size_t R, T; float step;
 	int rc = shtDims(p->W, p->H, p->thetaDeg, &R, &T, &step);
 	if (rc) return fail(ctx, rc, "invalid SHT geometry");
