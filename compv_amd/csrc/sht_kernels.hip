@@ -205,7 +205,7 @@ __global__ __launch_bounds__(kShtVoteThreads) void sht_vote_kernel(ShtArgs a)
 		if constexpr (SC) asm volatile("" : "+v"(inc[k])); // keep the addend in a VGPR (ds_add data operand), not re-materialised per vote
 	}
 	// SC: the LDS byte address of hist[0] rides in the high half too, so the masked high half IS the ds_add address
-	const int K = ((a.barrier << 16) + 65535) * (SC ? 4 : 1) + (SC ? (int)(((uint32_t)reinterpret_cast<uintptr_t>(hist) & 0xffffu) << 16) : 0);
+	const uint32_t K = (((uint32_t)a.barrier << 16) + 65535u) * (SC ? 4u : 1u) + (SC ? (((uint32_t)reinterpret_cast<uintptr_t>(hist) & 0xffffu) << 16) : 0u);
 	const uint32_t offMask = 0xfffcu;
 	const int nvalid = min(kShtThetaPerGroup, a.T - t0);
 
@@ -220,7 +220,7 @@ __global__ __launch_bounds__(kShtVoteThreads) void sht_vote_kernel(ShtArgs a)
 		const int x = (int)(xy & 0xffffu), y = (int)(xy >> 16);
 #pragma unroll
 		for (int k = 0; k < kShtThetaPerGroup; ++k) {
-			const uint32_t v = (uint32_t)(__mul24(x, ncq[k]) + (__mul24(y, nsq[k]) + K));
+			const uint32_t v = (uint32_t)__mul24(x, ncq[k]) + ((uint32_t)__mul24(y, nsq[k]) + K); // modulo 2^32 by construction
 			if constexpr (SC) {
 				uint32_t off;
 				asm("v_and_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:WORD_1" : "=v"(off) : "v"(offMask), "v"(v));
