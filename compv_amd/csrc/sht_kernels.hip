@@ -519,7 +519,7 @@ hipError_t launch_sht_vote(const ShtArgs& a, int frames, hipStream_t stream)
 	}
 	const int groups = (a.T + tg - 1) / tg;
 	dim3 grid(frames, groups, a.shards);
-	static const int threads = [] { const char* e = getenv("COMPVHIP_SHT_VOTE_THREADS"); const int v = e ? atoi(e) : 0; return (v == 256 || v == 512 || v == 1024) ? v : kShtVoteThreads; }(); // tuning knob
+	static const int threads = [] { const char* e = getenv("COMPVHIP_SHT_VOTE_THREADS"); const int v = e ? atoi(e) : 0; return (v >= 64 && v <= 1024 && (v % 64) == 0) ? v : kShtVoteThreads; }(); // tuning knob
 	if (tg == 4) hipLaunchKernelGGL((sht_vote_kernel<4, false>), grid, dim3(threads), lds, stream, a);
 	else if (sc) hipLaunchKernelGGL((sht_vote_kernel<2, true>), grid, dim3(threads), lds, stream, a);
 	else hipLaunchKernelGGL((sht_vote_kernel<2, false>), grid, dim3(threads), lds, stream, a);
