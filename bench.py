@@ -166,6 +166,11 @@ def main():
     plan.set_timing(0)
 
     counts = d_counts.cpu().numpy()
+    # the only result exchange of the job: all-gather of the tiny per-frame line counts, outside the timed region
+    try:
+        all_counts = sharding.gather_frame_results([int(c) for c in counts], dist if dist_on else None, dev)
+    except Exception:  # reporting only: never let it hide the throughput number
+        all_counts = None
     total_px = world * F * W * H * args.steps
     value = total_px / elapsed / 1e6
 
@@ -219,6 +224,7 @@ def main():
             "kernels_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in sorted(breakdown.items())},
             "kernels_ms_per_step_source": "second pass of %d steps with HIP events around every launch (not in the timed region)" % args.steps,
             "lines_frame0": int(counts[0]),
+            "lines_all_frames": (int(sum(all_counts)) if all_counts is not None else None),
         }
         if world == 1 and not args.no_cpu_baseline:
             try:
