@@ -6,9 +6,9 @@
 //                                            sum_k ((in[k] * kern[k]) >> 16), saturated to u8)
 // with kernels from CompVMathGauss::kernelDim1FixedPoint (base/math/compv_math_gauss.cxx:11-17), computed on the HOST (libm exp).
 //
-// Two streaming passes with a u8 intermediate, exactly the reference's data flow (the intermediate rounding to u8 is part of the
-// result). Per tap: v_mul_u32_u24 + add of the product's high half -- the passes are VALU-bound (2K instructions per pixel pair of
-// passes), not HBM-bound; each reads and writes 1 B/px.
+// Data flow of the reference: horizontal pass, u8 rounding, vertical pass (the intermediate rounding is part of the result).
+// Out of place: ONE fused kernel (no intermediate in memory, one v_mul_hi_u32_u24 per tap); in place: two streaming passes through
+// a scratch plane.  VALU-bound (2K taps per pixel), not HBM-bound.
 #include "kernels.hpp"
 
 #include <hip/hip_runtime.h>
@@ -83,6 +83,19 @@ __global__ __launch_bounds__(256) void convlt_fxp_vt_kernel(FxpArgs a)
 	}
 }
 
+// floor((b * k) / 65536) in ONE instruction: the pixel byte is kept pre-shifted in bits 8..15 of a 16-bit half (b << 8) and the Q16
+// weight as k << 8; v_mul_hi_u32_u24 returns bits 47..32 of the 24x24-bit product (b << 8) * (k << 8) = b * k * 65536.
+template <int HALF>
+__device__ __forceinline__ uint32_t tapHi(uint32_t halves, uint32_t k8)
+{
+	uint32_t d;
+	if (HALF == 0) asm("v_mul_hi_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0 src1_sel:DWORD" : "=v"(d) : "v"(halves), "v"(k8));
+	else asm("v_mul_hi_u32_u24_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1 src1_sel:DWORD" : "=v"(d) : "v"(halves), "v"(k8));
+	return d;
+}
+// bytes b0..b3 of a dword -> E = (b0 << 8) | (b2 << 24), O = (b1 << 8) | (b3 << 24)
+__device__ __forceinline__ void splitShifted(uint32_t w, uint32_t& E, uint32_t& O) { E = (w << 8) & 0xff00ff00u; O = w & 0xff00ff00u; }
+
 // Fused version (used when in and out do not alias): the thread filters each incoming row horizontally on the fly and pushes the
 // u8 result into the vertical ring, so the intermediate never goes to memory: 1 B/px read (+ the 2r/64 row halo and the 8-byte
 // column halos, which hit in L1/L2) and 1 B/px written, instead of 2 + 2.  Same arithmetic, same u8 rounding between the passes.
@@ -102,27 +115,38 @@ __global__ __launch_bounds__(256) void convlt_fxp_fused_kernel(FxpArgs a, FxpArg
 	uint32_t colok = 0; // bit j: column x0+j is inside [r, W-r)
 #pragma unroll
 	for (int j = 0; j < 8; ++j) colok |= ((x0 + j >= r && x0 + j < a.W - r) ? 1u : 0u) << j;
-	uint2 ring[K];
+	uint32_t hk[K], vk[K]; // Q16 weights << 8, in VGPRs (SDWA operands)
 #pragma unroll
-	for (int t = 0; t < K; ++t) ring[t] = make_uint2(0u, 0u);
+	for (int t = 0; t < K; ++t) { hk[t] = a.kern[t] << 8; vk[t] = v.kern[t] << 8; }
+	// ring[t]: horizontally filtered row (8 pixels) in split pre-shifted form: [0] = px 0,2  [1] = px 1,3  [2] = px 4,6  [3] = px 5,7
+	uint32_t ring[K][4];
+#pragma unroll
+	for (int t = 0; t < K; ++t) { ring[t][0] = ring[t][1] = ring[t][2] = ring[t][3] = 0u; }
 	uint2 nL, nM, nR;
 	loadRow(y0 - r, nL, nM, nR);
 	for (int i = 0; i < kFxpRows + 2 * r; ++i) {
 		const int yin = y0 - r + i; // input row filtered and pushed now; with K rows in the ring it completes output row yin - r
-		const uint32_t w[6] = { nL.x, nL.y, nM.x, nM.y, nR.x, nR.y };
+		// the 24 bytes x0-8 .. x0+15 as 12 registers of two pre-shifted bytes each: byte i -> sp[(i >> 2) * 2 + (i & 1)], half (i >> 1) & 1
+		uint32_t sp[12];
+		splitShifted(nL.x, sp[0], sp[1]); splitShifted(nL.y, sp[2], sp[3]); splitShifted(nM.x, sp[4], sp[5]);
+		splitShifted(nM.y, sp[6], sp[7]); splitShifted(nR.x, sp[8], sp[9]); splitShifted(nR.y, sp[10], sp[11]);
 		loadRow(yin + 1, nL, nM, nR); // prefetch: in flight while this row is filtered
 		uint32_t o[8];
 #pragma unroll
 		for (int j = 0; j < 8; ++j) {
 			uint32_t sum = 0;
 #pragma unroll
-			for (int t = 0; t < K; ++t) sum += __umul24(byteOf(w, 8 + j - r + t), a.kern[t]) >> 16;
+			for (int t = 0; t < K; ++t) {
+				const int bi = 8 + j - r + t; // byte index 0..23
+				const uint32_t reg = sp[(bi >> 2) * 2 + (bi & 1)];
+				sum += ((bi >> 1) & 1) ? tapHi<1>(reg, hk[t]) : tapHi<0>(reg, hk[t]);
+			}
 			o[j] = ((colok >> j) & 1u) ? min(sum, 255u) : 0u;
 		}
 #pragma unroll
-		for (int t = 0; t + 1 < K; ++t) ring[t] = ring[t + 1];
-		ring[K - 1].x = o[0] | (o[1] << 8) | (o[2] << 16) | (o[3] << 24);
-		ring[K - 1].y = o[4] | (o[5] << 8) | (o[6] << 16) | (o[7] << 24);
+		for (int t = 0; t + 1 < K; ++t) { ring[t][0] = ring[t + 1][0]; ring[t][1] = ring[t + 1][1]; ring[t][2] = ring[t + 1][2]; ring[t][3] = ring[t + 1][3]; }
+		ring[K - 1][0] = (o[0] << 8) | (o[2] << 24); ring[K - 1][1] = (o[1] << 8) | (o[3] << 24);
+		ring[K - 1][2] = (o[4] << 8) | (o[6] << 24); ring[K - 1][3] = (o[5] << 8) | (o[7] << 24);
 		const int yo = yin - r;
 		if (i < 2 * r || yo >= a.H) continue;
 		uint2 q = make_uint2(0u, 0u);
@@ -132,7 +156,10 @@ __global__ __launch_bounds__(256) void convlt_fxp_fused_kernel(FxpArgs a, FxpArg
 			for (int j = 0; j < 8; ++j) {
 				uint32_t sum = 0;
 #pragma unroll
-				for (int t = 0; t < K; ++t) sum += __umul24(((j < 4 ? ring[t].x : ring[t].y) >> (8 * (j & 3))) & 0xffu, v.kern[t]) >> 16;
+				for (int t = 0; t < K; ++t) {
+					const uint32_t reg = ring[t][(j >> 2) * 2 + (j & 1)];
+					sum += ((j >> 1) & 1) ? tapHi<1>(reg, vk[t]) : tapHi<0>(reg, vk[t]);
+				}
 				p[j] = min(sum, 255u);
 			}
 			q.x = p[0] | (p[1] << 8) | (p[2] << 16) | (p[3] << 24);
