@@ -474,12 +474,16 @@ size_t resolve_lds_bytes()
 
 hipError_t launch_canny_resolve(const ResolveArgs& a, int frames, hipStream_t stream)
 {
-	static bool attr_set = false;
+	// the opt-in to > 64 KB of dynamic LDS is a per-device function attribute: remember it per device (one process may own several)
+	static bool attr_set[64] = {};
 	const size_t lds = resolve_lds_bytes();
-	if (!attr_set) {
+	int dev = 0;
+	(void)hipGetDevice(&dev);
+	dev = (dev >= 0 && dev < 64) ? dev : 0;
+	if (!attr_set[dev]) {
 		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(canny_resolve_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 		if (e != hipSuccess) return e;
-		attr_set = true;
+		attr_set[dev] = true;
 	}
 	const int bands = (a.H + kBandH - 1) / kBandH;
 	const int chunks = (a.wb + kBandWords - 1) / kBandWords;

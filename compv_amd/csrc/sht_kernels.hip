@@ -506,12 +506,16 @@ hipError_t launch_sht_vote(const ShtArgs& a, int frames, hipStream_t stream)
 	if (lds > 160 * 1024) return hipErrorInvalidValue;
 	const void* fn = tg == 4 ? reinterpret_cast<const void*>(sht_vote_kernel<4, false>)
 	               : sc ? reinterpret_cast<const void*>(sht_vote_kernel<2, true>) : reinterpret_cast<const void*>(sht_vote_kernel<2, false>);
-	static size_t attr_lds[3] = { 0, 0, 0 };
+	// the opt-in to > 64 KB of dynamic LDS is a per-device function attribute: remember it per device (one process may own several)
+	static size_t attr_lds[64][3] = {};
 	const int slot = tg == 4 ? 0 : (sc ? 1 : 2);
-	if (lds > attr_lds[slot]) {
+	int dev = 0;
+	(void)hipGetDevice(&dev);
+	dev = (dev >= 0 && dev < 64) ? dev : 0;
+	if (lds > attr_lds[dev][slot]) {
 		hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
 		if (e != hipSuccess) return e;
-		attr_lds[slot] = lds;
+		attr_lds[dev][slot] = lds;
 	}
 	if (a.shards > 1) {
 		hipError_t e = hipMemsetAsync(a.acc, 0, sizeof(uint16_t) * a.accFrameStride * frames, stream);
