@@ -185,7 +185,18 @@ __global__ __launch_bounds__(256) void otsu_kernel(const uint32_t* __restrict__ 
 	__shared__ int s_idx[256];
 	const int f = blockIdx.x, i = threadIdx.x;
 	uint32_t hi_ = 0; // CompVMathHistogram::build: sum of the row-chunk partial histograms
-	for (int c = 0; c < chunks; ++c) hi_ += hist[((size_t)f * chunks + c) * 256 + i];
+	{
+		const uint32_t* hp = hist + (size_t)f * chunks * 256 + i;
+		int c = 0;
+		for (; c + 8 <= chunks; c += 8) { // eight independent loads in flight (a plain loop serialises on the load latency)
+			uint32_t v[8];
+#pragma unroll
+			for (int u = 0; u < 8; ++u) v[u] = hp[(size_t)(c + u) * 256];
+#pragma unroll
+			for (int u = 0; u < 8; ++u) hi_ += v[u];
+		}
+		for (; c < chunks; ++c) hi_ += hp[(size_t)c * 256];
+	}
 	s_sumA[i] = (uint32_t)i * hi_;
 	s_q1[i] = (int)hi_;
 	__syncthreads();
