@@ -77,7 +77,7 @@ struct compvhip_plan {
 	int cellBits = 0, strengthBits = 16, keyBits = 0;
 	int shards = 1;
 	// timing
-	int timing = 0; // 0 off, 1 every kernel, 2 roofline kernels only
+	int timing = 0; // 0 off, 1 every kernel, 2 canny_tile + sht_vote, 3 sht_vote only, 4 canny_tile only
 	std::vector<hipEvent_t> eventPool;
 	std::vector<TimingEntry> timeline;
 	std::vector<std::string> timingNames; std::vector<float> timingMs;
@@ -177,6 +177,8 @@ static bool stampWanted(const compvhip_plan* p, const char* name)
 {
 	if (p->timing == 1) return true;
 	if (p->timing == 2) return !strcmp(name, "canny_tile_kernel") || !strcmp(name, "sht_vote_kernel");
+	if (p->timing == 3) return !strcmp(name, "sht_vote_kernel");
+	if (p->timing == 4) return !strcmp(name, "canny_tile_kernel");
 	return false;
 }
 
@@ -524,7 +526,7 @@ void compvhip_plan_destroy(compvhip_plan* p)
 int compvhip_plan_set_timing(compvhip_plan* p, int enabled)
 {
 	if (!p) return COMPVHIP_E_INVALID_PARAMETER;
-	p->timing = (enabled == 2) ? 2 : (enabled != 0 ? 1 : 0);
+	p->timing = (enabled >= 2 && enabled <= 4) ? enabled : (enabled != 0 ? 1 : 0);
 	return COMPVHIP_OK;
 }
 

@@ -212,8 +212,9 @@ COMPVHIP_API int compvhip_plan_edge_counts(compvhip_plan* plan, const int32_t** 
 
 /* Per-kernel timing of the last plan call, measured with hipEvents on the stream the kernels were launched on.
  * names/ms: caller arrays of capacity cap; returns the number of entries (<= cap). compvhip_plan_set_timing(plan, mode):
- * 0 = off, 1 = every kernel, 2 = only canny_tile_kernel and sht_vote_kernel (an event pair costs a few microseconds of stream
- * time; mode 2 keeps that out of a throughput measurement). */
+ * 0 = off, 1 = every kernel, 2 = only canny_tile_kernel and sht_vote_kernel, 3 = only sht_vote_kernel, 4 = only canny_tile_kernel
+ * (an event pair costs ~10-20 us of stream time and lengthens the bracketed kernel: the narrow modes keep that out of a
+ * throughput measurement). */
 COMPVHIP_API int compvhip_plan_set_timing(compvhip_plan* plan, int enabled);
 COMPVHIP_API int compvhip_plan_get_timing(compvhip_plan* plan, const char** names, float* ms, int cap);
 
