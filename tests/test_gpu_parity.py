@@ -496,3 +496,17 @@ def test_full_size_properties_linearity_and_monotonicity(hip_ctx):
     assert (acc_a.astype(np.int64) + acc_b == acc).all()
     T = acc.shape[1]
     assert int(acc.sum()) == int((e_hi != 0).sum()) * T
+
+
+@pytest.mark.parametrize("W,H", [(32767, 5), (5, 32767), (16384, 3), (3, 4097)])
+def test_extreme_aspect_ratios(hip_ctx, oracle, W, H):
+    """The reference's coordinate limit is 32767 (int16 in the hysteresis stack, canny_dete.cxx:617-621): maximum widths/heights."""
+    rng = np.random.default_rng(W + 7 * H)
+    img = rng.integers(0, 256, size=(H, W), dtype=np.uint8)
+    assert (hip_ctx.edge_dete(img) == oracle.edge_dete(img)[0]).all()
+    rc, exp = oracle.canny(img, 40.0, 90.0)
+    assert rc == 0 and (hip_ctx.canny(img, 40.0, 90.0) == exp).all()
+    from compv_amd import capi
+    with pytest.raises(capi.CompvHipError) as e:
+        hip_ctx.canny(np.zeros((4, 32768), np.uint8), 40.0, 90.0)     # one past the limit
+    assert e.value.code == capi.E_INVALID_PARAMETER
