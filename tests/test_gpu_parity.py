@@ -510,3 +510,24 @@ def test_extreme_aspect_ratios(hip_ctx, oracle, W, H):
     with pytest.raises(capi.CompvHipError) as e:
         hip_ctx.canny(np.zeros((4, 32768), np.uint8), 40.0, 90.0)     # one past the limit
     assert e.value.code == capi.E_INVALID_PARAMETER
+
+
+def test_houghsht_line_buffer_contract(hip_ctx, oracle):
+    """C-ABI contract of the caller's line buffer (include/compv_hip.h): too small -> COMPVHIP_E_OUT_OF_BOUND, *n = lines found, the
+    first `cap` (strongest) lines written; and more lines than the library's initial device key buffer (65 536) are handled."""
+    import ctypes as C
+    from compv_amd import capi
+    W, H, deg = 1282, 720, 0.25
+    rng = np.random.default_rng(5)
+    edges = np.where(rng.random((H, W)) < 0.3, 0xff, 0).astype(np.uint8)
+    acc = oracle.sht_acc(edges, deg)
+    exp = oracle.sht_lines_from_acc(acc, W, H, deg, 1)
+    assert len(exp) > (1 << 16)                                # more than the initial device key capacity
+    got = hip_ctx.houghsht(edges, deg, 1)                      # the wrapper retries with the reported size
+    assert _lines_tuple(got) == _orc_tuple(exp)
+    cap = 7
+    lines = np.zeros(cap, capi.LINE_DTYPE)
+    n = C.c_size_t(0)
+    rc = hip_ctx.lib.compvhip_houghsht_u8(hip_ctx.h, edges.ctypes.data, W, H, W, 1.0, deg, 1, 0, lines.ctypes.data, cap, C.byref(n), None, 0)
+    assert rc == capi.E_OUT_OF_BOUND and n.value == len(exp)
+    assert _lines_tuple(lines) == _orc_tuple(exp[:cap])
