@@ -192,7 +192,9 @@ COMPVHIP_API int compvhip_plan_edge_dete(compvhip_plan* plan, const uint8_t* d_i
 /* SHT on the edge maps produced by the last compvhip_plan_canny() of this plan (uses its 1-bit edge masks, no byte
  * re-read) or, when d_edges != NULL, on arbitrary device edge maps.  Results stay on the device:
  * d_lines: frames * lineCap compvhip_line (sorted as compvhip_houghsht_u8), d_counts: frames int32 (lines found,
- * before clipping to lineCap). */
+ * before clipping to lineCap).  The call is asynchronous and cannot grow its buffers after the fact: when d_counts[f] exceeds
+ * max(lineCap, 65536) the device key buffer overflowed and frame f's lines are an arbitrary subset -- call again with
+ * lineCap >= d_counts[f] (the host entry point compvhip_houghsht_u8 does that by itself). */
 COMPVHIP_API int compvhip_plan_houghsht(compvhip_plan* plan, const uint8_t* d_edges, int threshold, int maxLines,
                                         compvhip_line* d_lines, size_t lineCap, int32_t* d_counts, void* stream);
 
