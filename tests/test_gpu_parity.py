@@ -531,3 +531,28 @@ def test_houghsht_line_buffer_contract(hip_ctx, oracle):
     rc = hip_ctx.lib.compvhip_houghsht_u8(hip_ctx.h, edges.ctypes.data, W, H, W, 1.0, deg, 1, 0, lines.ctypes.data, cap, C.byref(n), None, 0)
     assert rc == capi.E_OUT_OF_BOUND and n.value == len(exp)
     assert _lines_tuple(lines) == _orc_tuple(exp[:cap])
+
+
+def test_plan_small_line_capacity_keeps_the_strongest(hip_ctx, oracle):
+    """Plan API: lineCap smaller than the number of lines -> d_counts reports the lines found, d_lines holds the strongest lineCap."""
+    import torch
+    from compv_amd import capi
+    W, H, cap = 640, 480, 16
+    img = synth_frame(W, H, 31337)
+    rc, e = oracle.canny(img, 59.0, 119.0)
+    exp = oracle.sht(e, 1.0, 40)
+    assert len(exp) > cap
+    dev = torch.device("cuda:0")
+    d_in = torch.from_numpy(img[None]).to(dev)
+    d_edges = torch.empty_like(d_in)
+    d_lines = torch.zeros((1, cap, 5), dtype=torch.int32, device=dev)
+    d_counts = torch.zeros(1, dtype=torch.int32, device=dev)
+    plan = capi.Plan(hip_ctx, W, H, W, 1, 1.0)
+    try:
+        plan.pipeline(d_in.data_ptr(), 59.0, 119.0, 40, 0, d_edges.data_ptr(), d_lines.data_ptr(), cap, d_counts.data_ptr())
+        torch.cuda.synchronize()
+        assert int(d_counts.cpu()[0]) == len(exp)
+        rec = np.frombuffer(d_lines.cpu().numpy().tobytes(), dtype=capi.LINE_DTYPE)
+        assert _lines_tuple(rec) == _orc_tuple(exp[:cap])
+    finally:
+        plan.close()
