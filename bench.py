@@ -227,6 +227,9 @@ def main():
         roofline = roof(dom, alg.get(dom, F * W * H * 1.0)) if dom else None
         if roofline:
             roofline["timing"] = "HIP events on the launch stream around this kernel in every timed step"
+            if dom == "sht_vote_kernel":
+                roofline["note"] = ("the voting kernel is LDS-atomic bound (83 % LDS-busy, profiles/), not HBM bound; the HBM fraction is "
+                                    "reported because the contract prices every kernel of this path against the HBM roofline")
         rc = roof("canny_tile_kernel", alg["canny_tile_kernel"])
         if rc:
             rc["timing"] = "HIP events in the timed steps"
