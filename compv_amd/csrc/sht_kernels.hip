@@ -165,6 +165,7 @@ __global__ __launch_bounds__(kCompactThreads) void sht_compact_kernel(ShtArgs a)
 // sht_compact_kernel: 64 consecutive entries are 64 raster positions apart), so every wave streams its own 64-edge chunks
 // with plain coalesced loads and the main loop has NO workgroup barrier: the LDS atomic pipe never drains.
 constexpr int kVoteUnroll = 4;                           // 64-edge chunks in flight per wave
+constexpr int kVoteFramesInL2 = 2;                       // frames per XCD whose theta groups are in flight together
 
 size_t sht_vote_lds_bytes(int R, int tg)
 {
@@ -184,9 +185,21 @@ __global__ __launch_bounds__(kShtVoteThreads) void sht_vote_kernel(ShtArgs a)
 	// instruction (fixed pair, 64 different rho) can spread over all banks ([R][2] would only ever touch half).
 	const int Rp = (R + 31) & ~31;
 	uint32_t* hist = smem;
-	const int frame = blockIdx.x; // frames fastest: the launch walks the theta groups in groupOrder (expensive first) for all frames
-	const int shard = blockIdx.z;
-	const int t0 = a.groupOrder[blockIdx.y] * kShtThetaPerGroup;
+	// XCD-aware placement (workgroup b runs on XCD b % 8, each XCD has its own L2): frame f is always voted on XCD f % 8, so an
+	// XCD's L2 only ever holds the edge lists of ceil(frames/8) frames, which its resident workgroups (different theta groups of those
+	// frames) re-read from L2 instead of HBM.  Within an XCD the theta groups are walked in groupOrder (expensive first), frames fastest.
+	// The XCD's frames are taken kVoteFramesInL2 at a time (2 x 1.5 MB of edges at 4K against a 4 MB L2).
+	const int framesPerXcd = (a.frames + 7) >> 3;
+	const int groups = (a.T + kShtThetaPerGroup - 1) / kShtThetaPerGroup;
+	const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+	const int perSub = kVoteFramesInL2 * groups;
+	const int sub = k / perSub, rem = k - sub * perSub;
+	const int grank = rem / kVoteFramesInL2;
+	const int fi = sub * kVoteFramesInL2 + (rem - grank * kVoteFramesInL2);
+	const int frame = fi * 8 + xcd;
+	if (fi >= framesPerXcd || frame >= a.frames) return; // padding workgroup
+	const int shard = blockIdx.y;
+	const int t0 = a.groupOrder[grank] * kShtThetaPerGroup;
 	const int tid = threadIdx.x;
 
 	const int nthreads = blockDim.x; // 256..1024 (launch_sht_vote)
@@ -522,7 +535,8 @@ hipError_t launch_sht_vote(const ShtArgs& a, int frames, hipStream_t stream)
 		if (e != hipSuccess) return e;
 	}
 	const int groups = (a.T + tg - 1) / tg;
-	dim3 grid(frames, groups, a.shards);
+	const int fx = (frames + 7) / 8, subs = (fx + kVoteFramesInL2 - 1) / kVoteFramesInL2;
+	dim3 grid(8 * subs * kVoteFramesInL2 * groups, a.shards); // see the XCD-aware (frame, theta group) decoding in the kernel
 	static const int threads = [] { const char* e = getenv("COMPVHIP_SHT_VOTE_THREADS"); const int v = e ? atoi(e) : 0; return (v >= 64 && v <= 1024 && (v % 64) == 0) ? v : kShtVoteThreads; }(); // tuning knob
 	if (tg == 4) hipLaunchKernelGGL((sht_vote_kernel<4, false>), grid, dim3(threads), lds, stream, a);
 	else if (sc) hipLaunchKernelGGL((sht_vote_kernel<2, true>), grid, dim3(threads), lds, stream, a);
