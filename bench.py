@@ -28,6 +28,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+TIMING_MODES = {"sht_vote_kernel": 3, "canny_tile_kernel": 4}   # compvhip_plan_set_timing: HIP events around one kernel only
 T_LOW, T_HIGH = 59.0, 119.0
 THETA_DEG, SHT_THRESHOLD = 1.0, 100
 
@@ -88,6 +89,11 @@ def main():
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-events", action="store_true", help="experiment: no per-kernel HIP events in the timed steps")
+    ap.add_argument("--reps", type=int, default=5, help="repetitions of the timed K-step loop; the MEDIAN repetition is reported")
+    ap.add_argument("--sync-steps", action="store_true", help="experiment: the synchronous step (one host round trip per step)")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise torch.distributed (nccl = RCCL) even for a world of one rank: exercises init / barrier / all_reduce / "
+                         "all_gather on real hardware where only one GPU is available")
     args = ap.parse_args()
 
     import torch
@@ -96,7 +102,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist_on = world > 1
+    dist_on = world > 1 or (args.force_dist and "RANK" in os.environ)
     if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -131,8 +137,24 @@ def main():
         plan.pipeline(d_in.data_ptr(), T_LOW, T_HIGH, SHT_THRESHOLD, 0, d_edges.data_ptr(), d_lines.data_ptr(), line_cap,
                       d_counts.data_ptr(), stream)
 
-    for _ in range(args.warmup):
-        step()
+    def run_steps(k):
+        """k steps.  Default: each step is enqueued with compvhip_plan_pipeline_async and waited for while the NEXT one is already
+        running (the hysteresis convergence flag is read one step late; a miss replays that step) -- no host round trip per step."""
+        if args.sync_steps:
+            for _ in range(k):
+                step()
+            return
+        prev = None
+        for _ in range(k):
+            t = plan.pipeline_async(d_in.data_ptr(), T_LOW, T_HIGH, SHT_THRESHOLD, 0, d_edges.data_ptr(), d_lines.data_ptr(), line_cap,
+                                    d_counts.data_ptr(), stream)
+            if prev is not None:
+                plan.wait(prev)
+            prev = t
+        if prev is not None:
+            plan.wait(prev)
+
+    run_steps(args.warmup)
     torch.cuda.synchronize()
     # which kernel dominates a step?  One extra untimed, fully instrumented step decides which single kernel carries HIP events
     # during the timed steps (events around every launch would cost ~0.1 ms per step, around two kernels ~0.04 ms).
@@ -150,7 +172,7 @@ def main():
 
     # HIP events on the launch stream around the DOMINANT kernel during the timed steps (the roofline kernel); the full per-kernel
     # breakdown, and the Canny tile kernel's duration when it is not the dominant one, come from a second, untimed, instrumented pass.
-    timed_mode = {"sht_vote_kernel": 3, "canny_tile_kernel": 4}.get(dominant, 2)
+    timed_mode = TIMING_MODES.get(dominant, 2)
     plan.set_timing(0 if args.no_kernel_events else timed_mode)
     per_kernel = {}
 
@@ -160,19 +182,22 @@ def main():
             a[0] += ms
             a[1] += 1
 
-    if dist_on:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-        # the pipeline call ends with a stream sync (hysteresis convergence check); collect this step's events
-        collect(per_kernel)
-    torch.cuda.synchronize()
-    if dist_on:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    elapsed = sharding.max_over_ranks(elapsed, dist if dist_on else None, dev)
+    # The timed region is EXACTLY K steps between barrier + synchronize brackets; it is repeated `reps` times inside this run and
+    # the MEDIAN repetition is reported (one 20-step region lasts ~20 ms: a single one is a thin measurement).
+    rep_elapsed = []
+    for _ in range(max(1, args.reps)):
+        if dist_on:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run_steps(args.steps)
+        torch.cuda.synchronize()
+        if dist_on:
+            dist.barrier()
+        e = time.perf_counter() - t0
+        rep_elapsed.append(sharding.max_over_ranks(e, dist if dist_on else None, dev))
+        collect(per_kernel)   # the dominant kernel's events of this repetition's K steps (read after the closing bracket)
+    elapsed = sorted(rep_elapsed)[len(rep_elapsed) // 2]
 
     breakdown = {}
     if rank == 0 and not args.no_kernel_events:
@@ -181,6 +206,8 @@ def main():
             step()
             collect(breakdown)
     plan.set_timing(0)
+    if int(d_counts.max().item()) > line_cap:
+        raise RuntimeError("a frame produced %d lines, more than the line capacity %d: its line set would be an arbitrary subset" % (int(d_counts.max().item()), line_cap))
 
     counts = d_counts.cpu().numpy()
     # the only result exchange of the job: all-gather of the tiny per-frame line counts, outside the timed region
@@ -188,13 +215,15 @@ def main():
         all_counts = sharding.gather_frame_results([int(c) for c in counts], dist if dist_on else None, dev)
     except Exception:  # reporting only: never let it hide the throughput number
         all_counts = None
-    total_px = world * F * W * H * args.steps
+    n_ranks = dist.get_world_size() if dist_on else 1
+    total_px = n_ranks * F * W * H * args.steps
     value = total_px / elapsed / 1e6
 
     if rank == 0:
         R = 2 * (W + H) + 1
         T = 180
-        kern = {k: {"ms_per_launch": v[0] / v[1], "launches_per_step": v[1] / args.steps, "ms_per_step": v[0] / args.steps}
+        nsteps_timed = args.steps * max(1, args.reps)
+        kern = {k: {"ms_per_launch": v[0] / v[1], "launches_per_step": v[1] / nsteps_timed, "ms_per_step": v[0] / nsteps_timed}
                 for k, v in per_kernel.items()}
         dom = max(kern.items(), key=lambda kv: kv[1]["ms_per_step"])[0] if kern else None
         # algorithmic bytes per frame: Sobel->Canny 1 B/px read (+1 B/px write reported separately);
@@ -204,13 +233,17 @@ def main():
             "sht_vote_kernel": F * (W * H + R * T * 4.0),
         }
 
+        traffic_src = [None]
+
         def measured_traffic(name):
-            # HBM bytes per launch from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, KiB; see
-            # tools/traffic_from_pmc.py for the calibration) -- only valid for the workload they were collected on
+            # HBM bytes per launch from the COMMITTED rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, KiB; see
+            # tools/traffic_from_pmc.py for the calibration) -- not a counter of this run, and only valid for the workload they
+            # were collected on; the JSON line says which file the number comes from
             try:
                 rounds = sorted(d for d in os.listdir(os.path.join(ROOT, "profiles")) if os.path.exists(os.path.join(ROOT, "profiles", d, "traffic.json")))
                 t = json.load(open(os.path.join(ROOT, "profiles", rounds[-1], "traffic.json")))
-                if t["workload"] == {"W": W, "H": H, "frames": F}:
+                if t["workload"] == {"W": W, "H": H, "frames": F} and name in t["kernels"]:
+                    traffic_src[0] = "committed PMC pass profiles/%s/traffic.json (rocprofv3 --pmc, separate runs; not measured in this run)" % rounds[-1]
                     return t["kernels"][name]["hbm_bytes"]
             except Exception:
                 pass
@@ -221,9 +254,10 @@ def main():
                 return None
             ms = kern[name]["ms_per_launch"]
             ach = nbytes / (ms * 1e-3) / 1e9
+            tr = measured_traffic(name)
             return {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": measured_traffic(name), "ms_per_launch": round(ms, 4),
-                    "algorithmic_bytes_per_launch": int(nbytes)}
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": tr, "traffic_source": traffic_src[0] if tr is not None else None,
+                    "ms_per_launch": round(ms, 4), "algorithmic_bytes_per_launch": int(nbytes)}
         roofline = roof(dom, alg.get(dom, F * W * H * 1.0)) if dom else None
         if roofline:
             roofline["timing"] = "HIP events on the launch stream around this kernel in every timed step"
@@ -245,7 +279,11 @@ def main():
             "metric": "Mpixels/s Sobel->Canny->HoughSHT on 4K uint8",
             "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "reps": len(rep_elapsed), "reps_ms_per_step": [round(e / args.steps * 1e3, 4) for e in rep_elapsed],
+            "timing": "median of %d repetitions of the K-step region (each: barrier + synchronize, K steps, synchronize + barrier, MAX over ranks)" % len(rep_elapsed),
+            "step_mode": "synchronous (host reads the hysteresis flag every step)" if args.sync_steps else "pipelined (compvhip_plan_pipeline_async: step k's hysteresis flag is read while step k+1 runs)",
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+            "dist_backend": (dist.get_backend() if dist_on else None),
             "config": {"workload": "batched %dx%d uint8 frames, Sobel3x3 -> Canny(59,119) -> HoughSHT(rho=1, theta=1deg, thr=100)" % (W, H),
                        "frames_per_gpu": F, "global_frames": world * F,
                        "parallelism": "frames sharded across %d GPU(s), no data-path collective" % world},

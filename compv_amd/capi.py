@@ -37,6 +37,7 @@ EXPORTS = [
     "compvhip_plan_set_timing", "compvhip_plan_get_timing", "compvhip_plan_acc_export", "compvhip_plan_edge_dete",
     "compvhip_houghkht_u8", "compvhip_grayscale_u8", "compvhip_otsu_u8", "compvhip_plan_grayscale", "compvhip_plan_otsu",
     "compvhip_gauss_kernel_fixedpoint", "compvhip_convlt1_fixedpoint_u8", "compvhip_plan_convlt1_fixedpoint", "compvhip_plan_to_cartesian",
+    "compvhip_plan_pipeline_async", "compvhip_plan_wait",
 ]
 
 
@@ -110,6 +111,8 @@ def load():
     L.compvhip_convlt1_fixedpoint_u8.argtypes = [vp, vp, sz, sz, sz, vp, vp, sz, vp, sz]
     L.compvhip_plan_convlt1_fixedpoint.argtypes = [vp, vp, vp, vp, sz, vp, vp]
     L.compvhip_plan_pipeline.argtypes = [vp, vp, C.c_float, C.c_float, i32, i32, vp, vp, sz, vp, vp]
+    L.compvhip_plan_pipeline_async.argtypes = [vp, vp, C.c_float, C.c_float, i32, i32, vp, vp, sz, vp, vp, C.POINTER(i32)]
+    L.compvhip_plan_wait.argtypes = [vp, i32]
     L.compvhip_plan_acc.argtypes = [vp, sz, C.POINTER(vp), C.POINTER(sz), C.POINTER(sz), C.POINTER(sz)]
     L.compvhip_plan_acc_export.argtypes = [vp, sz, vp, sz, vp]
     L.compvhip_plan_edge_counts.argtypes = [vp, C.POINTER(vp)]
@@ -280,6 +283,16 @@ class Plan:
     def pipeline(self, d_in, tLow, tHigh, threshold, max_lines, d_edges, d_lines, line_cap, d_counts, stream=0):
         self.ctx._chk(self.lib.compvhip_plan_pipeline(self.h, d_in, tLow, tHigh, threshold, max_lines, d_edges, d_lines, line_cap,
                                                       d_counts, stream))
+
+    def pipeline_async(self, d_in, tLow, tHigh, threshold, max_lines, d_edges, d_lines, line_cap, d_counts, stream=0):
+        """Enqueue one step without waiting for its hysteresis flag; returns the ticket for wait()."""
+        t = C.c_int(-1)
+        self.ctx._chk(self.lib.compvhip_plan_pipeline_async(self.h, d_in, tLow, tHigh, threshold, max_lines, d_edges, d_lines, line_cap,
+                                                            d_counts, stream, C.byref(t)))
+        return t.value
+
+    def wait(self, ticket):
+        self.ctx._chk(self.lib.compvhip_plan_wait(self.h, ticket))
 
     def acc(self, frame):
         p, R, T, pitch = C.c_void_p(), C.c_size_t(), C.c_size_t(), C.c_size_t()

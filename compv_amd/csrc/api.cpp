@@ -24,7 +24,8 @@ using namespace compvhip;
 namespace {
 constexpr int kMaxRounds = 4096;       // hysteresis resolve rounds before giving up (one per 64-row band crossed)
 constexpr int kSpecRounds = 3;         // rounds enqueued speculatively between two convergence checks
-constexpr size_t kMinLineCap = 1u << 10;  // per-frame line-key slots are sized by the caller's lineCap (grown on demand)
+constexpr size_t kMinLineCap = 1u << 16;  // per-frame line-key slots: max(caller's lineCap, 65536), clamped to R*T (include/compv_hip.h, compvhip_plan_houghsht)
+constexpr int kAsyncDepth = 4;            // outstanding compvhip_plan_pipeline_async steps per plan
 } // namespace
 
 struct compvhip_ctx {
@@ -58,8 +59,10 @@ struct compvhip_plan {
 	int tilesX = 0, tilesY = 0, wb = 0;
 	size_t bitsFrameStride = 0;
 	uint32_t* ebits = nullptr; uint32_t* ubits = nullptr;
-	int* flags = nullptr; int* hFlags = nullptr; // device / pinned host
+	int* counters = nullptr;  // ONE device allocation zeroed by ONE memset per step: [edgeCounts frames][lineCounts frames][flags kMaxRounds]
+	int* flags = nullptr; int* hFlags = nullptr; // device (inside counters) / pinned host (kAsyncDepth + 1 slots)
 	int roundsUsed = 0;
+	bool countersFresh = false; // the step's memset already zeroed the edge/line counts (no second fill in front of the SHT stage)
 	int2* thrDev = nullptr; unsigned int* sums = nullptr;
 	uint8_t* tmpOut = nullptr; // aliasing (in == out) scratch
 	bool bitsValid = false;
@@ -76,6 +79,12 @@ struct compvhip_plan {
 	void* sortTemp = nullptr; size_t sortTempBytes = 0;
 	int cellBits = 0, strengthBits = 16, keyBits = 0;
 	int shards = 1;
+	// asynchronous steps (compvhip_plan_pipeline_async / compvhip_plan_wait)
+	struct AsyncStep {
+		bool used = false; hipEvent_t done = nullptr; hipStream_t stream = nullptr;
+		const uint8_t* d_in = nullptr; float tLow = 0.f, tHigh = 0.f; int threshold = 0, maxLines = 0; uint8_t* d_edges = nullptr;
+		compvhip_line* d_lines = nullptr; size_t lineCap = 0; int32_t* d_counts = nullptr;
+	} steps[kAsyncDepth];
 	// timing
 	int timing = 0; // 0 off, 1 every kernel, 2 canny_tile + sht_vote, 3 sht_vote only, 4 canny_tile only
 	std::vector<hipEvent_t> eventPool;
@@ -226,7 +235,7 @@ int ensureSht(compvhip_plan* p)
 	compvhip_ctx* ctx = p->ctx;
 	// a previous attempt may have failed half way (out of memory): start from a clean slate instead of leaking its buffers
 	dfree(ctx, p->sinQ); dfree(ctx, p->cosQ); dfree(ctx, p->cosT); dfree(ctx, p->invSinT); dfree(ctx, p->groupOrder);
-	dfree(ctx, p->edges); dfree(ctx, p->edgeCounts); dfree(ctx, p->acc); dfree(ctx, p->lineCounts);
+	dfree(ctx, p->edges); dfree(ctx, p->acc);
 	size_t R, T; float step;
 	int rc = shtDims(p->W, p->H, p->thetaDeg, &R, &T, &step);
 	if (rc) return fail(ctx, rc, "invalid SHT geometry");
@@ -281,11 +290,8 @@ int ensureSht(compvhip_plan* p)
 	}
 	p->edgeCap = p->W * p->H;
 	HIPCHK(ctx, dmalloc(ctx, &p->edges, p->edgeCap * p->frames));
-	HIPCHK(ctx, dmalloc(ctx, &p->edgeCounts, p->frames));
-	HIPCHK(ctx, hipMemset(p->edgeCounts, 0, sizeof(int) * p->frames));
 	HIPCHK(ctx, dmalloc(ctx, &p->acc, p->accFrameStride * p->frames));
 	HIPCHK(ctx, hipMemset(p->acc, 0, sizeof(uint16_t) * p->accFrameStride * p->frames)); // rows [Rp, accPitch) stay zero for ever
-	HIPCHK(ctx, dmalloc(ctx, &p->lineCounts, p->frames));
 	// line key = frameTag | strength (strengthBits) | cell index (cellBits): see sht_nms_kernel. A cell of column theta counts the
 	// pixels with (x*cosQ + y*sinQ) in one 65536-wide interval; max(|cosQ|,|sinQ|) >= 46340 so every x (or every y) contributes at
 	// most 2 pixels: count <= 2*max(W,H). Fewer key bits = fewer radix-sort passes.
@@ -297,6 +303,7 @@ int ensureSht(compvhip_plan* p)
 	int frameBits = 0;
 	while ((static_cast<size_t>(1) << frameBits) < p->frames) frameBits++;
 	p->keyBits = frameBits + p->strengthBits + p->cellBits;
+	if (p->cellBits > 31) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "theta step too small: the accumulator has 2^31 cells or more"); // 32-bit cell masks in the kernels
 	if (p->keyBits > 64) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "too many frames x accumulator cells for a 64-bit line key");
 	p->shtReady = true;
 	return COMPVHIP_OK;
@@ -370,7 +377,9 @@ int enqueueCanny(compvhip_plan* p, const uint8_t* d_in, uint8_t* d_out, int tLow
 		Stamp s(p, st, "canny_mean_thresholds");
 		HIPCHK(ctx, launch_mean_thresholds(d_in, a.W, a.H, a.S, a.inFrameStride, static_cast<int>(p->frames), fLow, fHigh, p->sums, p->thrDev, st));
 	}
-	HIPCHK(ctx, hipMemsetAsync(p->flags, 0, sizeof(int) * kMaxRounds, st));
+	// ONE fill per step: edge counts, line counts and the hysteresis round flags live in one allocation
+	HIPCHK(ctx, hipMemsetAsync(p->counters, 0, sizeof(int) * (2 * p->frames + kMaxRounds), st));
+	p->countersFresh = true;
 	p->roundsUsed = 0;
 	{
 		Stamp s(p, st, "canny_tile_kernel");
@@ -496,10 +505,12 @@ int compvhip_plan_create(compvhip_ctx* ctx, size_t W, size_t H, size_t S, size_t
 	do {
 		if (dmalloc(ctx, &p->ebits, p->bitsFrameStride * frames) != hipSuccess) { rc = COMPVHIP_E_OUT_OF_MEMORY; break; }
 		if (dmalloc(ctx, &p->ubits, p->bitsFrameStride * frames) != hipSuccess) { rc = COMPVHIP_E_OUT_OF_MEMORY; break; }
-		if (dmalloc(ctx, &p->flags, kMaxRounds) != hipSuccess) { rc = COMPVHIP_E_OUT_OF_MEMORY; break; }
+		if (dmalloc(ctx, &p->counters, 2 * frames + kMaxRounds) != hipSuccess) { rc = COMPVHIP_E_OUT_OF_MEMORY; break; }
+		p->edgeCounts = p->counters; p->lineCounts = p->counters + frames; p->flags = p->counters + 2 * frames;
+		if (hipMemset(p->counters, 0, sizeof(int) * (2 * frames + kMaxRounds)) != hipSuccess) { rc = COMPVHIP_E_HIP; break; }
 		if (dmalloc(ctx, &p->thrDev, frames) != hipSuccess) { rc = COMPVHIP_E_OUT_OF_MEMORY; break; }
 		if (dmalloc(ctx, &p->sums, frames) != hipSuccess) { rc = COMPVHIP_E_OUT_OF_MEMORY; break; }
-		if (hipHostMalloc(reinterpret_cast<void**>(&p->hFlags), sizeof(int) * 4) != hipSuccess) { rc = COMPVHIP_E_OUT_OF_MEMORY; break; }
+		if (hipHostMalloc(reinterpret_cast<void**>(&p->hFlags), sizeof(int) * (kAsyncDepth + 1)) != hipSuccess) { rc = COMPVHIP_E_OUT_OF_MEMORY; break; }
 	} while (0);
 	if (rc) { compvhip_plan_destroy(p); return fail(ctx, rc, "plan allocation"); }
 	*out = p;
@@ -513,12 +524,13 @@ void compvhip_plan_destroy(compvhip_plan* p)
 	(void)hipSetDevice(ctx->device);
 	timelineClear(p);
 	for (hipEvent_t e : p->eventPool) (void)hipEventDestroy(e);
-	dfree(ctx, p->ebits); dfree(ctx, p->ubits); dfree(ctx, p->flags); dfree(ctx, p->thrDev); dfree(ctx, p->sums); dfree(ctx, p->tmpOut);
+	for (auto& stp : p->steps) if (stp.done) (void)hipEventDestroy(stp.done);
+	dfree(ctx, p->ebits); dfree(ctx, p->ubits); dfree(ctx, p->counters); dfree(ctx, p->thrDev); dfree(ctx, p->sums); dfree(ctx, p->tmpOut);
 	if (p->hFlags) (void)hipHostFree(p->hFlags);
 	dfree(ctx, p->hist); dfree(ctx, p->otsu); dfree(ctx, p->blurTmp);
 	dfree(ctx, p->cosT); dfree(ctx, p->invSinT);
-	dfree(ctx, p->sinQ); dfree(ctx, p->cosQ); dfree(ctx, p->groupOrder); dfree(ctx, p->edges); dfree(ctx, p->edgeCounts); dfree(ctx, p->acc);
-	dfree(ctx, p->keysA); dfree(ctx, p->keysB); dfree(ctx, p->lineCounts);
+	dfree(ctx, p->sinQ); dfree(ctx, p->cosQ); dfree(ctx, p->groupOrder); dfree(ctx, p->edges); dfree(ctx, p->acc);
+	dfree(ctx, p->keysA); dfree(ctx, p->keysB);
 	dfree(ctx, p->sortTemp);
 	delete p;
 }
@@ -533,14 +545,15 @@ int compvhip_plan_set_timing(compvhip_plan* p, int enabled)
 int compvhip_plan_get_timing(compvhip_plan* p, const char** names, float* ms, int cap)
 {
 	if (!p) return COMPVHIP_E_INVALID_PARAMETER;
-	if (!p->timeline.empty()) { (void)hipDeviceSynchronize(); timelineCollect(p); }
+	(void)hipSetDevice(p->ctx->device);
+	if (!p->timeline.empty()) { (void)hipEventSynchronize(p->timeline.back().b); timelineCollect(p); } // events of one stream complete in order
 	const int n = std::min<int>(cap, static_cast<int>(p->timingMs.size()));
 	for (int i = 0; i < n; ++i) { if (names) names[i] = p->timingNames[i].c_str(); if (ms) ms[i] = p->timingMs[i]; }
 	return n;
 }
 
 static int planCannyImpl(compvhip_plan* p, const uint8_t* d_in, float tLow, float tHigh, int ksize, int type, uint8_t* d_edges, hipStream_t st,
-                         bool waitConverged)
+                         bool waitConverged, bool clearTimeline = true)
 {
 	compvhip_ctx* ctx = p->ctx;
 	if (!d_in || !d_edges) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "null frame pointer");
@@ -548,7 +561,7 @@ static int planCannyImpl(compvhip_plan* p, const uint8_t* d_in, float tLow, floa
 	int rc = validateCannyParams(ctx, tLow, tHigh, ksize, type, &lo, &hi);
 	if (rc) return rc;
 	HIPCHK(ctx, hipSetDevice(ctx->device));
-	if (p->timing) timelineClear(p);
+	if (p->timing && clearTimeline) timelineClear(p);
 	uint8_t* out = d_edges;
 	const size_t bytes = p->S * p->H * p->frames;
 	const bool alias = (d_in < d_edges + bytes) && (d_edges < d_in + bytes);
@@ -692,6 +705,8 @@ static int planShtImpl(compvhip_plan* p, const uint8_t* d_edges, int threshold, 
 		p->bitsValid = false; // U masks no longer match
 	}
 	ShtArgs a = shtArgs(p, threshold);
+	if (!p->countersFresh) HIPCHK(ctx, hipMemsetAsync(p->counters, 0, sizeof(int) * 2 * p->frames, st)); // edge + line counts
+	p->countersFresh = false;
 	{ Stamp s(p, st, "sht_compact_kernel"); HIPCHK(ctx, launch_sht_compact(a, frames, st)); }
 	{ Stamp s(p, st, "sht_vote_kernel"); HIPCHK(ctx, launch_sht_vote(a, frames, st)); }
 	{ Stamp s(p, st, "sht_nms_kernel"); HIPCHK(ctx, launch_sht_nms(a, frames, st)); }
@@ -748,6 +763,53 @@ int compvhip_plan_pipeline(compvhip_plan* p, const uint8_t* d_in, float tLow, fl
 	return COMPVHIP_OK;
 }
 
+// The step without its host round trip: the hysteresis flag of the last speculative round travels to a pinned host slot behind
+// the step's kernels and is looked at by compvhip_plan_wait(), normally while the NEXT step is already running.
+int compvhip_plan_pipeline_async(compvhip_plan* p, const uint8_t* d_in, float tLow, float tHigh, int threshold, int maxLines, uint8_t* d_edges,
+                                 compvhip_line* d_lines, size_t lineCap, int32_t* d_counts, void* stream, int* ticket)
+{
+	if (!p || !ticket) return COMPVHIP_E_INVALID_PARAMETER;
+	compvhip_ctx* ctx = p->ctx;
+	*ticket = -1;
+	int slot = -1;
+	for (int i = 0; i < kAsyncDepth; ++i) if (!p->steps[i].used) { slot = i; break; }
+	if (slot < 0) return fail(ctx, COMPVHIP_E_INVALID_STATE, "too many steps in flight: call compvhip_plan_wait first");
+	const size_t bytes = p->S * p->H * p->frames;
+	if (d_in && d_edges && (d_in < d_edges + bytes) && (d_edges < d_in + bytes))
+		return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "the asynchronous step needs distinct input and edge buffers"); // a replay re-reads d_in
+	hipStream_t st = static_cast<hipStream_t>(stream);
+	compvhip_plan::AsyncStep& stp = p->steps[slot];
+	HIPCHK(ctx, hipSetDevice(ctx->device));
+	if (!stp.done) HIPCHK(ctx, hipEventCreateWithFlags(&stp.done, hipEventDisableTiming));
+	// timing events of asynchronous steps accumulate until compvhip_plan_get_timing reads them (nothing is cleared per step)
+	int rc = planCannyImpl(p, d_in, tLow, tHigh, 3, COMPVHIP_CANNY_THRESHOLD_COMPARE_TO_GRADIENT, d_edges, st, false, false);
+	if (rc) return rc;
+	rc = planShtImpl(p, nullptr, threshold, maxLines, d_lines, lineCap, d_counts, st, false);
+	if (rc) return rc;
+	HIPCHK(ctx, hipMemcpyAsync(p->hFlags + 1 + slot, p->flags + (p->roundsUsed - 1), sizeof(int), hipMemcpyDeviceToHost, st));
+	HIPCHK(ctx, hipEventRecord(stp.done, st));
+	stp.used = true; stp.stream = st;
+	stp.d_in = d_in; stp.tLow = tLow; stp.tHigh = tHigh; stp.threshold = threshold; stp.maxLines = maxLines; stp.d_edges = d_edges;
+	stp.d_lines = d_lines; stp.lineCap = lineCap; stp.d_counts = d_counts;
+	*ticket = slot;
+	return COMPVHIP_OK;
+}
+
+int compvhip_plan_wait(compvhip_plan* p, int ticket)
+{
+	if (!p || ticket < 0 || ticket >= kAsyncDepth || !p->steps[ticket].used) return COMPVHIP_E_INVALID_PARAMETER;
+	compvhip_ctx* ctx = p->ctx;
+	compvhip_plan::AsyncStep& stp = p->steps[ticket];
+	HIPCHK(ctx, hipSetDevice(ctx->device));
+	HIPCHK(ctx, hipEventSynchronize(stp.done));
+	stp.used = false;
+	if (p->hFlags[1 + ticket] == 0) return COMPVHIP_OK; // the speculative rounds reached the fixed point (the usual case)
+	// Rare: the hysteresis of this step needed more rounds than were enqueued, and a later step may already have reused the
+	// plan's masks.  Let the stream drain and run the step again, synchronously, from its (unmodified) input.
+	HIPCHK(ctx, hipStreamSynchronize(stp.stream));
+	return compvhip_plan_pipeline(p, stp.d_in, stp.tLow, stp.tHigh, stp.threshold, stp.maxLines, stp.d_edges, stp.d_lines, stp.lineCap, stp.d_counts, stp.stream);
+}
+
 int compvhip_plan_to_cartesian(compvhip_plan* p, const compvhip_line* d_lines, const int32_t* d_counts, size_t lineCap, float* d_cart, void* stream)
 {
 	if (!p) return COMPVHIP_E_INVALID_PARAMETER;
@@ -776,6 +838,7 @@ int compvhip_plan_acc_export(compvhip_plan* p, size_t frame, int32_t* d_out, siz
 {
 	if (!p || !p->shtReady || frame >= p->frames || !d_out || outStride < p->T) return COMPVHIP_E_INVALID_PARAMETER;
 	compvhip_ctx* ctx = p->ctx;
+	HIPCHK(ctx, hipSetDevice(ctx->device));
 	HIPCHK(ctx, launch_sht_acc_transpose(p->acc + frame * p->accFrameStride, static_cast<int>(p->R), static_cast<int>(p->T), p->accPitch, d_out, outStride,
 	                                     static_cast<hipStream_t>(stream)));
 	return COMPVHIP_OK;

@@ -20,7 +20,7 @@ def frame_seed(frame_index):
 
 def max_over_ranks(value, dist=None, device=None):
     """MAX of a python float over all ranks (the timing rule of bench.py); identity when not distributed."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized():   # a world of ONE initialised rank still goes through the collective (bench.py --force-dist)
         return float(value)
     import torch
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
@@ -30,7 +30,7 @@ def max_over_ranks(value, dist=None, device=None):
 
 def gather_frame_results(local_values, dist=None, device=None):
     """All-gather a short list of per-frame integers (e.g. line counts); returns the global list in frame order."""
-    if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:
+    if dist is None or not dist.is_initialized():
         return list(local_values)
     import torch
     world = dist.get_world_size()

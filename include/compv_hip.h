@@ -3,7 +3,7 @@
  * This is the drop-in boundary: plain pointers and sizes, no C++ types, no ownership transfer.  It is what a
  * CompV maintainer binds from the replacement factories registered with CompVFeature::addFactory()
  * (reference: base/include/compv/base/compv_features.h:36-44 registry, base/compv_features.cxx:30-40 replace-by-id);
- * the reference-side binding is shown in INTEGRATION.md and implemented in compv_amd/host/.
+ * the reference-side binding is shown in INTEGRATION.md and implemented in integration/compv_hip_plugin.cxx.
  * Precedent for a function-pointer GPU hook in the reference: gpu/include/compv/gpu/base/math/compv_gpu_math_convlt.h.
  *
  * All file:line citations are relative to the CompV source tree.
@@ -161,6 +161,8 @@ COMPVHIP_API int compvhip_houghsht_dims(size_t W, size_t H, float thetaDeg, size
  * Q16 sin/cos tables for thetaDeg.  Frames are independent units: one plan per GPU, shard frames across GPUs. */
 COMPVHIP_API int compvhip_plan_create(compvhip_ctx* ctx, size_t W, size_t H, size_t S, size_t frames, float thetaDeg,
                                       compvhip_plan** plan);
+/* A plan must be destroyed BEFORE its context (it keeps a pointer to it); compvhip_ctx_destroy only releases the private
+ * single-frame plan of the host entry points. */
 COMPVHIP_API void compvhip_plan_destroy(compvhip_plan* plan);
 
 /* Canny on `frames` device frames: d_in -> d_edges (both frames*S*H bytes, may alias).  Asynchronous on `stream`
@@ -192,9 +194,10 @@ COMPVHIP_API int compvhip_plan_edge_dete(compvhip_plan* plan, const uint8_t* d_i
 /* SHT on the edge maps produced by the last compvhip_plan_canny() of this plan (uses its 1-bit edge masks, no byte
  * re-read) or, when d_edges != NULL, on arbitrary device edge maps.  Results stay on the device:
  * d_lines: frames * lineCap compvhip_line (sorted as compvhip_houghsht_u8), d_counts: frames int32 (lines found,
- * before clipping to lineCap).  The call is asynchronous and cannot grow its buffers after the fact: when d_counts[f] exceeds
- * max(lineCap, 65536) the device key buffer overflowed and frame f's lines are an arbitrary subset -- call again with
- * lineCap >= d_counts[f] (the host entry point compvhip_houghsht_u8 does that by itself). */
+ * before clipping to lineCap).  The call is asynchronous and cannot grow its buffers after the fact: the device key buffer holds
+ * min(R*T, max(lineCap, 65536)) candidates per frame, so whatever lineCap is, the lineCap STRONGEST lines are returned as long as
+ * d_counts[f] <= max(lineCap, 65536); beyond that the key buffer overflowed and frame f's lines are an arbitrary subset -- call
+ * again with lineCap >= d_counts[f] (the host entry point compvhip_houghsht_u8 does that by itself). */
 COMPVHIP_API int compvhip_plan_houghsht(compvhip_plan* plan, const uint8_t* d_edges, int threshold, int maxLines,
                                         compvhip_line* d_lines, size_t lineCap, int32_t* d_counts, void* stream);
 
@@ -202,6 +205,18 @@ COMPVHIP_API int compvhip_plan_houghsht(compvhip_plan* plan, const uint8_t* d_ed
 COMPVHIP_API int compvhip_plan_pipeline(compvhip_plan* plan, const uint8_t* d_in, float tLow, float tHigh,
                                         int threshold, int maxLines, uint8_t* d_edges,
                                         compvhip_line* d_lines, size_t lineCap, int32_t* d_counts, void* stream);
+
+/* compvhip_plan_pipeline without its host round trip.  The synchronous call reads the hysteresis convergence flag before it
+ * returns (one stream synchronisation per step); this one enqueues the step, lets the flag travel to pinned host memory behind
+ * the kernels and returns a ticket.  compvhip_plan_wait(plan, ticket) blocks until that step has finished and, in the rare case
+ * its hysteresis needed more resolve rounds than were enqueued speculatively, drains the stream and runs the step again
+ * synchronously -- so d_in must stay unmodified, and distinct from d_edges, until the step was waited for.  Up to 4 steps may be
+ * in flight (further calls return COMPVHIP_E_INVALID_STATE); steps of one plan must use one stream.  Typical use:
+ * t1 = async(batch k+1); wait(t0) -- the GPU never idles between steps. */
+COMPVHIP_API int compvhip_plan_pipeline_async(compvhip_plan* plan, const uint8_t* d_in, float tLow, float tHigh,
+                                              int threshold, int maxLines, uint8_t* d_edges,
+                                              compvhip_line* d_lines, size_t lineCap, int32_t* d_counts, void* stream, int* ticket);
+COMPVHIP_API int compvhip_plan_wait(compvhip_plan* plan, int ticket);
 
 /* Device accumulator of frame f after compvhip_plan_houghsht: uint16 (a cell never exceeds the pixels of a 1-px band),
  * theta-major [T][accPitch] (pitch >= R).  compvhip_plan_acc_export gives the reference's int32 rho-major layout. */

@@ -556,3 +556,162 @@ def test_plan_small_line_capacity_keeps_the_strongest(hip_ctx, oracle):
         assert _lines_tuple(rec) == _orc_tuple(exp[:cap])
     finally:
         plan.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# round-2 evidence: cell-by-cell vote histograms at BASELINE's full sizes, the reference's own unit-test parameters,
+# the key-buffer contract with a small lineCap, the asynchronous step
+# ---------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", ["fhd_1920x1080", "uhd_3840x2160"])
+def test_plan_full_size_accumulator_cell_by_cell(hip_ctx, oracle, golden, name):
+    """BASELINE config 3/4: the Hough vote histogram of the batched plan equals the oracle's CELL BY CELL at 1920x1080 and
+    3840x2160 (int32 [R][T], reference layout), and so does the complete line set."""
+    from compv_amd import capi
+    meta, _ = golden
+    m = meta[name]
+    W, H = m["W"], m["H"]
+    frames = np.stack([synth_frame(W, H, m["seed"]), synth_frame(W, H, m["seed"] + 3)])
+    thr = m["sht"]["threshold"]
+    edges, lines_raw, counts, accs = _plan_run(hip_ctx, frames, m["tLow"], m["tHigh"], thr, 1 << 16)
+    assert md5_rows(edges[0]) == m["canny_md5"]
+    for f in range(2):
+        rc, e = oracle.canny(frames[f], m["tLow"], m["tHigh"])
+        assert rc == 0 and (edges[f] == e).all()
+        acc = oracle.sht_acc(e, 1.0)
+        assert accs[f].shape == acc.shape
+        assert (accs[f] == acc).all(), (f, int((accs[f] != acc).sum()))
+        exp = oracle.sht_lines_from_acc(acc, W, H, 1.0, thr)
+        assert counts[f] == len(exp)
+        got = np.frombuffer(lines_raw[f].tobytes(), dtype=capi.LINE_DTYPE)[:len(exp)]
+        assert _lines_tuple(got) == _orc_tuple(exp)
+
+
+def _unittest_golden():
+    import json
+    import os
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_unittest.json")) as f:
+        return json.load(f)
+
+
+def test_houghsht_reference_unittest_parameters_small(hip_ctx, oracle):
+    """unittests/houghsht.cxx:17-21: Canny(0.8, 1.6), theta = kfMathTrigPiOver180 'degrees' (T = 10313 theta bins, 5157 vote
+    workgroups, 26-bit cell indices), threshold 100 -- accumulator and line set against the oracle, sums against the fixture the
+    compiled reference produced (tests/golden/make_golden_unittest.py)."""
+    g = _unittest_golden()
+    for name in ("unittest_200x258", "unittest_320x240"):
+        m = g[name]
+        W, H = m["W"], m["H"]
+        can = hip_ctx.canny(synth_frame(W, H, m["seed"]), m["tLow"], m["tHigh"])
+        assert md5_rows(can) == m["canny_md5"]
+        R, T, _ = hip_ctx.houghsht_dims(W, H, m["theta_deg"])
+        assert T == 10313 and R == 2 * (W + H) + 1
+        acc_exp = oracle.sht_acc(can, m["theta_deg"])
+        exp = oracle.sht_lines_from_acc(acc_exp, W, H, m["theta_deg"], m["threshold"])
+        lines, acc = hip_ctx.houghsht(can, m["theta_deg"], m["threshold"], cap=max(1, m["lines"]), want_acc=True)
+        assert (acc == acc_exp).all(), int((acc != acc_exp).sum())
+        assert len(lines) == m["lines"] == len(exp)
+        assert _lines_tuple(lines) == _orc_tuple(exp)
+        assert float(lines["rho"].astype(np.float64).sum()) == m["sum_rho"]
+        assert abs(float(lines["theta"].astype(np.float64).sum()) - m["sum_theta"]) <= 0.0009765625      # the unit test's own tolerance
+        assert int(lines["strength"].astype(np.int64).sum()) == m["sum_strength"]
+
+
+def test_houghsht_reference_unittest_parameters_1282x720(hip_ctx):
+    """The same at the size of the unit test's first image (1282x720): 347 625 edge pixels x 10 313 theta bins, 1.3 million lines
+    (20x the initial device key buffer) -- the three sums the unit test checks (houghsht.cxx:64-73) against the compiled reference."""
+    m = _unittest_golden()["unittest_1282x720"]
+    W, H = m["W"], m["H"]
+    can = hip_ctx.canny(synth_frame(W, H, m["seed"]), m["tLow"], m["tHigh"])
+    assert md5_rows(can) == m["canny_md5"] and int((can != 0).sum()) == m["canny_edges"]
+    lines = hip_ctx.houghsht(can, m["theta_deg"], m["threshold"], cap=m["lines"])
+    assert len(lines) == m["lines"]
+    assert float(lines["rho"].astype(np.float64).sum()) == m["sum_rho"]
+    assert abs(float(lines["theta"].astype(np.float64).sum()) - m["sum_theta"]) <= 0.0009765625
+    assert int(lines["strength"].astype(np.int64).sum()) == m["sum_strength"]
+    assert int(lines["strength"][0]) == m["max_strength"]
+    assert (np.diff(lines["strength"].astype(np.int64)) <= 0).all()
+
+
+def test_plan_small_line_capacity_with_many_candidates(hip_ctx, oracle):
+    """Key-buffer contract (include/compv_hip.h, compvhip_plan_houghsht): with MORE than 1024 candidate lines per frame and a
+    tiny lineCap / maxLines the plan still returns the strongest lines (the device key buffer holds max(lineCap, 65536))."""
+    import torch
+    from compv_amd import capi
+    W, H, n = 800, 600, 2
+    frames = np.stack([synth_frame(W, H, 4242 + f) for f in range(n)])
+    dev = torch.device("cuda:0")
+    d_in = torch.from_numpy(frames).to(dev)
+    d_edges = torch.empty_like(d_in)
+    for cap, max_lines in ((8, 0), (64, 5), (2000, 0)):
+        d_lines = torch.zeros((n, cap, 5), dtype=torch.int32, device=dev)
+        d_counts = torch.zeros(n, dtype=torch.int32, device=dev)
+        plan = capi.Plan(hip_ctx, W, H, W, n, 1.0)
+        try:
+            plan.pipeline(d_in.data_ptr(), 0.8, 1.6, 30, max_lines, d_edges.data_ptr(), d_lines.data_ptr(), cap, d_counts.data_ptr())
+            torch.cuda.synchronize()
+            raw = d_lines.cpu().numpy().view(np.uint8).reshape(n, cap, 20)
+            for f in range(n):
+                rc, e = oracle.canny(frames[f], 0.8, 1.6)
+                exp = oracle.sht(e, 1.0, 30)
+                assert len(exp) > 1024                          # more candidates than the old minimum key capacity
+                assert int(d_counts.cpu()[f]) == len(exp)
+                keep = min(cap, max_lines) if max_lines > 0 else cap
+                rec = np.frombuffer(raw[f].tobytes(), dtype=capi.LINE_DTYPE)[:keep]
+                assert _lines_tuple(rec) == _orc_tuple(exp[:keep]), (cap, max_lines, f)
+        finally:
+            plan.close()
+
+
+def test_plan_pipeline_async_matches_sync(hip_ctx, oracle):
+    """compvhip_plan_pipeline_async / compvhip_plan_wait: two steps in flight on two buffer sets, same results as the
+    synchronous call; includes a frame whose hysteresis needs more than the speculative resolve rounds (replay path)."""
+    import torch
+    from compv_amd import capi
+    W, H, n, cap = 1100, 700, 2, 4096
+    serp = np.full((H, W), 100, np.uint8)                       # long weak chains crossing many 64-row bands (test_canny_long_weak_chains)
+    for k, yy in enumerate(range(20, H - 20, 12)):
+        serp[yy:yy + 3, 15:W - 15] = 112
+        xs = W - 30 if (k % 2 == 0) else 15
+        serp[yy:yy + 15, xs:xs + 3] = 112
+    serp[18:26, 10:20] = 255
+    batches = [np.stack([synth_frame(W, H, 5), synth_frame(W, H, 6)]), np.stack([serp, synth_frame(W, H, 7)])]
+    params = [(59.0, 119.0), (10.0, 200.0)]
+    dev = torch.device("cuda:0")
+    plan = capi.Plan(hip_ctx, W, H, W, n, 1.0)
+    st = torch.cuda.Stream(device=dev)
+    try:
+        bufs = []
+        for b in batches:
+            bufs.append((torch.from_numpy(b).to(dev), torch.empty((n, H, W), dtype=torch.uint8, device=dev),
+                         torch.zeros((n, cap, 5), dtype=torch.int32, device=dev), torch.zeros(n, dtype=torch.int32, device=dev)))
+        torch.cuda.synchronize()
+        tickets = []
+        for (d_in, d_e, d_l, d_c), (tl, th) in zip(bufs, params):
+            tickets.append(plan.pipeline_async(d_in.data_ptr(), tl, th, 40, 0, d_e.data_ptr(), d_l.data_ptr(), cap, d_c.data_ptr(), st.cuda_stream))
+        # results are checked in issue order: each wait() may replay its step synchronously
+        for k, t in enumerate(tickets):
+            plan.wait(t)
+            st.synchronize()
+            d_in, d_e, d_l, d_c = bufs[k]
+            tl, th = params[k]
+            if k == 0:
+                edges = d_e.cpu().numpy(); counts = d_c.cpu().numpy(); raw = d_l.cpu().numpy().view(np.uint8).reshape(n, cap, 20)
+                for f in range(n):
+                    rc, e = oracle.canny(batches[k][f], tl, th)
+                    assert (edges[f] == e).all(), (k, f)
+                    exp = oracle.sht(e, 1.0, 40)
+                    assert counts[f] == len(exp)
+                    assert _lines_tuple(np.frombuffer(raw[f].tobytes(), dtype=capi.LINE_DTYPE)[:min(len(exp), cap)]) == _orc_tuple(exp[:cap])
+        # step 0's buffers may have been produced while step 1 was already running; step 1 (the hard one) is verified last
+        d_in, d_e, d_l, d_c = bufs[1]
+        edges = d_e.cpu().numpy(); counts = d_c.cpu().numpy(); raw = d_l.cpu().numpy().view(np.uint8).reshape(n, cap, 20)
+        for f in range(n):
+            rc, e = oracle.canny(batches[1][f], *params[1])
+            assert (edges[f] == e).all(), ("step1", f, int((edges[f] != e).sum()))
+            exp = oracle.sht(e, 1.0, 40)
+            assert counts[f] == len(exp)
+            assert _lines_tuple(np.frombuffer(raw[f].tobytes(), dtype=capi.LINE_DTYPE)[:min(len(exp), cap)]) == _orc_tuple(exp[:cap])
+        with pytest.raises(capi.CompvHipError):
+            plan.wait(tickets[0])                                 # a ticket can be waited for once
+    finally:
+        plan.close()

@@ -19,3 +19,24 @@ def test_real_compv_with_hip_factories(W, H, frames):
     r = subprocess.run([BIN, str(W), str(H), str(frames)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert "DROP-IN PARITY OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
     assert r.returncode == 0
+
+
+@pytest.mark.gpu
+def test_bench_under_torchrun_nccl_single_rank(tmp_path):
+    """The multi-GPU code path of bench.py (torch.distributed with backend nccl = RCCL: init_process_group, barrier around the timed
+    region, all_reduce(MAX) of the elapsed time, all_gather of the per-frame line counts) executed on real hardware with the one
+    GPU a test box has: `torch.distributed.run --nproc-per-node 1 bench.py --force-dist`."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1", "--master-port", "29617",
+           os.path.join(root, "bench.py"), "--gpus", "1", "--force-dist", "--steps", "3", "--warmup", "1", "--reps", "2", "--frames-per-gpu", "2",
+           "--width", "1280", "--height", "720", "--no-cpu-baseline"]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
+    res = json.loads(line)
+    assert res["dist_backend"] == "nccl" and res["n_gpus"] == 1 and res["value"] > 0
+    assert res["lines_all_frames"] is not None and res["lines_frame0"] > 0
