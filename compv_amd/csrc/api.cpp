@@ -64,7 +64,9 @@ struct compvhip_plan {
 	int roundsUsed = 0;
 	bool countersFresh = false; // the step's memset already zeroed the edge/line counts (no second fill in front of the SHT stage)
 	int2* thrDev = nullptr; unsigned int* sums = nullptr;
-	uint8_t* tmpOut = nullptr; // aliasing (in == out) scratch
+	uint8_t* tmpOut = nullptr; // aliasing (in == out) scratch of the first-generation tile kernel (kernel size 5), which writes bytes itself
+	hipStream_t side = nullptr; hipEvent_t evFork = nullptr, evJoin = nullptr; // side stream of the pipeline: edge-byte expansion next to the Hough stage
+	bool joinPending = false;
 	bool bitsValid = false;
 	// sht
 	bool shtReady = false;
@@ -363,7 +365,7 @@ int enqueueCanny(compvhip_plan* p, const uint8_t* d_in, uint8_t* d_out, int tLow
 	a.in = d_in; a.out = d_out; a.ebits = p->ebits; a.ubits = p->ubits; a.thrDev = (thrMode != COMPVHIP_CANNY_THRESHOLD_COMPARE_TO_GRADIENT) ? p->thrDev : nullptr;
 	a.inFrameStride = p->S * p->H; a.outFrameStride = p->S * p->H; a.bitsFrameStride = p->bitsFrameStride;
 	a.W = static_cast<int>(p->W); a.H = static_cast<int>(p->H); a.S = static_cast<int>(p->S); a.So = static_cast<int>(p->S);
-	a.wb = p->wb; a.tilesX = p->tilesX; a.tilesY = p->tilesY; a.tLow = tLow; a.tHigh = tHigh; a.ksize = ksize;
+	a.wb = p->wb; a.tilesX = p->tilesX; a.tilesY = p->tilesY; a.tLow = tLow; a.tHigh = tHigh; a.ksize = ksize; a.dbg = 0;
 	cannyCoverage(p->W, &a.simdEnd, &a.cStart);
 	// coverage [1,simdEnd) U [cStart,W-1) equals the whole interior unless the two pieces leave a hole (W = 1 mod 16 ...)
 	const bool gap = !((a.simdEnd >= a.W - 1) || (a.cStart <= a.simdEnd));
@@ -388,11 +390,11 @@ int enqueueCanny(compvhip_plan* p, const uint8_t* d_in, uint8_t* d_out, int tLow
 	return COMPVHIP_OK;
 }
 
-int enqueueResolve(compvhip_plan* p, uint8_t* d_out, int rounds, hipStream_t st)
+int enqueueResolve(compvhip_plan* p, uint8_t* /*d_out*/, int rounds, hipStream_t st)
 {
 	compvhip_ctx* ctx = p->ctx;
 	ResolveArgs r;
-	r.ebits = p->ebits; r.ubits = p->ubits; r.out = d_out; r.flags = p->flags;
+	r.ebits = p->ebits; r.ubits = p->ubits; r.out = nullptr; r.flags = p->flags; // the byte map is rebuilt from the final E masks (enqueueExpand)
 	r.outFrameStride = p->S * p->H; r.bitsFrameStride = p->bitsFrameStride;
 	r.H = static_cast<int>(p->H); r.So = static_cast<int>(p->S); r.wb = p->wb;
 	for (int i = 0; i < rounds; ++i) {
@@ -401,6 +403,39 @@ int enqueueResolve(compvhip_plan* p, uint8_t* d_out, int rounds, hipStream_t st)
 		Stamp s(p, st, "canny_resolve_kernel");
 		HIPCHK(ctx, launch_canny_resolve(r, static_cast<int>(p->frames), st));
 	}
+	return COMPVHIP_OK;
+}
+
+// Edge bytes from the final E masks.  side == false: on `st`.  side == true (the pipeline): on the plan's side stream, forked
+// behind everything enqueued on `st` so far; joinSide() makes `st` wait for it again.
+int enqueueExpand(compvhip_plan* p, uint8_t* d_edges, hipStream_t st, bool side)
+{
+	compvhip_ctx* ctx = p->ctx;
+	hipStream_t es = st;
+	if (side) {
+		if (!p->side) {
+			HIPCHK(ctx, hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
+			HIPCHK(ctx, hipEventCreateWithFlags(&p->evFork, hipEventDisableTiming));
+			HIPCHK(ctx, hipEventCreateWithFlags(&p->evJoin, hipEventDisableTiming));
+		}
+		HIPCHK(ctx, hipEventRecord(p->evFork, st));
+		HIPCHK(ctx, hipStreamWaitEvent(p->side, p->evFork, 0));
+		es = p->side;
+	}
+	{
+		Stamp s(p, es, "canny_expand_kernel");
+		HIPCHK(ctx, launch_canny_expand(p->ebits, p->wb, p->bitsFrameStride, static_cast<int>(p->H), static_cast<int>(p->S), d_edges, p->S * p->H,
+		                                static_cast<int>(p->frames), es));
+	}
+	if (side) { HIPCHK(ctx, hipEventRecord(p->evJoin, p->side)); p->joinPending = true; }
+	return COMPVHIP_OK;
+}
+
+int joinSide(compvhip_plan* p, hipStream_t st)
+{
+	if (!p->joinPending) return COMPVHIP_OK;
+	p->joinPending = false;
+	HIPCHK(p->ctx, hipStreamWaitEvent(st, p->evJoin, 0));
 	return COMPVHIP_OK;
 }
 
@@ -505,6 +540,9 @@ int compvhip_plan_create(compvhip_ctx* ctx, size_t W, size_t H, size_t S, size_t
 	do {
 		if (dmalloc(ctx, &p->ebits, p->bitsFrameStride * frames) != hipSuccess) { rc = COMPVHIP_E_OUT_OF_MEMORY; break; }
 		if (dmalloc(ctx, &p->ubits, p->bitsFrameStride * frames) != hipSuccess) { rc = COMPVHIP_E_OUT_OF_MEMORY; break; }
+		// mask words past the last 496-column tile of a row are never written by the Canny kernel: they stay zero for ever
+		if (hipMemset(p->ebits, 0, sizeof(uint32_t) * p->bitsFrameStride * frames) != hipSuccess) { rc = COMPVHIP_E_HIP; break; }
+		if (hipMemset(p->ubits, 0, sizeof(uint32_t) * p->bitsFrameStride * frames) != hipSuccess) { rc = COMPVHIP_E_HIP; break; }
 		if (dmalloc(ctx, &p->counters, 2 * frames + kMaxRounds) != hipSuccess) { rc = COMPVHIP_E_OUT_OF_MEMORY; break; }
 		p->edgeCounts = p->counters; p->lineCounts = p->counters + frames; p->flags = p->counters + 2 * frames;
 		if (hipMemset(p->counters, 0, sizeof(int) * (2 * frames + kMaxRounds)) != hipSuccess) { rc = COMPVHIP_E_HIP; break; }
@@ -525,6 +563,9 @@ void compvhip_plan_destroy(compvhip_plan* p)
 	timelineClear(p);
 	for (hipEvent_t e : p->eventPool) (void)hipEventDestroy(e);
 	for (auto& stp : p->steps) if (stp.done) (void)hipEventDestroy(stp.done);
+	if (p->evFork) (void)hipEventDestroy(p->evFork);
+	if (p->evJoin) (void)hipEventDestroy(p->evJoin);
+	if (p->side) (void)hipStreamDestroy(p->side);
 	dfree(ctx, p->ebits); dfree(ctx, p->ubits); dfree(ctx, p->counters); dfree(ctx, p->thrDev); dfree(ctx, p->sums); dfree(ctx, p->tmpOut);
 	if (p->hFlags) (void)hipHostFree(p->hFlags);
 	dfree(ctx, p->hist); dfree(ctx, p->otsu); dfree(ctx, p->blurTmp);
@@ -546,14 +587,18 @@ int compvhip_plan_get_timing(compvhip_plan* p, const char** names, float* ms, in
 {
 	if (!p) return COMPVHIP_E_INVALID_PARAMETER;
 	(void)hipSetDevice(p->ctx->device);
-	if (!p->timeline.empty()) { (void)hipEventSynchronize(p->timeline.back().b); timelineCollect(p); } // events of one stream complete in order
+	if (!p->timeline.empty()) {
+		for (auto& t : p->timeline) (void)hipEventSynchronize(t.b); // main and side stream events
+		timelineCollect(p);
+	}
 	const int n = std::min<int>(cap, static_cast<int>(p->timingMs.size()));
 	for (int i = 0; i < n; ++i) { if (names) names[i] = p->timingNames[i].c_str(); if (ms) ms[i] = p->timingMs[i]; }
 	return n;
 }
 
+// expand: 0 = the caller enqueues the byte expansion itself, 1 = on `st` after the resolve rounds
 static int planCannyImpl(compvhip_plan* p, const uint8_t* d_in, float tLow, float tHigh, int ksize, int type, uint8_t* d_edges, hipStream_t st,
-                         bool waitConverged, bool clearTimeline = true)
+                         bool waitConverged, bool clearTimeline = true, int expand = 1)
 {
 	compvhip_ctx* ctx = p->ctx;
 	if (!d_in || !d_edges) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "null frame pointer");
@@ -562,11 +607,13 @@ static int planCannyImpl(compvhip_plan* p, const uint8_t* d_in, float tLow, floa
 	if (rc) return rc;
 	HIPCHK(ctx, hipSetDevice(ctx->device));
 	if (p->timing && clearTimeline) timelineClear(p);
+	// The kernel-size-3 tile kernel writes masks only (in-place calls need no scratch: the bytes are expanded after every input row
+	// was read).  The first-generation kernel (kernel size 5) also writes a byte map while neighbouring tiles may still read their
+	// row halo: when in and out alias it gets a scratch target; its bytes are overwritten by the expansion anyway.
 	uint8_t* out = d_edges;
 	const size_t bytes = p->S * p->H * p->frames;
 	const bool alias = (d_in < d_edges + bytes) && (d_edges < d_in + bytes);
-	if (alias) {
-		// the tile kernel reads a 2-row halo that a neighbouring tile may already have overwritten: go through scratch
+	if (alias && canny_tiles_write_bytes(ksize)) {
 		if (!p->tmpOut) HIPCHK(ctx, dmalloc(ctx, &p->tmpOut, bytes));
 		out = p->tmpOut;
 	}
@@ -585,7 +632,7 @@ static int planCannyImpl(compvhip_plan* p, const uint8_t* d_in, float tLow, floa
 			if (rc) return rc;
 		}
 	}
-	if (alias) HIPCHK(ctx, hipMemcpyAsync(d_edges, out, bytes, hipMemcpyDeviceToDevice, st));
+	if (expand == 1) { rc = enqueueExpand(p, d_edges, st, false); if (rc) return rc; }
 	p->bitsValid = true;
 	return COMPVHIP_OK;
 }
@@ -736,29 +783,31 @@ int compvhip_plan_pipeline(compvhip_plan* p, const uint8_t* d_in, float tLow, fl
                            compvhip_line* d_lines, size_t lineCap, int32_t* d_counts, void* stream)
 {
 	if (!p) return COMPVHIP_E_INVALID_PARAMETER;
-	compvhip_ctx* ctx = p->ctx;
 	hipStream_t st = static_cast<hipStream_t>(stream);
-	// Everything is enqueued back to back (speculative resolve rounds included); the convergence flag is checked once at
-	// the end and, in the rare case the hysteresis needed more rounds, the tail is replayed.
-	int rc = planCannyImpl(p, d_in, tLow, tHigh, 3, COMPVHIP_CANNY_THRESHOLD_COMPARE_TO_GRADIENT, d_edges, st, false);
+	// Everything is enqueued back to back (speculative resolve rounds included); the edge bytes are expanded from the E masks on a
+	// side stream while the Hough stage runs; the convergence flag is checked once at the end and, in the rare case the hysteresis
+	// needed more rounds, the tail is replayed.
+	int rc = planCannyImpl(p, d_in, tLow, tHigh, 3, COMPVHIP_CANNY_THRESHOLD_COMPARE_TO_GRADIENT, d_edges, st, false, true, 0);
 	if (rc) return rc;
-	const size_t bytes = p->S * p->H * p->frames;
-	const bool alias = (d_in < d_edges + bytes) && (d_edges < d_in + bytes);
-	uint8_t* out = alias ? p->tmpOut : d_edges;
+	rc = enqueueExpand(p, d_edges, st, true);
+	if (rc) return rc;
 	for (;;) {
 		rc = planShtImpl(p, nullptr, threshold, maxLines, d_lines, lineCap, d_counts, st, false);
+		if (rc) return rc;
+		rc = joinSide(p, st);
 		if (rc) return rc;
 		bool done = false;
 		rc = resolveConverged(p, st, &done);
 		if (rc) return rc;
 		if (done) break;
 		do {
-			rc = enqueueResolve(p, out, kSpecRounds, st);
+			rc = enqueueResolve(p, nullptr, kSpecRounds, st);
 			if (rc) return rc;
 			rc = resolveConverged(p, st, &done);
 			if (rc) return rc;
 		} while (!done);
-		if (alias) HIPCHK(ctx, hipMemcpyAsync(d_edges, out, bytes, hipMemcpyDeviceToDevice, st));
+		rc = enqueueExpand(p, d_edges, st, false);
+		if (rc) return rc;
 	}
 	return COMPVHIP_OK;
 }
@@ -782,9 +831,13 @@ int compvhip_plan_pipeline_async(compvhip_plan* p, const uint8_t* d_in, float tL
 	HIPCHK(ctx, hipSetDevice(ctx->device));
 	if (!stp.done) HIPCHK(ctx, hipEventCreateWithFlags(&stp.done, hipEventDisableTiming));
 	// timing events of asynchronous steps accumulate until compvhip_plan_get_timing reads them (nothing is cleared per step)
-	int rc = planCannyImpl(p, d_in, tLow, tHigh, 3, COMPVHIP_CANNY_THRESHOLD_COMPARE_TO_GRADIENT, d_edges, st, false, false);
+	int rc = planCannyImpl(p, d_in, tLow, tHigh, 3, COMPVHIP_CANNY_THRESHOLD_COMPARE_TO_GRADIENT, d_edges, st, false, false, 0);
+	if (rc) return rc;
+	rc = enqueueExpand(p, d_edges, st, true); // edge bytes on the side stream, next to the Hough stage
 	if (rc) return rc;
 	rc = planShtImpl(p, nullptr, threshold, maxLines, d_lines, lineCap, d_counts, st, false);
+	if (rc) return rc;
+	rc = joinSide(p, st);
 	if (rc) return rc;
 	HIPCHK(ctx, hipMemcpyAsync(p->hFlags + 1 + slot, p->flags + (p->roundsUsed - 1), sizeof(int), hipMemcpyDeviceToHost, st));
 	HIPCHK(ctx, hipEventRecord(stp.done, st));

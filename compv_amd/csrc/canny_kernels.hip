@@ -22,6 +22,8 @@
 #include "stencil.hpp"
 #include "kernels.hpp"
 
+#include <cstdlib>
+#include <cstring>
 #include <type_traits>
 
 namespace compvhip {
@@ -386,7 +388,7 @@ __global__ __launch_bounds__(kResolveThreads) void canny_resolve_kernel(ResolveA
 
 	// write back: promoted = E_new & U_old
 	int wrote = 0;
-	uint8_t* __restrict__ out = a.out + (size_t)frame * a.outFrameStride;
+	uint8_t* __restrict__ out = a.out ? a.out + (size_t)frame * a.outFrameStride : nullptr;
 	for (int i = tid; i < rows * cw; i += kResolveThreads) {
 		const int r = i / cw, k = i - r * cw;
 		const uint32_t u = sU[i];
@@ -397,16 +399,49 @@ __global__ __launch_bounds__(kResolveThreads) void canny_resolve_kernel(ResolveA
 		gE[gi] = sE[(r + 1) * ew + k + 1];
 		gU[gi] = u & ~p;
 		wrote = 1;
-		uint8_t* orow = out + (size_t)(y0 + r) * a.So + (size_t)(w0 + k) * 32;
-		while (p) {
-			const int b = __ffs(p) - 1;
-			p &= p - 1;
-			orow[b] = 0xff;
+		if (a.out) { // byte map patched in place (only when no canny_expand_kernel pass follows)
+			uint8_t* orow = out + (size_t)(y0 + r) * a.So + (size_t)(w0 + k) * 32;
+			while (p) {
+				const int b = __ffs(p) - 1;
+				p &= p - 1;
+				orow[b] = 0xff;
+			}
 		}
 	}
 	if (__syncthreads_or(wrote)) {
 		if (tid == 0) a.flags[a.round] = 1; // benign race: every writer stores 1
 	}
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// Edge bytes from the final E mask: out[y][x] = bit x of E row y ? 0xff : 0, for x < So (bits past W are zero).  One thread = 16
+// pixels (one half-word of mask, one 16-byte store); a wave writes 1 KB of a row.  Pure streaming: 1/8 B/px read, 1 B/px written.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void canny_expand_kernel(const uint32_t* __restrict__ ebits, int wb, size_t bitsFrameStride, int H, int So,
+                                                           uint8_t* __restrict__ out, size_t outFrameStride)
+{
+	const int frame = blockIdx.z;
+	const int y = blockIdx.y;
+	const int g = blockIdx.x * blockDim.x + threadIdx.x; // group of 16 columns
+	const int x = g * 16;
+	if (x >= So) return;
+	const uint16_t* __restrict__ mrow = reinterpret_cast<const uint16_t*>(ebits + (size_t)frame * bitsFrameStride + (size_t)y * wb);
+	const uint32_t m = (g < wb * 2) ? mrow[g] : 0u;
+	uint32_t w[4];
+#pragma unroll
+	for (int q = 0; q < 4; ++q) w[q] = (__umul24((m >> (4 * q)) & 0xfu, 0x00204081u) & 0x01010101u) * 0xffu; // nibble -> 4 bytes
+	uint8_t* __restrict__ o = out + (size_t)frame * outFrameStride + (size_t)y * So + x;
+	if (x + 16 <= So) *reinterpret_cast<uint4*>(o) = make_uint4(w[0], w[1], w[2], w[3]);
+	else *reinterpret_cast<uint2*>(o) = make_uint2(w[0], w[1]); // So % 8 == 0: an 8-column tail
+}
+
+hipError_t launch_canny_expand(const uint32_t* ebits, int wb, size_t bitsFrameStride, int H, int So, uint8_t* out, size_t outFrameStride, int frames,
+                               hipStream_t stream)
+{
+	const int groups = (So + 15) / 16;
+	dim3 grid((groups + 255) / 256, H, frames);
+	hipLaunchKernelGGL(canny_expand_kernel, grid, dim3(256), 0, stream, ebits, wb, bitsFrameStride, H, So, out, outFrameStride);
+	return hipGetLastError();
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -449,8 +484,18 @@ __global__ void mean_thresholds_kernel(const unsigned int* __restrict__ sums, in
 // ---------------------------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------------------------
+// kernel size 3: the SWAR + candidate-list kernel (canny_swar_kernels.hip); COMPVHIP_CANNY_IMPL=ring selects this file's first-generation
+// kernel for A/B measurements.  Kernel size 5 always runs here.
+static bool use_ring_kernel(int ksize)
+{
+	static const bool ring = [] { const char* e = getenv("COMPVHIP_CANNY_IMPL"); return e && !strcmp(e, "ring"); }();
+	return ksize == 5 || ring;
+}
+bool canny_tiles_write_bytes(int ksize) { return use_ring_kernel(ksize); }
+
 hipError_t launch_canny_tiles(const CannyArgs& a0, int frames, bool gap, hipStream_t stream)
 {
+	if (!use_ring_kernel(a0.ksize)) return launch_canny_tiles_swar(a0, frames, gap, stream);
 	CannyArgs a = a0;
 	a.blockRows = (a.tilesY + kCannyWaves - 1) / kCannyWaves;
 	a.groups = a.blockRows * frames;

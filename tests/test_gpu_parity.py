@@ -667,7 +667,7 @@ def test_plan_pipeline_async_matches_sync(hip_ctx, oracle):
     synchronous call; includes a frame whose hysteresis needs more than the speculative resolve rounds (replay path)."""
     import torch
     from compv_amd import capi
-    W, H, n, cap = 1100, 700, 2, 4096
+    W, H, n, cap = 1104, 700, 2, 4096                           # the plan API needs a stride that is a multiple of 8
     serp = np.full((H, W), 100, np.uint8)                       # long weak chains crossing many 64-row bands (test_canny_long_weak_chains)
     for k, yy in enumerate(range(20, H - 20, 12)):
         serp[yy:yy + 3, 15:W - 15] = 112
