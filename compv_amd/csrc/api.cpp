@@ -64,6 +64,8 @@ struct compvhip_plan {
 	int roundsUsed = 0;
 	bool countersFresh = false; // the step's memset already zeroed the edge/line counts (no second fill in front of the SHT stage)
 	int2* thrDev = nullptr; unsigned int* sums = nullptr;
+	uint8_t* dirty = nullptr;  // per-workgroup change flags of the resolve rounds
+	uint8_t* patchOut = nullptr; uint8_t* copyBack = nullptr; // byte map the resolve rounds patch (or null: masks only) / in-place target of the last Canny call
 	uint8_t* tmpOut = nullptr; // aliasing (in == out) scratch of the first-generation tile kernel (kernel size 5), which writes bytes itself
 	hipStream_t side = nullptr; hipEvent_t evFork = nullptr, evJoin = nullptr; // side stream of the pipeline: edge-byte expansion next to the Hough stage
 	bool joinPending = false;
@@ -365,7 +367,7 @@ int enqueueCanny(compvhip_plan* p, const uint8_t* d_in, uint8_t* d_out, int tLow
 	a.in = d_in; a.out = d_out; a.ebits = p->ebits; a.ubits = p->ubits; a.thrDev = (thrMode != COMPVHIP_CANNY_THRESHOLD_COMPARE_TO_GRADIENT) ? p->thrDev : nullptr;
 	a.inFrameStride = p->S * p->H; a.outFrameStride = p->S * p->H; a.bitsFrameStride = p->bitsFrameStride;
 	a.W = static_cast<int>(p->W); a.H = static_cast<int>(p->H); a.S = static_cast<int>(p->S); a.So = static_cast<int>(p->S);
-	a.wb = p->wb; a.tilesX = p->tilesX; a.tilesY = p->tilesY; a.tLow = tLow; a.tHigh = tHigh; a.ksize = ksize; a.dbg = 0;
+	a.wb = p->wb; a.tilesX = p->tilesX; a.tilesY = p->tilesY; a.tLow = tLow; a.tHigh = tHigh; a.ksize = ksize;
 	cannyCoverage(p->W, &a.simdEnd, &a.cStart);
 	// coverage [1,simdEnd) U [cStart,W-1) equals the whole interior unless the two pieces leave a hole (W = 1 mod 16 ...)
 	const bool gap = !((a.simdEnd >= a.W - 1) || (a.cStart <= a.simdEnd));
@@ -390,11 +392,12 @@ int enqueueCanny(compvhip_plan* p, const uint8_t* d_in, uint8_t* d_out, int tLow
 	return COMPVHIP_OK;
 }
 
-int enqueueResolve(compvhip_plan* p, uint8_t* /*d_out*/, int rounds, hipStream_t st)
+// d_out: the byte map to patch with the promoted pixels, or nullptr when the bytes are rebuilt from the final E masks (enqueueExpand)
+int enqueueResolve(compvhip_plan* p, uint8_t* d_out, int rounds, hipStream_t st)
 {
 	compvhip_ctx* ctx = p->ctx;
 	ResolveArgs r;
-	r.ebits = p->ebits; r.ubits = p->ubits; r.out = nullptr; r.flags = p->flags; // the byte map is rebuilt from the final E masks (enqueueExpand)
+	r.ebits = p->ebits; r.ubits = p->ubits; r.out = d_out; r.flags = p->flags; r.dirty = p->dirty;
 	r.outFrameStride = p->S * p->H; r.bitsFrameStride = p->bitsFrameStride;
 	r.H = static_cast<int>(p->H); r.So = static_cast<int>(p->S); r.wb = p->wb;
 	for (int i = 0; i < rounds; ++i) {
@@ -543,10 +546,13 @@ int compvhip_plan_create(compvhip_ctx* ctx, size_t W, size_t H, size_t S, size_t
 		// mask words past the last 496-column tile of a row are never written by the Canny kernel: they stay zero for ever
 		if (hipMemset(p->ebits, 0, sizeof(uint32_t) * p->bitsFrameStride * frames) != hipSuccess) { rc = COMPVHIP_E_HIP; break; }
 		if (hipMemset(p->ubits, 0, sizeof(uint32_t) * p->bitsFrameStride * frames) != hipSuccess) { rc = COMPVHIP_E_HIP; break; }
+		// the fills run on the null stream; the plan's kernels may be enqueued on non-blocking streams that do not wait for it
+		if (hipDeviceSynchronize() != hipSuccess) { rc = COMPVHIP_E_HIP; break; }
 		if (dmalloc(ctx, &p->counters, 2 * frames + kMaxRounds) != hipSuccess) { rc = COMPVHIP_E_OUT_OF_MEMORY; break; }
 		p->edgeCounts = p->counters; p->lineCounts = p->counters + frames; p->flags = p->counters + 2 * frames;
 		if (hipMemset(p->counters, 0, sizeof(int) * (2 * frames + kMaxRounds)) != hipSuccess) { rc = COMPVHIP_E_HIP; break; }
 		if (dmalloc(ctx, &p->thrDev, frames) != hipSuccess) { rc = COMPVHIP_E_OUT_OF_MEMORY; break; }
+		if (dmalloc(ctx, &p->dirty, canny_resolve_dirty_bytes(static_cast<int>(H), p->wb, static_cast<int>(frames))) != hipSuccess) { rc = COMPVHIP_E_OUT_OF_MEMORY; break; }
 		if (dmalloc(ctx, &p->sums, frames) != hipSuccess) { rc = COMPVHIP_E_OUT_OF_MEMORY; break; }
 		if (hipHostMalloc(reinterpret_cast<void**>(&p->hFlags), sizeof(int) * (kAsyncDepth + 1)) != hipSuccess) { rc = COMPVHIP_E_OUT_OF_MEMORY; break; }
 	} while (0);
@@ -566,6 +572,7 @@ void compvhip_plan_destroy(compvhip_plan* p)
 	if (p->evFork) (void)hipEventDestroy(p->evFork);
 	if (p->evJoin) (void)hipEventDestroy(p->evJoin);
 	if (p->side) (void)hipStreamDestroy(p->side);
+	dfree(ctx, p->dirty);
 	dfree(ctx, p->ebits); dfree(ctx, p->ubits); dfree(ctx, p->counters); dfree(ctx, p->thrDev); dfree(ctx, p->sums); dfree(ctx, p->tmpOut);
 	if (p->hFlags) (void)hipHostFree(p->hFlags);
 	dfree(ctx, p->hist); dfree(ctx, p->otsu); dfree(ctx, p->blurTmp);
@@ -596,7 +603,11 @@ int compvhip_plan_get_timing(compvhip_plan* p, const char** names, float* ms, in
 	return n;
 }
 
-// expand: 0 = the caller enqueues the byte expansion itself, 1 = on `st` after the resolve rounds
+// Two ways to the edge bytes (launch_canny_tiles picks the tile kernel):
+//  * the tile kernel writes them and the resolve rounds patch the promoted pixels (p->patchOut = that byte map; when in and out
+//    alias it is a scratch copy: a tile may still read the row halo a neighbour has overwritten);
+//  * the tile kernel writes masks only and canny_expand_kernel rebuilds the bytes from the final E masks (p->patchOut = nullptr).
+//    expand: 0 = the caller enqueues that expansion itself (pipeline: on the side stream), 1 = here, on `st`.
 static int planCannyImpl(compvhip_plan* p, const uint8_t* d_in, float tLow, float tHigh, int ksize, int type, uint8_t* d_edges, hipStream_t st,
                          bool waitConverged, bool clearTimeline = true, int expand = 1)
 {
@@ -607,20 +618,20 @@ static int planCannyImpl(compvhip_plan* p, const uint8_t* d_in, float tLow, floa
 	if (rc) return rc;
 	HIPCHK(ctx, hipSetDevice(ctx->device));
 	if (p->timing && clearTimeline) timelineClear(p);
-	// The kernel-size-3 tile kernel writes masks only (in-place calls need no scratch: the bytes are expanded after every input row
-	// was read).  The first-generation kernel (kernel size 5) also writes a byte map while neighbouring tiles may still read their
-	// row halo: when in and out alias it gets a scratch target; its bytes are overwritten by the expansion anyway.
+	const bool tileBytes = canny_tiles_write_bytes(ksize);
 	uint8_t* out = d_edges;
 	const size_t bytes = p->S * p->H * p->frames;
 	const bool alias = (d_in < d_edges + bytes) && (d_edges < d_in + bytes);
-	if (alias && canny_tiles_write_bytes(ksize)) {
+	if (alias && tileBytes) {
 		if (!p->tmpOut) HIPCHK(ctx, dmalloc(ctx, &p->tmpOut, bytes));
 		out = p->tmpOut;
 	}
+	p->patchOut = tileBytes ? out : nullptr;
+	p->copyBack = (alias && tileBytes) ? d_edges : nullptr;
 	if (p->W < static_cast<size_t>(ksize) || p->H < static_cast<size_t>(ksize)) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "image smaller than the kernel"); // compv_math_convlt.h:100
 	rc = enqueueCanny(p, d_in, out, lo, hi, ksize, type, tLow, tHigh, st);
 	if (rc) return rc;
-	rc = enqueueResolve(p, out, kSpecRounds, st);
+	rc = enqueueResolve(p, p->patchOut, kSpecRounds, st);
 	if (rc) return rc;
 	if (waitConverged) {
 		for (;;) {
@@ -628,11 +639,12 @@ static int planCannyImpl(compvhip_plan* p, const uint8_t* d_in, float tLow, floa
 			rc = resolveConverged(p, st, &done);
 			if (rc) return rc;
 			if (done) break;
-			rc = enqueueResolve(p, out, kSpecRounds, st);
+			rc = enqueueResolve(p, p->patchOut, kSpecRounds, st);
 			if (rc) return rc;
 		}
 	}
-	if (expand == 1) { rc = enqueueExpand(p, d_edges, st, false); if (rc) return rc; }
+	if (tileBytes) { if (p->copyBack) HIPCHK(ctx, hipMemcpyAsync(p->copyBack, out, bytes, hipMemcpyDeviceToDevice, st)); }
+	else if (expand == 1) { rc = enqueueExpand(p, d_edges, st, false); if (rc) return rc; }
 	p->bitsValid = true;
 	return COMPVHIP_OK;
 }
@@ -732,8 +744,10 @@ int compvhip_plan_edge_dete(compvhip_plan* p, const uint8_t* d_in, int op, uint8
 	return COMPVHIP_OK;
 }
 
+// expandTo != NULL (the pipeline): the edge bytes are expanded from the E masks on the side stream, forked behind the vote launch so
+// that the 1 B/px of stores overlaps the small kernels of the line stage (NMS, radix sort passes, decode) instead of the LDS-bound vote.
 static int planShtImpl(compvhip_plan* p, const uint8_t* d_edges, int threshold, int maxLines, compvhip_line* d_lines, size_t lineCap, int32_t* d_counts,
-                       hipStream_t st, bool clearTimeline)
+                       hipStream_t st, bool clearTimeline, uint8_t* expandTo = nullptr)
 {
 	compvhip_ctx* ctx = p->ctx;
 	if (threshold <= 0) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "threshold must be > 0"); // houghsht.cxx:82
@@ -756,6 +770,7 @@ static int planShtImpl(compvhip_plan* p, const uint8_t* d_edges, int threshold, 
 	p->countersFresh = false;
 	{ Stamp s(p, st, "sht_compact_kernel"); HIPCHK(ctx, launch_sht_compact(a, frames, st)); }
 	{ Stamp s(p, st, "sht_vote_kernel"); HIPCHK(ctx, launch_sht_vote(a, frames, st)); }
+	if (expandTo) { rc = enqueueExpand(p, expandTo, st, true); if (rc) return rc; }
 	{ Stamp s(p, st, "sht_nms_kernel"); HIPCHK(ctx, launch_sht_nms(a, frames, st)); }
 	{
 		Stamp s(p, st, "sht_sort_lines");
@@ -789,10 +804,10 @@ int compvhip_plan_pipeline(compvhip_plan* p, const uint8_t* d_in, float tLow, fl
 	// needed more rounds, the tail is replayed.
 	int rc = planCannyImpl(p, d_in, tLow, tHigh, 3, COMPVHIP_CANNY_THRESHOLD_COMPARE_TO_GRADIENT, d_edges, st, false, true, 0);
 	if (rc) return rc;
-	rc = enqueueExpand(p, d_edges, st, true);
-	if (rc) return rc;
+	uint8_t* const expandTo = p->patchOut ? nullptr : d_edges; // masks-only tile kernel: the bytes are expanded next to the line stage
+	const size_t bytes = p->S * p->H * p->frames;
 	for (;;) {
-		rc = planShtImpl(p, nullptr, threshold, maxLines, d_lines, lineCap, d_counts, st, false);
+		rc = planShtImpl(p, nullptr, threshold, maxLines, d_lines, lineCap, d_counts, st, false, expandTo);
 		if (rc) return rc;
 		rc = joinSide(p, st);
 		if (rc) return rc;
@@ -801,13 +816,13 @@ int compvhip_plan_pipeline(compvhip_plan* p, const uint8_t* d_in, float tLow, fl
 		if (rc) return rc;
 		if (done) break;
 		do {
-			rc = enqueueResolve(p, nullptr, kSpecRounds, st);
+			rc = enqueueResolve(p, p->patchOut, kSpecRounds, st);
 			if (rc) return rc;
 			rc = resolveConverged(p, st, &done);
 			if (rc) return rc;
 		} while (!done);
-		rc = enqueueExpand(p, d_edges, st, false);
-		if (rc) return rc;
+		if (p->copyBack) HIPCHK(p->ctx, hipMemcpyAsync(p->copyBack, p->patchOut, bytes, hipMemcpyDeviceToDevice, st));
+		// replay of the Hough stage on the now final masks (a masks-only byte map is expanded again next to it)
 	}
 	return COMPVHIP_OK;
 }
@@ -833,9 +848,7 @@ int compvhip_plan_pipeline_async(compvhip_plan* p, const uint8_t* d_in, float tL
 	// timing events of asynchronous steps accumulate until compvhip_plan_get_timing reads them (nothing is cleared per step)
 	int rc = planCannyImpl(p, d_in, tLow, tHigh, 3, COMPVHIP_CANNY_THRESHOLD_COMPARE_TO_GRADIENT, d_edges, st, false, false, 0);
 	if (rc) return rc;
-	rc = enqueueExpand(p, d_edges, st, true); // edge bytes on the side stream, next to the Hough stage
-	if (rc) return rc;
-	rc = planShtImpl(p, nullptr, threshold, maxLines, d_lines, lineCap, d_counts, st, false);
+	rc = planShtImpl(p, nullptr, threshold, maxLines, d_lines, lineCap, d_counts, st, false, p->patchOut ? nullptr : d_edges); // masks-only: bytes on the side stream
 	if (rc) return rc;
 	rc = joinSide(p, st);
 	if (rc) return rc;

@@ -341,6 +341,23 @@ __global__ __launch_bounds__(kResolveThreads) void canny_resolve_kernel(ResolveA
 	uint32_t* __restrict__ gU = a.ubits + (size_t)frame * a.bitsFrameStride;
 	const int tid = threadIdx.x;
 
+	// Per-workgroup change flags, four generations (round & 3): a workgroup whose 3x3 neighbourhood of (band, chunk) cells changed
+	// nothing in the previous round is at its fixed point already -- its E/U words and its halo are what it last saw -- and only
+	// records "no change".  Every workgroup that gets here writes its own cell, so the buffer needs no clearing.
+	const int nb = gridDim.y, nc = gridDim.x;
+	const size_t cells = (size_t)gridDim.z * nb * nc;
+	uint8_t* const mine = a.dirty + (size_t)(a.round & 3) * cells + ((size_t)frame * nb + band) * nc + chunk;
+	if (a.round > 0) {
+		const uint8_t* prev = a.dirty + (size_t)((a.round - 1) & 3) * cells + (size_t)frame * nb * nc;
+		int any = 0;
+		for (int db = -1; db <= 1; ++db)
+			for (int dc = -1; dc <= 1; ++dc) {
+				const int b2 = band + db, c2 = chunk + dc;
+				if (b2 >= 0 && b2 < nb && c2 >= 0 && c2 < nc) any |= prev[b2 * nc + c2];
+			}
+		if (!any) { if (tid == 0) *mine = 0; return; } // uniform
+	}
+
 	// load U; bail out early when the band has nothing unresolved
 	int haveU = 0;
 	for (int i = tid; i < rows * cw; i += kResolveThreads) {
@@ -349,7 +366,7 @@ __global__ __launch_bounds__(kResolveThreads) void canny_resolve_kernel(ResolveA
 		sU[r * cw + k] = u;
 		haveU |= (u != 0);
 	}
-	if (!__syncthreads_or(haveU)) return;
+	if (!__syncthreads_or(haveU)) { if (tid == 0) *mine = 0; return; }
 	for (int i = tid; i < (rows + 2) * ew; i += kResolveThreads) {
 		const int r = i / ew, k = i - r * ew;
 		const int y = y0 - 1 + r, w = w0 - 1 + k;
@@ -408,8 +425,10 @@ __global__ __launch_bounds__(kResolveThreads) void canny_resolve_kernel(ResolveA
 			}
 		}
 	}
-	if (__syncthreads_or(wrote)) {
-		if (tid == 0) a.flags[a.round] = 1; // benign race: every writer stores 1
+	const int w = __syncthreads_or(wrote);
+	if (tid == 0) {
+		*mine = w ? 1 : 0;
+		if (w) a.flags[a.round] = 1; // benign race: every writer stores 1
 	}
 }
 
@@ -484,12 +503,14 @@ __global__ void mean_thresholds_kernel(const unsigned int* __restrict__ sums, in
 // ---------------------------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------------------------
-// kernel size 3: the SWAR + candidate-list kernel (canny_swar_kernels.hip); COMPVHIP_CANNY_IMPL=ring selects this file's first-generation
-// kernel for A/B measurements.  Kernel size 5 always runs here.
+// Two tile kernels exist for kernel size 3: this file's register-ring kernel (dense NMS, writes the edge bytes itself) and the SWAR +
+// candidate-list kernel of canny_swar_kernels.hip (masks only; the bytes come from canny_expand_kernel).  Measured end to end on the
+// 32 x 4K benchmark step the ring kernel is still the faster pipeline, so it is the default;
+// COMPVHIP_CANNY_IMPL=swar selects the other one.  Kernel size 5 always runs here.
 static bool use_ring_kernel(int ksize)
 {
-	static const bool ring = [] { const char* e = getenv("COMPVHIP_CANNY_IMPL"); return e && !strcmp(e, "ring"); }();
-	return ksize == 5 || ring;
+	static const bool swar = [] { const char* e = getenv("COMPVHIP_CANNY_IMPL"); return e && !strcmp(e, "swar"); }();
+	return ksize == 5 || !swar;
 }
 bool canny_tiles_write_bytes(int ksize) { return use_ring_kernel(ksize); }
 
@@ -510,6 +531,12 @@ hipError_t launch_canny_tiles(const CannyArgs& a0, int frames, bool gap, hipStre
 		else hipLaunchKernelGGL((canny_tile_kernel<3, false>), grid, block, 0, stream, a);
 	}
 	return hipGetLastError();
+}
+
+size_t canny_resolve_dirty_bytes(int H, int wb, int frames)
+{
+	const size_t bands = (H + kBandH - 1) / kBandH, chunks = (wb + kBandWords - 1) / kBandWords;
+	return 4 * bands * chunks * (size_t)frames;
 }
 
 size_t resolve_lds_bytes()

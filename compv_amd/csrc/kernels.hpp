@@ -28,7 +28,6 @@ struct CannyArgs {
 	int simdEnd, cStart;      // quirk Q3 coverage: [1,simdEnd) U [cStart,W-1)
 	int blockRows, groups;    // filled by the launcher: workgroup rows per frame, row groups in the launch (XCD-aware map)
 	int ksize;                // Sobel kernel size of the gradient: 3 or 5
-	int dbg;                  // measurement knob (COMPVHIP_CANNY_DBG, results become wrong): 1 no flood, 2 no NMS passes, 4 no candidate lists
 };
 
 struct ResolveArgs {
@@ -36,6 +35,7 @@ struct ResolveArgs {
 	uint32_t* ubits;
 	uint8_t* out;             // byte map to patch, or nullptr when canny_expand_kernel rebuilds it from the masks afterwards
 	int* flags;               // flags[round] = 1 when round changed something
+	uint8_t* dirty;           // [4][frames][bands][chunks]: which workgroups changed their band in round (r & 3)
 	size_t outFrameStride, bitsFrameStride;
 	int H, So, wb;
 	int round;
@@ -45,6 +45,7 @@ hipError_t launch_canny_tiles(const CannyArgs& a, int frames, bool gap, hipStrea
 bool canny_tiles_write_bytes(int ksize); // true for the first-generation tile kernel (kernel size 5, or COMPVHIP_CANNY_IMPL=ring)
 hipError_t launch_canny_tiles_swar(const CannyArgs& a, int frames, bool gap, hipStream_t stream); // kernel size 3 (canny_swar_kernels.hip)
 hipError_t launch_canny_resolve(const ResolveArgs& a, int frames, hipStream_t stream);
+size_t canny_resolve_dirty_bytes(int H, int wb, int frames);
 // edge bytes {0,0xff} from the final E masks (1 bit/px): out[frames][H][So]
 hipError_t launch_canny_expand(const uint32_t* ebits, int wb, size_t bitsFrameStride, int H, int So, uint8_t* out, size_t outFrameStride, int frames,
                                hipStream_t stream);

@@ -65,7 +65,7 @@ def test_plan_blur_then_canny_batch(hip_ctx, oracle):
     d_edges = torch.empty_like(d)
     plan = capi.Plan(hip_ctx, W, H, S, F, 1.0)
     try:
-        d_blur = torch.empty_like(d)
+        d_blur = torch.zeros_like(d)                                           # the kernels write the W valid columns only: keep the stride padding defined
         plan.convlt_fixedpoint(d.data_ptr(), kern, kern, d_blur.data_ptr())   # out of place: fused single-kernel path
         plan.convlt_fixedpoint(d.data_ptr(), kern, kern, d.data_ptr())        # in place: two passes through the plan's scratch
         torch.cuda.synchronize()
