@@ -37,7 +37,7 @@ EXPORTS = [
     "compvhip_plan_set_timing", "compvhip_plan_get_timing", "compvhip_plan_acc_export", "compvhip_plan_edge_dete",
     "compvhip_houghkht_u8", "compvhip_grayscale_u8", "compvhip_otsu_u8", "compvhip_plan_grayscale", "compvhip_plan_otsu",
     "compvhip_gauss_kernel_fixedpoint", "compvhip_convlt1_fixedpoint_u8", "compvhip_plan_convlt1_fixedpoint", "compvhip_plan_to_cartesian",
-    "compvhip_plan_pipeline_async", "compvhip_plan_wait",
+    "compvhip_plan_pipeline_async", "compvhip_plan_wait", "compvhip_houghsht_to_cartesian", "compvhip_houghkht_to_cartesian",
 ]
 
 
@@ -316,6 +316,22 @@ class Plan:
         ms = (C.c_float * cap)()
         n = self.lib.compvhip_plan_get_timing(self.h, names, ms, cap)
         return [(names[i].decode(), ms[i]) for i in range(max(n, 0))]
+
+
+def to_cartesian(W, H, lines, kht=False):
+    """CompVHoughSht / CompVHoughKht::toCartesian for (rho, theta) pairs: (n, 4) float32 a.x, a.y, b.x, b.y (host arithmetic, no GPU needed)."""
+    L = load()
+    n = len(lines)
+    buf = np.zeros(max(n, 1), LINE_DTYPE)
+    for i, l in enumerate(lines):
+        buf[i]["rho"] = l[0]; buf[i]["theta"] = l[1]
+    out = np.zeros((max(n, 1), 4), np.float32)
+    fn = L.compvhip_houghkht_to_cartesian if kht else L.compvhip_houghsht_to_cartesian
+    fn.argtypes = [C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
+    rc = fn(W, H, _ptr(buf), n, _ptr(out))
+    if rc != OK:
+        raise CompvHipError(rc, "invalid toCartesian parameters")
+    return out[:n]
 
 
 def gauss_kernel_fixedpoint(size, sigma):

@@ -516,6 +516,37 @@ void compvhip_ctx_destroy(compvhip_ctx* ctx)
 const char* compvhip_last_error(const compvhip_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 long compvhip_live_allocations(const compvhip_ctx* ctx) { return ctx ? ctx->live : 0; }
 
+int compvhip_houghsht_to_cartesian(size_t W, size_t H, const compvhip_line* lines, size_t n, float* out)
+{
+	if (!W || !H || (n && (!lines || !out))) return COMPVHIP_E_INVALID_PARAMETER; // houghsht.cxx:268
+	const float widthF = static_cast<float>(W), heightF = static_cast<float>(H);
+	const float r = std::sqrt((widthF * widthF) + (heightF * heightF));
+	for (size_t i = 0; i < n; ++i, out += 4) {
+		const float rho = lines[i].rho, theta = lines[i].theta;
+		if (theta == 0.f) { out[0] = rho; out[1] = r; out[2] = rho; out[3] = -r; continue; }
+		const float c = libmCosf(theta), inv = 1.f / libmSinf(theta);
+		out[0] = 0.f; out[1] = rho * inv;
+		out[2] = widthF; out[3] = (rho - (widthF * c)) * inv;
+	}
+	return COMPVHIP_OK;
+}
+
+int compvhip_houghkht_to_cartesian(size_t W, size_t H, const compvhip_line* lines, size_t n, float* out)
+{
+	if (!W || !H || (n && (!lines || !out))) return COMPVHIP_E_INVALID_PARAMETER; // houghkht.cxx:453
+	const float widthF = static_cast<float>(W), heightF = static_cast<float>(H);
+	const float r = std::sqrt((widthF * widthF) + (heightF * heightF));
+	const float halfW = widthF * 0.5f, halfH = heightF * 0.5f;
+	for (size_t i = 0; i < n; ++i, out += 4) {
+		const float rho = lines[i].rho, theta = lines[i].theta;
+		if (theta == 0.f) { out[0] = rho + halfW; out[1] = r; out[2] = rho + halfW; out[3] = -r; continue; }
+		const float c = libmCosf(theta) * halfW, inv = 1.f / libmSinf(theta);
+		out[0] = 0.f; out[1] = ((rho + c) * inv) + halfH;
+		out[2] = widthF; out[3] = ((rho - c) * inv) + halfH;
+	}
+	return COMPVHIP_OK;
+}
+
 int compvhip_houghsht_dims(size_t W, size_t H, float thetaDeg, size_t* R, size_t* T, float* step)
 {
 	if (!R || !T) return COMPVHIP_E_INVALID_PARAMETER;
@@ -1119,7 +1150,7 @@ int compvhip_houghkht_u8(compvhip_ctx* ctx, const uint8_t* edges, size_t W, size
 	if (!ctx) return COMPVHIP_E_INVALID_PARAMETER;
 	if (!edges || !n || (cap && !lines) || S < W || !W || !H) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "null/invalid argument"); // houghkht.cxx:210-211
 	if (!(rho > 0.f) || rho > 1.f || !(thetaDeg > 0.f) || threshold <= 0) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "rho in (0,1], theta > 0, threshold > 0"); // :146-163,491
-	if (!(clusterMinDeviation > 0.0) || !clusterMinSize || !(kernelMinHeight > 0.0)) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "invalid KHT knob"); // :169-186
+	if (!clusterMinSize || !(kernelMinHeight >= 0.0)) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "invalid KHT knob"); // :169-186 (the deviation is unchecked there)
 	if (W > 32767 || H > 32767) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "image size out of range");
 	*n = 0;
 	KhtAxes ax;

@@ -140,8 +140,8 @@ COMPVHIP_API int compvhip_houghsht_u8(compvhip_ctx* ctx, const uint8_t* edges, s
 
 /* CompVHoughKht::process (core/features/hough/compv_core_feature_houghkht.cxx:208-447): kernel-based Hough transform.
  * rho in (0,1], thetaDeg in degrees, threshold on the 3x3-smoothed vote count, maxLines <= 0 keeps every line;
- * clusterMinDeviation / clusterMinSize / kernelMinHeight are the COMPV_HOUGHKHT_SET_* knobs (defaults 2.0, 10, 0.002,
- * houghkht.cxx:38-40).  Lines come back in the reference's order (descending smoothed count, the reference's own
+ * clusterMinDeviation / clusterMinSize (> 0) / kernelMinHeight (>= 0) are the COMPV_HOUGHKHT_SET_* knobs (defaults 2.0, 10, 0.002,
+ * houghkht.cxx:38-40; ranges as CompVHoughKht::set checks them, :169-186).  Lines come back in the reference's order (descending smoothed count, the reference's own
  * std::sort tie order); rho is measured from the image centre (toCartesian, :1249-1280); row/col of compvhip_line hold
  * the rho/theta indices.  *gs receives COMPV_HOUGHKHT_GET_FLT64_GS when kernels survive (left untouched otherwise, like
  * the reference's m_dGS).  Hybrid: edge linking, cluster subdivision, per-cluster statistics and the final sweep are
@@ -150,6 +150,15 @@ COMPVHIP_API int compvhip_houghkht_u8(compvhip_ctx* ctx, const uint8_t* edges, s
                                       float rho, float thetaDeg, int threshold, int maxLines,
                                       double clusterMinDeviation, size_t clusterMinSize, double kernelMinHeight,
                                       compvhip_line* lines, size_t cap, size_t* n, double* gs);
+
+/* CompVHoughSht::toCartesian (core/features/hough/compv_core_feature_houghsht.cxx:264-304,566-589) and
+ * CompVHoughKht::toCartesian (core/features/hough/compv_core_feature_houghkht.cxx:449-489,1249-1280) for caller-held polar lines:
+ * out[4 i ..] = {a.x, a.y, b.x, b.y} of line i (a.z = b.z = 1 in CompVLineFloat32).  SHT: rho from the image origin, endpoints at
+ * x = 0 and x = W; KHT: rho from the image centre.  theta == 0 is the perfect vertical line (x = rho, y = +-sqrt(W^2 + H^2)).
+ * Host float32 arithmetic in the reference's operation order (libm cosf / sinf called separately); no GPU involved.  Only the
+ * rho / theta fields of `lines` are read. */
+COMPVHIP_API int compvhip_houghsht_to_cartesian(size_t W, size_t H, const compvhip_line* lines, size_t n, float* out);
+COMPVHIP_API int compvhip_houghkht_to_cartesian(size_t W, size_t H, const compvhip_line* lines, size_t n, float* out);
 
 /* Geometry helper: R (rho rows), T (theta bins) and the float32 theta step for a W x H image
  * (initCoords, houghsht.cxx:318-348). */

@@ -148,6 +148,53 @@ static COMPV_ERROR_CODE runSamples(size_t W, size_t H, uint32_t seed, Result& r)
 	return COMPV_ERROR_CODE_S_OK;
 }
 
+// The option contract of the detector classes: the same set() / get() calls -- accepted and refused ones (wrong value size,
+// out-of-range value, unknown id) -- against whatever factories are registered; the return codes are compared CPU vs HIP.
+static std::vector<int> probeOptions()
+{
+	std::vector<int> codes;
+	CompVEdgeDetePtr canny; CompVHoughPtr sht, kht;
+	codes.push_back(CompVEdgeDete::newObj(&canny, COMPV_CANNY_ID, 10.f, 20.f, 3));
+	codes.push_back(CompVHough::newObj(&sht, COMPV_HOUGHSHT_ID, 1.f, 1.f, 10));
+	codes.push_back(CompVHough::newObj(&kht, COMPV_HOUGHKHT_ID, 0.5f, 1.f, 10));
+	CompVHoughPtr none;
+	codes.push_back(CompVHough::newObj(&none, COMPV_HOUGHKHT_ID, 1.5f, 1.f, 10));   // rho > 1
+	codes.push_back(CompVHough::newObj(&none, COMPV_HOUGHKHT_ID, 0.f, 1.f, 10));    // rho <= 0
+	if (!canny || !sht || !kht) return codes;
+	const float fpos = 0.5f, fneg = -1.f, fzero = 0.f, fbig = 2.f, fone = 1.f;
+	const int ipos = 7, izero = 0, ineg = -3, k3 = 3, k5 = 5, k4 = 4, tMean = COMPV_CANNY_THRESHOLD_TYPE_PERCENT_OF_MEAN, tBad = 12345;
+	const bool b = true; const double d = 1.0; const int64_t wide = 1;
+	struct Probe { int id; const void* p; size_t n; };
+	const Probe cannyProbes[] = {
+		{ COMPV_CANNY_SET_INT_THRESHOLD_TYPE, &tMean, sizeof(int) }, { COMPV_CANNY_SET_INT_THRESHOLD_TYPE, &tBad, sizeof(int) }, { COMPV_CANNY_SET_INT_THRESHOLD_TYPE, &wide, sizeof(wide) },
+		{ COMPV_CANNY_SET_FLT32_THRESHOLD_LOW, &fpos, sizeof(float) }, { COMPV_CANNY_SET_FLT32_THRESHOLD_LOW, &fzero, sizeof(float) }, { COMPV_CANNY_SET_FLT32_THRESHOLD_LOW, &d, sizeof(d) },
+		{ COMPV_CANNY_SET_FLT32_THRESHOLD_HIGH, &fbig, sizeof(float) }, { COMPV_CANNY_SET_FLT32_THRESHOLD_HIGH, &fneg, sizeof(float) },
+		{ COMPV_CANNY_SET_INT_KERNEL_SIZE, &k3, sizeof(int) }, { COMPV_CANNY_SET_INT_KERNEL_SIZE, &k5, sizeof(int) }, { COMPV_CANNY_SET_INT_KERNEL_SIZE, &k4, sizeof(int) },
+		{ COMPV_CANNY_SET_INT_KERNEL_SIZE, NULL, sizeof(int) }, { COMPV_CANNY_SET_INT_KERNEL_SIZE, &k3, 0 },
+	};
+	for (const Probe& q : cannyProbes) codes.push_back(canny->set(q.id, q.p, q.n));
+	const Probe houghProbes[] = {
+		{ COMPV_HOUGH_SET_FLT32_RHO, &fone, sizeof(float) }, { COMPV_HOUGH_SET_FLT32_RHO, &fpos, sizeof(float) }, { COMPV_HOUGH_SET_FLT32_RHO, &fbig, sizeof(float) }, { COMPV_HOUGH_SET_FLT32_RHO, &fzero, sizeof(float) },
+		{ COMPV_HOUGH_SET_FLT32_THETA, &fpos, sizeof(float) }, { COMPV_HOUGH_SET_FLT32_THETA, &fneg, sizeof(float) }, { COMPV_HOUGH_SET_FLT32_THETA, &d, sizeof(d) },
+		{ COMPV_HOUGH_SET_INT_THRESHOLD, &ipos, sizeof(int) }, { COMPV_HOUGH_SET_INT_THRESHOLD, &izero, sizeof(int) }, { COMPV_HOUGH_SET_INT_THRESHOLD, &wide, sizeof(wide) },
+		{ COMPV_HOUGH_SET_INT_MAXLINES, &ipos, sizeof(int) }, { COMPV_HOUGH_SET_INT_MAXLINES, &ineg, sizeof(int) }, { COMPV_HOUGH_SET_INT_MAXLINES, &b, sizeof(b) },
+		{ COMPV_HOUGHKHT_SET_FLT32_CLUSTER_MIN_DEVIATION, &fpos, sizeof(float) }, { COMPV_HOUGHKHT_SET_FLT32_CLUSTER_MIN_DEVIATION, &fzero, sizeof(float) },
+		{ COMPV_HOUGHKHT_SET_INT_CLUSTER_MIN_SIZE, &ipos, sizeof(int) }, { COMPV_HOUGHKHT_SET_INT_CLUSTER_MIN_SIZE, &izero, sizeof(int) },
+		{ COMPV_HOUGHKHT_SET_FLT32_KERNEL_MIN_HEIGTH, &fpos, sizeof(float) }, { COMPV_HOUGHKHT_SET_FLT32_KERNEL_MIN_HEIGTH, &fneg, sizeof(float) },
+		{ COMPV_HOUGHKHT_SET_BOOL_OVERRIDE_INPUT_EDGES, &b, sizeof(b) }, { COMPV_HOUGHKHT_SET_BOOL_OVERRIDE_INPUT_EDGES, &ipos, sizeof(int) },
+		{ 987654, &ipos, sizeof(int) },
+	};
+	for (const Probe& q : houghProbes) { codes.push_back(sht->set(q.id, q.p, q.n)); codes.push_back(kht->set(q.id, q.p, q.n)); }
+	compv_float64_t gs = -1; float notDouble = 0.f;
+	codes.push_back(kht->getFloat64(COMPV_HOUGHKHT_GET_FLT64_GS, &gs)); codes.push_back(gs == 1.0 ? 0 : 1);
+	const void* pp = &notDouble;
+	codes.push_back(kht->get(COMPV_HOUGHKHT_GET_FLT64_GS, &pp, sizeof(float)));
+	codes.push_back(kht->get(424242, &pp, sizeof(compv_float64_t)));
+	CompVLineFloat32Vector cart; CompVHoughLineVector polar;
+	codes.push_back(sht->toCartesian(0, 10, polar, cart)); codes.push_back(kht->toCartesian(10, 0, polar, cart)); codes.push_back(sht->toCartesian(10, 10, polar, cart));
+	return codes;
+}
+
 // samples/hough_lines/main.cxx:102-105 on a packed RGB24 camera frame: convertGrayscale -> thresholdOtsu -> Canny thresholds.
 // CompVImage::convertGrayscale / thresholdOtsu are static functions (no factory to swap), so the HIP side is the C ABI a
 // maintainer would call from inside them: both results must be identical.
@@ -195,7 +242,9 @@ int main(int argc, char** argv)
 		if (COMPV_ERROR_CODE_IS_NOK(runSamples(W, H, 12345u + f, cpu[f]))) { fprintf(stderr, "CPU run failed\n"); return 3; }
 	}
 	resetObjects();
+	const std::vector<int> optCpu = probeOptions();
 	if (compv_hip_plugin_register() != 0) { fprintf(stderr, "HIP plugin registration failed (no GPU?)\n"); return 4; }
+	const std::vector<int> optHip = probeOptions();
 	for (int f = 0; f < frames; ++f) {
 		if (COMPV_ERROR_CODE_IS_NOK(runSamples(W, H, 12345u + f, gpu[f]))) { fprintf(stderr, "HIP run failed\n"); return 5; }
 	}
@@ -210,6 +259,13 @@ int main(int argc, char** argv)
 		bad += !(okS && okC && okM && okL && okX && okK);
 	}
 	resetObjects();
+	{
+		size_t diff = 0;
+		for (size_t i = 0; i < optCpu.size() && i < optHip.size(); ++i) if (optCpu[i] != optHip[i]) { ++diff; printf("  option probe %zu: CompV %d, HIP %d\n", i, optCpu[i], optHip[i]); }
+		diff += optCpu.size() != optHip.size();
+		printf("option contract (%zu set/get/newObj/toCartesian probes): %s\n", optCpu.size(), diff ? "DIFF" : "==");
+		bad += diff != 0;
+	}
 	bad += checkPreproc(W, H, 4242u) != 0;
 	printf(bad ? "DROP-IN PARITY FAILED\n" : "DROP-IN PARITY OK\n");
 	return bad ? 1 : 0;

@@ -622,3 +622,21 @@ void orc_sht_to_cartesian(size_t W, size_t H, const orc_line* lines, size_t n, f
 		}
 	}
 }
+
+/* CompVHoughKht::toCartesian, core/features/hough/compv_core_feature_houghkht.cxx:1249-1280: rho is measured from the image centre */
+void orc_kht_to_cartesian(size_t W, size_t H, const orc_line* lines, size_t n, float* out)
+{
+	const float widthF = (float)W, heightF = (float)H;
+	const float r = sqrtf((widthF * widthF) + (heightF * heightF));
+	const float half_widthF = widthF * 0.5f, half_heightF = heightF * 0.5f;
+	for (size_t i = 0; i < n; ++i) {
+		const float rho = lines[i].rho, theta = lines[i].theta;
+		float* o = out + 4 * i;
+		if (theta == 0.f) { o[0] = o[2] = (rho + half_widthF); o[1] = r; o[3] = -r; }
+		else {
+			const float a = (cosf(theta) * half_widthF), b = (1.f / sinf(theta));
+			o[0] = 0.f; o[1] = ((rho + a) * b) + half_heightF;
+			o[2] = widthF; o[3] = ((rho - a) * b) + half_heightF;
+		}
+	}
+}

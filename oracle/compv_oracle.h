@@ -86,6 +86,7 @@ int orc_convlt1_fixedpoint(const uint8_t* in, size_t W, size_t H, size_t S, cons
 
 /* CompVHoughSht::toCartesian (core/features/hough/compv_core_feature_houghsht.cxx:566-589): out[4*i..] = a.x, a.y, b.x, b.y */
 void orc_sht_to_cartesian(size_t W, size_t H, const orc_line* lines, size_t n, float* out);
+void orc_kht_to_cartesian(size_t W, size_t H, const orc_line* lines, size_t n, float* out);
 
 #ifdef __cplusplus
 }

@@ -290,11 +290,14 @@ int refshim_convlt1_fixedpoint(const uint8_t* in, size_t W, size_t H, size_t S, 
 	return 0;
 }
 
-// CompVHoughSht::toCartesian on caller-provided polar lines: out[4*i..] = a.x, a.y, b.x, b.y
-int refshim_sht_to_cartesian(size_t W, size_t H, const RefLine* lines, size_t n, float* out)
+// CompVHoughSht / CompVHoughKht::toCartesian on caller-provided polar lines: out[4*i..] = a.x, a.y, b.x, b.y
+static int to_cartesian(int id, size_t W, size_t H, const RefLine* lines, size_t n, float* out);
+int refshim_sht_to_cartesian(size_t W, size_t H, const RefLine* lines, size_t n, float* out) { return to_cartesian(COMPV_HOUGHSHT_ID, W, H, lines, n, out); }
+int refshim_kht_to_cartesian(size_t W, size_t H, const RefLine* lines, size_t n, float* out) { return to_cartesian(COMPV_HOUGHKHT_ID, W, H, lines, n, out); }
+static int to_cartesian(int id, size_t W, size_t H, const RefLine* lines, size_t n, float* out)
 {
 	CompVHoughPtr h;
-	if (COMPV_ERROR_CODE_IS_NOK(CompVHough::newObj(&h, COMPV_HOUGHSHT_ID, 1.f, 1.f, 1))) return -2;
+	if (COMPV_ERROR_CODE_IS_NOK(CompVHough::newObj(&h, id, 1.f, 1.f, 1))) return -2;
 	CompVHoughLineVector polar(n);
 	for (size_t i = 0; i < n; ++i) { polar[i].rho = lines[i].rho; polar[i].theta = lines[i].theta; polar[i].strength = (size_t)lines[i].strength; }
 	CompVLineFloat32Vector cart;

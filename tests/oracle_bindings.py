@@ -117,18 +117,21 @@ class Oracle:
         self.lib.orc_synth_frame(_p(out), W, H, W, seed)
         return out
 
-    def sht_to_cartesian(self, W, H, lines):
-        """lines: iterable of (rho, theta, ...) -> (n, 4) float32 array a.x, a.y, b.x, b.y (CompVHoughSht::toCartesian)."""
+    def sht_to_cartesian(self, W, H, lines, kht=False):
+        """lines: iterable of (rho, theta, ...) -> (n, 4) float32 array a.x, a.y, b.x, b.y (CompVHoughSht / CompVHoughKht::toCartesian)."""
         n = len(lines)
         buf = (OrcLine * max(n, 1))()
         for i, l in enumerate(lines):
             buf[i].rho = l[0]; buf[i].theta = l[1]
         out = np.zeros((max(n, 1), 4), np.float32)
-        L = self.lib
-        L.orc_sht_to_cartesian.argtypes = [C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
-        L.orc_sht_to_cartesian.restype = None
-        L.orc_sht_to_cartesian(W, H, buf, n, _p(out))
+        fn = self.lib.orc_kht_to_cartesian if kht else self.lib.orc_sht_to_cartesian
+        fn.argtypes = [C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
+        fn.restype = None
+        fn(W, H, buf, n, _p(out))
         return out[:n]
+
+    def kht_to_cartesian(self, W, H, lines):
+        return self.sht_to_cartesian(W, H, lines, kht=True)
 
     # ---- optional Gaussian pre-blur (SURVEY 8f row 2) ----
     def gauss_kernel_f32(self, size, sigma):
@@ -310,16 +313,19 @@ class RefShim:
         assert self.lib.refshim_init(threads) == 0
         self.threads = self.lib.refshim_threads()
 
-    def sht_to_cartesian(self, W, H, lines):
+    def sht_to_cartesian(self, W, H, lines, kht=False):
         n = len(lines)
         buf = (RefLine * max(n, 1))()
         for i, l in enumerate(lines):
             buf[i].rho = l[0]; buf[i].theta = l[1]; buf[i].strength = 1
         out = np.zeros((max(n, 1), 4), np.float32)
-        L = self.lib
-        L.refshim_sht_to_cartesian.argtypes = [C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
-        assert L.refshim_sht_to_cartesian(W, H, buf, n, _p(out)) == 0
+        fn = self.lib.refshim_kht_to_cartesian if kht else self.lib.refshim_sht_to_cartesian
+        fn.argtypes = [C.c_size_t, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
+        assert fn(W, H, buf, n, _p(out)) == 0
         return out[:n]
+
+    def kht_to_cartesian(self, W, H, lines):
+        return self.sht_to_cartesian(W, H, lines, kht=True)
 
     def gauss_kernel_f32(self, size, sigma):
         k = np.zeros(size, np.float32)

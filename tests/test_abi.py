@@ -51,3 +51,24 @@ def test_product_never_touches_the_oracle():
             if f.endswith((".py", ".cpp", ".hip", ".hpp", ".h", "Makefile")):
                 txt = open(os.path.join(dirpath, f), errors="ignore").read()
                 assert "oracle" not in txt.replace("no oracle", ""), os.path.join(dirpath, f)
+
+
+def test_to_cartesian_host_helpers_match_oracle_and_reference(oracle):
+    """compvhip_houghsht_to_cartesian / compvhip_houghkht_to_cartesian (host float32 arithmetic behind the C ABI, what the plugin
+    classes call) against the oracle and, where the compiled reference is present, against CompVHoughSht / CompVHoughKht::toCartesian
+    themselves: bit patterns of all four endpoints, including the theta == 0 branch."""
+    import numpy as np
+    from compv_amd import capi
+    from oracle_bindings import RefShim, have_refshim
+    rng = np.random.default_rng(7)
+    W, H = 1282, 720
+    lines = [(float(np.float32(r)), float(np.float32(t))) for r, t in zip(rng.uniform(-1500, 1500, 400), rng.uniform(0.0, 3.14159, 400))]
+    lines += [(123.0, 0.0), (-77.5, 0.0), (0.0, float(np.float32(1.5707964))), (640.0, float(np.float32(3.1241393)))]
+    ref = RefShim(1) if have_refshim() else None
+    for kht in (False, True):
+        got = capi.to_cartesian(W, H, lines, kht=kht)
+        exp = oracle.sht_to_cartesian(W, H, lines, kht=kht)
+        assert got.view(np.uint32).tolist() == exp.view(np.uint32).tolist(), kht
+        if ref is not None:
+            assert got.view(np.uint32).tolist() == ref.sht_to_cartesian(W, H, lines, kht=kht).view(np.uint32).tolist(), kht
+    assert capi.to_cartesian(W, H, []).shape == (0, 4)
