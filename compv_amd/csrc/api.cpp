@@ -59,7 +59,8 @@ struct compvhip_plan {
 	int tilesX = 0, tilesY = 0, wb = 0;
 	size_t bitsFrameStride = 0;
 	uint32_t* ebits = nullptr; uint32_t* ubits = nullptr;
-	int* counters = nullptr;  // ONE device allocation zeroed by ONE memset per step: [edgeCounts frames][lineCounts frames][flags kMaxRounds]
+	int* counters = nullptr;  // ONE device allocation zeroed by ONE memset per step: [edgeCounts frames][lineCounts frames][tileCounts frames*tiles][flags kMaxRounds]
+	size_t nCounts = 0;       // ints in front of the flags
 	int* flags = nullptr; int* hFlags = nullptr; // device (inside counters) / pinned host (kAsyncDepth + 1 slots)
 	int roundsUsed = 0;
 	bool countersFresh = false; // the step's memset already zeroed the edge/line counts (no second fill in front of the SHT stage)
@@ -83,6 +84,11 @@ struct compvhip_plan {
 	void* sortTemp = nullptr; size_t sortTempBytes = 0;
 	int cellBits = 0, strengthBits = 16, keyBits = 0;
 	int shards = 1;
+	// second-generation voting: image tiles (planned at plan creation: the per-tile edge counters live in `counters`)
+	bool voteTiles = true;                       // COMPVHIP_SHT_VOTE=legacy selects the first-generation kernels
+	ShtTileArgs vt = {};                         // geometry + device tables
+	std::vector<int32_t> vtKt, vtRowBase;        // host copies of the [tiles][T] tables
+	int32_t* dKt = nullptr; int32_t* dRowBase = nullptr; uint16_t* partial = nullptr; int* tileCounts = nullptr;
 	// asynchronous steps (compvhip_plan_pipeline_async / compvhip_plan_wait)
 	struct AsyncStep {
 		bool used = false; hipEvent_t done = nullptr; hipStream_t stream = nullptr;
@@ -184,6 +190,60 @@ void shtTables(float thetaDeg, size_t T, std::vector<int32_t>& sinQ, std::vector
 	}
 }
 
+// ---- tiles of the second-generation vote kernel (sht_tiles_kernels.hip) ----
+// Smallest grid of equal tiles (width a multiple of 32 px) whose rho windows -- per theta, the span of (lx cosQ + ly sinQ + Clo) >> 16
+// over the tile -- have at most kShtMaxWindow rows; fills the [tiles][T] tables K and rowBase (int64 arithmetic here, int32 on the device).
+bool planVoteTiles(size_t W, size_t H, const std::vector<int32_t>& sinQ, const std::vector<int32_t>& cosQ, ShtTileArgs& v, std::vector<int32_t>& kt,
+                   std::vector<int32_t>& rowBase)
+{
+	const size_t T = sinQ.size();
+	const long long barrier = static_cast<long long>(W + H);
+	for (int split = 0; split < 64; ++split) {
+		// try grids in order of tile count: split the dimension with the longer tile side
+		int nx = 1, ny = 1;
+		for (int k = 0; k < split; ++k) {
+			const double tw = static_cast<double>(W) / nx, th = static_cast<double>(H) / ny;
+			if (tw >= th) ++nx; else ++ny;
+		}
+		const int TW = static_cast<int>(alignUp((W + nx - 1) / nx, 32)), TH = static_cast<int>((H + ny - 1) / ny);
+		nx = static_cast<int>((W + TW - 1) / TW); // the rounding to 32 columns may save a column of tiles
+		const int tiles = nx * ny;
+		kt.assign(static_cast<size_t>(tiles) * T, 0); rowBase.assign(static_cast<size_t>(tiles) * T, 0);
+		long long worst = 0;
+		for (int ty = 0; ty < ny; ++ty) for (int tx = 0; tx < nx; ++tx) {
+			const long long x0 = static_cast<long long>(tx) * TW, y0 = static_cast<long long>(ty) * TH;
+			const long long mx = TW - 1, my = TH - 1; // largest local coordinates (tiles at the image border are not clipped: simpler, still exact)
+			for (size_t t = 0; t < T; ++t) {
+				const long long c = cosQ[t], sn = sinQ[t];
+				const long long C = x0 * c + y0 * sn;
+				long long Chi = C / 65536; if (C - Chi * 65536 < 0) --Chi; // floor
+				const long long Clo = C - Chi * 65536;
+				const long long corners[4] = { Clo, mx * c + Clo, my * sn + Clo, mx * c + my * sn + Clo };
+				long long qmin = 0, qmax = 0;
+				for (int k = 0; k < 4; ++k) {
+					long long q = corners[k] / 65536; if (corners[k] - q * 65536 < 0) --q;
+					if (k == 0 || q < qmin) qmin = q;
+					if (k == 0 || q > qmax) qmax = q;
+				}
+				// the window starts on a multiple of 8 accumulator rows (d extra rows at its top): the reduce kernel adds whole 16-byte groups
+				const long long base = barrier - Chi - qmax;
+				const long long d = ((base % 8) + 8) % 8;
+				worst = std::max(worst, qmax - qmin + 1 + d);
+				kt[(static_cast<size_t>(ty) * nx + tx) * T + t] = static_cast<int32_t>((qmax + d) * 65536 + 65535 - Clo);
+				rowBase[(static_cast<size_t>(ty) * nx + tx) * T + t] = static_cast<int32_t>(base - d);
+			}
+		}
+		if (alignUp(static_cast<size_t>(worst), 8) <= static_cast<size_t>(kShtMaxWindow) && TW <= 2048 && static_cast<long long>(TW - 1) * 65535 + static_cast<long long>(TH - 1) * 65535 < 0x7f000000LL) {
+			v.nx = nx; v.ny = ny; v.TW = TW; v.TH = TH; v.tiles = tiles;
+			v.Rw = static_cast<int>(alignUp(static_cast<size_t>(worst), 8)); v.rwPitch = v.Rw;
+			v.groups = static_cast<int>((T + 63) / 64); v.Tpad = v.groups * 64;
+			v.tileCap = static_cast<size_t>(TW) * TH;
+			return true;
+		}
+	}
+	return false;
+}
+
 // timing mode 1 = every kernel; 2 = only the two kernels bench.py prices against the roofline (an event pair costs a few
 // microseconds of stream time, ~0.1 ms per step when wrapped around all ~13 launches of the pipeline)
 static bool stampWanted(const compvhip_plan* p, const char* name)
@@ -244,8 +304,10 @@ int ensureSht(compvhip_plan* p)
 	int rc = shtDims(p->W, p->H, p->thetaDeg, &R, &T, &step);
 	if (rc) return fail(ctx, rc, "invalid SHT geometry");
 	if (T < 5) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "theta step too large (fewer than 5 theta bins)");
-	if (p->W + p->H >= 65536) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "W+H must be < 65536 (u16 LDS vote counters)");
-	if (sht_vote_lds_bytes(static_cast<int>(R), 2) > 160 * 1024) return fail(ctx, COMPVHIP_E_NOT_IMPLEMENTED, "rho range does not fit the LDS histogram");
+	if (!p->voteTiles) {
+		if (p->W + p->H >= 65536) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "W+H must be < 65536 (u16 LDS vote counters)");
+		if (sht_vote_lds_bytes(static_cast<int>(R), 2) > 160 * 1024) return fail(ctx, COMPVHIP_E_NOT_IMPLEMENTED, "rho range does not fit the LDS histogram");
+	}
 	p->R = R; p->T = T; p->thetaStep = step;
 	p->accPitch = static_cast<int>(alignUp(R, 64));
 	p->accFrameStride = static_cast<size_t>(p->accPitch) * T;
@@ -293,6 +355,17 @@ int ensureSht(compvhip_plan* p)
 		HIPCHK(ctx, hipMemcpy(p->groupOrder, order.data(), groups * sizeof(int32_t), hipMemcpyHostToDevice));
 	}
 	p->edgeCap = p->W * p->H;
+	if (p->voteTiles) {
+		if (p->vt.tiles <= 0 || p->vtKt.size() != static_cast<size_t>(p->vt.tiles) * T) return fail(ctx, COMPVHIP_E_INVALID_STATE, "vote tiles were not planned");
+		dfree(ctx, p->dKt); dfree(ctx, p->dRowBase); dfree(ctx, p->partial);
+		HIPCHK(ctx, dmalloc(ctx, &p->dKt, p->vtKt.size()));
+		HIPCHK(ctx, dmalloc(ctx, &p->dRowBase, p->vtRowBase.size()));
+		HIPCHK(ctx, hipMemcpy(p->dKt, p->vtKt.data(), p->vtKt.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+		HIPCHK(ctx, hipMemcpy(p->dRowBase, p->vtRowBase.data(), p->vtRowBase.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+		HIPCHK(ctx, dmalloc(ctx, &p->partial, p->frames * p->vt.tiles * static_cast<size_t>(p->vt.Tpad) * p->vt.rwPitch));
+		p->vt.kt = p->dKt; p->vt.rowBase = p->dRowBase; p->vt.partial = p->partial; p->vt.tileCounts = p->tileCounts;
+		p->edgeCap = static_cast<size_t>(p->vt.tiles) * p->vt.tileCap; // per frame: one list of TW * TH entries per tile
+	}
 	HIPCHK(ctx, dmalloc(ctx, &p->edges, p->edgeCap * p->frames));
 	HIPCHK(ctx, dmalloc(ctx, &p->acc, p->accFrameStride * p->frames));
 	HIPCHK(ctx, hipMemset(p->acc, 0, sizeof(uint16_t) * p->accFrameStride * p->frames)); // rows [Rp, accPitch) stay zero for ever
@@ -382,7 +455,7 @@ int enqueueCanny(compvhip_plan* p, const uint8_t* d_in, uint8_t* d_out, int tLow
 		HIPCHK(ctx, launch_mean_thresholds(d_in, a.W, a.H, a.S, a.inFrameStride, static_cast<int>(p->frames), fLow, fHigh, p->sums, p->thrDev, st));
 	}
 	// ONE fill per step: edge counts, line counts and the hysteresis round flags live in one allocation
-	HIPCHK(ctx, hipMemsetAsync(p->counters, 0, sizeof(int) * (2 * p->frames + kMaxRounds), st));
+	HIPCHK(ctx, hipMemsetAsync(p->counters, 0, sizeof(int) * (p->nCounts + kMaxRounds), st));
 	p->countersFresh = true;
 	p->roundsUsed = 0;
 	{
@@ -579,9 +652,21 @@ int compvhip_plan_create(compvhip_ctx* ctx, size_t W, size_t H, size_t S, size_t
 		if (hipMemset(p->ubits, 0, sizeof(uint32_t) * p->bitsFrameStride * frames) != hipSuccess) { rc = COMPVHIP_E_HIP; break; }
 		// the fills run on the null stream; the plan's kernels may be enqueued on non-blocking streams that do not wait for it
 		if (hipDeviceSynchronize() != hipSuccess) { rc = COMPVHIP_E_HIP; break; }
-		if (dmalloc(ctx, &p->counters, 2 * frames + kMaxRounds) != hipSuccess) { rc = COMPVHIP_E_OUT_OF_MEMORY; break; }
-		p->edgeCounts = p->counters; p->lineCounts = p->counters + frames; p->flags = p->counters + 2 * frames;
-		if (hipMemset(p->counters, 0, sizeof(int) * (2 * frames + kMaxRounds)) != hipSuccess) { rc = COMPVHIP_E_HIP; break; }
+		{
+			static const bool legacy = [] { const char* e = getenv("COMPVHIP_SHT_VOTE"); return e && !strcmp(e, "legacy"); }();
+			p->voteTiles = !legacy;
+			size_t R = 0, T = 0; float step = 0.f;
+			if (p->voteTiles && shtDims(W, H, thetaDeg, &R, &T, &step) == COMPVHIP_OK && T >= 5) {
+				std::vector<int32_t> sq, cq;
+				shtTables(thetaDeg, T, sq, cq);
+				if (!planVoteTiles(W, H, sq, cq, p->vt, p->vtKt, p->vtRowBase)) p->voteTiles = false;
+			}
+			else p->voteTiles = false;
+			p->nCounts = (2 + static_cast<size_t>(p->voteTiles ? p->vt.tiles : 0)) * frames;
+		}
+		if (dmalloc(ctx, &p->counters, p->nCounts + kMaxRounds) != hipSuccess) { rc = COMPVHIP_E_OUT_OF_MEMORY; break; }
+		p->edgeCounts = p->counters; p->lineCounts = p->counters + frames; p->tileCounts = p->counters + 2 * frames; p->flags = p->counters + p->nCounts;
+		if (hipMemset(p->counters, 0, sizeof(int) * (p->nCounts + kMaxRounds)) != hipSuccess) { rc = COMPVHIP_E_HIP; break; }
 		if (dmalloc(ctx, &p->thrDev, frames) != hipSuccess) { rc = COMPVHIP_E_OUT_OF_MEMORY; break; }
 		if (dmalloc(ctx, &p->dirty, canny_resolve_dirty_bytes(static_cast<int>(H), p->wb, static_cast<int>(frames))) != hipSuccess) { rc = COMPVHIP_E_OUT_OF_MEMORY; break; }
 		if (dmalloc(ctx, &p->sums, frames) != hipSuccess) { rc = COMPVHIP_E_OUT_OF_MEMORY; break; }
@@ -608,6 +693,7 @@ void compvhip_plan_destroy(compvhip_plan* p)
 	if (p->hFlags) (void)hipHostFree(p->hFlags);
 	dfree(ctx, p->hist); dfree(ctx, p->otsu); dfree(ctx, p->blurTmp);
 	dfree(ctx, p->cosT); dfree(ctx, p->invSinT);
+	dfree(ctx, p->dKt); dfree(ctx, p->dRowBase); dfree(ctx, p->partial);
 	dfree(ctx, p->sinQ); dfree(ctx, p->cosQ); dfree(ctx, p->groupOrder); dfree(ctx, p->edges); dfree(ctx, p->acc);
 	dfree(ctx, p->keysA); dfree(ctx, p->keysB);
 	dfree(ctx, p->sortTemp);
@@ -797,10 +883,17 @@ static int planShtImpl(compvhip_plan* p, const uint8_t* d_edges, int threshold, 
 		p->bitsValid = false; // U masks no longer match
 	}
 	ShtArgs a = shtArgs(p, threshold);
-	if (!p->countersFresh) HIPCHK(ctx, hipMemsetAsync(p->counters, 0, sizeof(int) * 2 * p->frames, st)); // edge + line counts
+	if (!p->countersFresh) HIPCHK(ctx, hipMemsetAsync(p->counters, 0, sizeof(int) * p->nCounts, st)); // edge, line and tile counts
 	p->countersFresh = false;
-	{ Stamp s(p, st, "sht_compact_kernel"); HIPCHK(ctx, launch_sht_compact(a, frames, st)); }
-	{ Stamp s(p, st, "sht_vote_kernel"); HIPCHK(ctx, launch_sht_vote(a, frames, st)); }
+	if (p->voteTiles) {
+		{ Stamp s(p, st, "sht_compact_kernel"); HIPCHK(ctx, launch_sht_compact_tiles(a, p->vt, frames, st)); }
+		{ Stamp s(p, st, "sht_vote_kernel"); HIPCHK(ctx, launch_sht_vote_tiles(a, p->vt, frames, st)); }
+		{ Stamp s(p, st, "sht_reduce_kernel"); HIPCHK(ctx, launch_sht_reduce_tiles(a, p->vt, frames, st)); }
+	}
+	else {
+		{ Stamp s(p, st, "sht_compact_kernel"); HIPCHK(ctx, launch_sht_compact(a, frames, st)); }
+		{ Stamp s(p, st, "sht_vote_kernel"); HIPCHK(ctx, launch_sht_vote(a, frames, st)); }
+	}
 	if (expandTo) { rc = enqueueExpand(p, expandTo, st, true); if (rc) return rc; }
 	{ Stamp s(p, st, "sht_nms_kernel"); HIPCHK(ctx, launch_sht_nms(a, frames, st)); }
 	{

@@ -111,6 +111,21 @@ struct ShtArgs {
 	int thetaPerGroup;        // 4 (default) or 2 theta bins per vote workgroup
 	const int32_t* groupOrder; // vote workgroup rank -> theta group, most expensive groups (theta near 90, 0, 180 deg) first
 };
+// second-generation voting (sht_tiles_kernels.hip): image tiles, lane = theta
+struct ShtTileArgs {
+	const int32_t* kt;        // [tiles][T]  window constant K of (tile, theta): window row = (K - lx cosQ - ly sinQ) >> 16
+	const int32_t* rowBase;   // [tiles][T]  accumulator row of window row 0
+	uint16_t* partial;        // [frames][tiles][Tpad][rwPitch]  theta-major partial accumulators (one window per tile and theta)
+	int* tileCounts;          // [frames][tiles] edges per tile
+	int nx, ny, TW, TH, tiles;  // tile grid; TW % 32 == 0
+	int Rw, rwPitch;          // window rows (<= 1264), pitch of a partial row (multiple of 8)
+	int Tpad, groups;         // theta bins padded to groups * 64
+	size_t tileCap;           // edge-list entries per tile (TW * TH)
+};
+constexpr int kShtMaxWindow = 1264;   // window rows of a vote workgroup: 1264 * 128 B = 158 KB of LDS
+hipError_t launch_sht_compact_tiles(const ShtArgs& a, const ShtTileArgs& v, int frames, hipStream_t stream);
+hipError_t launch_sht_vote_tiles(const ShtArgs& a, const ShtTileArgs& v, int frames, hipStream_t stream);
+hipError_t launch_sht_reduce_tiles(const ShtArgs& a, const ShtTileArgs& v, int frames, hipStream_t stream);
 hipError_t launch_bytes_to_bits(const uint8_t* edges, int W, int H, int S, size_t frameStride, uint32_t* ebits, int wb, size_t bitsFrameStride,
                                 int frames, hipStream_t stream);
 hipError_t launch_sht_compact(const ShtArgs& a, int frames, hipStream_t stream);

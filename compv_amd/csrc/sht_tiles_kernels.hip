@@ -1,0 +1,261 @@
+// sht_tiles_kernels.hip -- Hough (SHT) vote accumulation, second generation: lane = theta, image tiles, bank = lane.
+//
+// Replaces, behind compvhip_houghsht_u8 / compvhip_plan_houghsht / compvhip_plan_pipeline:
+//   CompVHoughSht::acc_gather + CompVHoughShtAccGatherRow_* / CompVHoughShtRowTimesSinRho_*
+//   core/features/hough/compv_core_feature_houghsht.cxx:350-481,607-627 (+ intrin/x86/compv_core_feature_houghsht_intrin_avx2.cxx:41-98)
+//
+// Why: the first-generation kernel (sht_kernels.hip: lane = edge, one workgroup per theta pair, the whole rho column in LDS) is
+// bound by the LDS atomic pipe at the cost of RANDOM addresses -- 7.3 cycles per ds_add wave-instruction, 8.4 on real frames where
+// collinear edges also pile onto one address -- against 4.1 cycles when the 32 lanes of each half-wave hit 32 different banks
+// (tools/microbench/lds_atomic_bench2).  Here the 64 lanes of a wave are 64 theta bins voting for ONE edge: the histogram of a
+// workgroup is [window row][32 dwords], dword l of a row = the u16 counters of theta bins l (low half) and 32 + l (high half), so
+// lane l always hits bank l & 31: conflict-free by construction, no two lanes of an instruction ever share an address, and the
+// edge coordinates are wave-uniform (scalar loads, scalar operands).  64 full rho columns do not fit the LDS, so the edges are
+// binned into image tiles: a tile of diagonal d only reaches a window of <= d + 1 rho rows per theta (<= 1264 rows = 158 KB).
+// A workgroup = (frame, tile, 64 theta bins); it writes its window theta-major to a partial accumulator and a small reduce kernel
+// adds the tiles' windows into the accumulator (each partial cell is written once and read once: 2 x 5.5 MB per 4K frame).
+// This also removes the W + H <= 20 479 limit of the first generation: the LDS only ever holds one tile's window.
+//
+// Exactness: rho = (x cosQ + y sinQ) >> 16 with x = x0 + lx, y = y0 + ly.  With C = x0 cosQ + y0 sinQ = Chi * 65536 + Clo
+// (Clo in [0, 65536)): rho = Chi + q, q = (lx cosQ + ly sinQ + Clo) >> 16, and the accumulator row barrier - rho =
+// rowBase + w with w = qmax - q = (K - lx cosQ - ly sinQ) >> 16, K = qmax * 65536 + 65535 - Clo (host tables, int64 there).
+#include "kernels.hpp"
+
+namespace compvhip {
+
+// ---------------------------------------------------------------------------------------------------------------
+// bit masks -> per-tile edge lists, entry = (ly << 16) | lx (tile-local).  One workgroup = kTcRows rows of one tile; the words of
+// the chunk are spread over the threads, popcounts are prefix-summed in the workgroup, ONE atomic reserves the chunk's slice of the
+// tile's list (the order of the entries inside a tile does not matter: votes commute).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kTcThreads = 256;
+constexpr int kTcRows = 64;
+
+__global__ __launch_bounds__(kTcThreads) void sht_compact_tiles_kernel(ShtArgs a, ShtTileArgs v)
+{
+	__shared__ int s_wave[kTcThreads / 64];
+	__shared__ int s_base;
+	const int frame = blockIdx.y;
+	const int chunksPerTile = (v.TH + kTcRows - 1) / kTcRows;
+	const int tile = blockIdx.x / chunksPerTile, chunk = blockIdx.x - tile * chunksPerTile;
+	const int ty = tile / v.nx, tx = tile - ty * v.nx;
+	const int x0 = tx * v.TW, y0 = ty * v.TH;
+	const int wpr = v.TW >> 5;                                  // mask words per tile row
+	const int ly0 = chunk * kTcRows;
+	const int rows = min(min(kTcRows, v.TH - ly0), a.H - (y0 + ly0));
+	const int nwords = max(rows, 0) * wpr;
+	const uint32_t* __restrict__ bits = a.ebits + (size_t)frame * a.bitsFrameStride;
+	const int w0 = x0 >> 5;
+	constexpr int kPer = (kTcRows * 40 + kTcThreads - 1) / kTcThreads; // words per thread; tiles are at most 1264 = kShtMaxWindow columns wide (40 words)
+	uint32_t wv[kPer]; int wl[kPer];
+	int cnt = 0;
+#pragma unroll
+	for (int k = 0; k < kPer; ++k) {
+		const int i = threadIdx.x + k * kTcThreads;
+		wv[k] = 0u; wl[k] = 0;
+		if (i < nwords) {
+			const int r = i / wpr, c = i - r * wpr;
+			if (w0 + c < a.wb) wv[k] = bits[(size_t)(y0 + ly0 + r) * a.wb + w0 + c];
+			wl[k] = ((ly0 + r) << 16) | (c << 5);
+			cnt += __popc(wv[k]);
+		}
+	}
+	int incl = cnt;
+	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+	for (int o = 1; o < 64; o <<= 1) {
+		const int n = __shfl_up(incl, o);
+		if (lane >= o) incl += n;
+	}
+	if (lane == 63) s_wave[wave] = incl;
+	__syncthreads();
+	int wbase = 0, total = 0;
+#pragma unroll
+	for (int k = 0; k < kTcThreads / 64; ++k) {
+		const int t = s_wave[k];
+		if (k < wave) wbase += t;
+		total += t;
+	}
+	if (total == 0) return; // uniform
+	if (threadIdx.x == 0) {
+		s_base = atomicAdd(&v.tileCounts[frame * v.tiles + tile], total);
+		atomicAdd(&a.edgeCounts[frame], total);
+	}
+	__syncthreads();
+	uint32_t* __restrict__ dst = a.edges + ((size_t)frame * v.tiles + tile) * v.tileCap;
+	size_t pos = (size_t)s_base + wbase + (incl - cnt);
+#pragma unroll
+	for (int k = 0; k < kPer; ++k) {
+		uint32_t b = wv[k];
+		while (b) {
+			const int bit = __ffs(b) - 1;
+			b &= b - 1;
+			if (pos < v.tileCap) dst[pos] = (uint32_t)(wl[k] + bit);
+			++pos;
+		}
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// voting: workgroup = (frame, tile, group of 64 theta bins), 1024 threads; lane = theta bin.
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kVtThreads = 1024;
+constexpr int kVtUnroll = 32;   // edges per block of scalar loads
+
+__global__ __launch_bounds__(kVtThreads) void sht_vote_tiles_kernel(ShtArgs a, ShtTileArgs v)
+{
+	extern __shared__ __attribute__((aligned(16))) uint32_t hist[]; // [Rw][32]: dword l of row w = counters of theta l (low half) and 32 + l (high half)
+	// XCD-aware order (workgroup b runs on XCD b % 8): the groups of one (frame, tile) unit run on the same XCD, so the unit's edge list
+	// is fetched from HBM once and re-read from that XCD's L2 by the other groups.
+	const int units = a.frames * v.tiles;
+	const int xcd = blockIdx.x & 7, k = blockIdx.x >> 3;
+	const int g = k % v.groups;
+	const int unit = (k / v.groups) * 8 + xcd;
+	if (unit >= units) return;
+	const int frame = unit / v.tiles, tile = unit - frame * v.tiles;
+	const int tid = threadIdx.x, lane = tid & 63;
+	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+	const int n = min(v.tileCounts[unit], (int)v.tileCap);
+	const int words = v.Rw * 32;
+	for (int i = tid * 4; i < words; i += kVtThreads * 4) *reinterpret_cast<uint4*>(&hist[i]) = make_uint4(0, 0, 0, 0);
+
+	const int t = g * 64 + lane;
+	const int tt = min(t, a.T - 1);
+	const int nc = -a.cosQ[tt], ns = -a.sinQ[tt];
+	const int K = v.kt[(size_t)tile * a.T + tt];
+	uint32_t inc = (t < a.T) ? ((lane & 32) ? 0x10000u : 1u) : 0u; // a theta past T adds nothing
+	asm volatile("" : "+v"(inc));
+	const uint32_t lane4 = (uint32_t)(lane & 31) * 4u;
+	__syncthreads();
+
+	const uint32_t* __restrict__ list = a.edges + (size_t)unit * v.tileCap;
+	// The waves take interleaved blocks of kVtUnroll edges.  The block address is wave-uniform: one SCALAR load per block (s_load_dwordx8,
+	// issued a block ahead), the coordinates are unpacked by the scalar unit and enter the two v_mad_i32_i24 as scalar operands: per
+	// vote 2 multiply-adds + 2 address operations + the LDS atomic.
+	typedef uint32_t u32x16 __attribute__((ext_vector_type(16)));
+	auto vote = [&](uint32_t e) {
+		const int lx = (int)(e & 0xffffu), ly = (int)(e >> 16);
+		int val, ad;
+		asm volatile("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(val) : "s"(lx), "v"(nc), "v"(K));      // K - lx cos
+		asm volatile("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(val) : "s"(ly), "v"(ns), "v"(val));    // ... - ly sin: window row in the high half
+		const uint32_t row = (uint32_t)val >> 16;
+		asm volatile("v_lshl_add_u32 %0, %1, 7, %2" : "=v"(ad) : "v"(row), "v"(lane4));           // row * 128 B + bank * 4 B
+		asm volatile("ds_add_u32 %0, %1" : : "v"(ad), "v"(inc) : "memory");
+	};
+	// Blocks of kVtUnroll = 32 edges (two s_load_dwordx16), one block in flight while the previous one is voted: a scalar load that misses
+	// the constant cache takes ~800 cycles here, 32 votes of one wave take ~2000.  Two register sets alternate (no copies).
+	// (A load and the s_waitcnt that covers it are tied by a "+s" operand: the compiler must not read the registers before the wait.)
+	const int nblk = n / kVtUnroll;
+	constexpr int kStep = kVtThreads / 64;
+	u32x16 a0, a1, b0, b1;
+#define VT_LOAD(r0, r1, blk) asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40" : "=&s"(r0), "=&s"(r1) : "s"(list + (size_t)(blk) * kVtUnroll) : "memory")
+#define VT_WAIT(r0, r1) asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(r0), "+s"(r1) : : "memory")
+#define VT_VOTE(r0, r1) _Pragma("unroll") for (int u = 0; u < 16; ++u) vote(r0[u]); _Pragma("unroll") for (int u = 0; u < 16; ++u) vote(r1[u])
+	int b = wave;
+	if (b < nblk) {
+		VT_LOAD(a0, a1, b);
+		VT_WAIT(a0, a1);
+		for (;;) {
+			const int bn = b + kStep;
+			if (bn < nblk) VT_LOAD(b0, b1, bn);
+			VT_VOTE(a0, a1);
+			if (bn >= nblk) break;
+			VT_WAIT(b0, b1);
+			b = bn + kStep;
+			if (b < nblk) VT_LOAD(a0, a1, b);
+			VT_VOTE(b0, b1);
+			if (b >= nblk) break;
+			VT_WAIT(a0, a1);
+		}
+	}
+#undef VT_LOAD
+#undef VT_WAIT
+#undef VT_VOTE
+	for (int i = nblk * kVtUnroll + wave; i < n; i += kStep) vote(__builtin_amdgcn_readfirstlane(list[i]));
+	__builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): the asm ds_add are invisible to the compiler's counters
+	__syncthreads();
+
+	// flush, theta-major: lane = theta reads 8 consecutive window rows of its own column (bank = lane: conflict-free) and writes them
+	// as one 16-byte store into partial[frame][tile][theta][w .. w + 7]
+	uint16_t* __restrict__ part = v.partial + (((size_t)unit * v.Tpad) + (size_t)g * 64 + lane) * v.rwPitch;
+	const int sh = (lane & 32) ? 16 : 0;
+	for (int w0 = wave * 8; w0 < v.Rw; w0 += (kVtThreads / 64) * 8) {
+		uint32_t c[8];
+#pragma unroll
+		for (int j = 0; j < 8; ++j) c[j] = (hist[(w0 + j) * 32 + (lane & 31)] >> sh) & 0xffffu; // Rw is a multiple of 8
+		typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+		u32x4 o;
+		o.x = c[0] | (c[1] << 16); o.y = c[2] | (c[3] << 16); o.z = c[4] | (c[5] << 16); o.w = c[6] | (c[7] << 16);
+		// (one 16-byte store, spelled out: the loop vectoriser otherwise splits it into four dword stores, 4x the store instructions)
+		asm volatile("global_store_dwordx4 %0, %1, off" : : "v"(part + w0), "v"(o) : "memory");
+	}
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// reduce: acc[frame][theta][r] = sum over the tiles whose window of that theta covers row r.  For a fixed theta the window rows of
+// a tile are contiguous in r: every read and the write are coalesced along r.  One thread = 8 consecutive rows (one 16-byte store), one
+// workgroup = 2048 rows of one theta; a tile whose window misses the workgroup's rows is skipped by a scalar test (a row is covered
+// by ~1.2 of the 12 tiles of a 4K frame).
+// ---------------------------------------------------------------------------------------------------------------
+constexpr int kRdThreads = 256;
+constexpr int kRdRows = 8;
+
+__global__ __launch_bounds__(kRdThreads) void sht_reduce_tiles_kernel(ShtArgs a, ShtTileArgs v)
+{
+	const int frame = blockIdx.z, theta = blockIdx.y;
+	const int rb0 = blockIdx.x * (kRdThreads * kRdRows);
+	const int r0 = rb0 + threadIdx.x * kRdRows;
+	const uint16_t* __restrict__ part = v.partial + ((size_t)frame * v.tiles * v.Tpad + theta) * v.rwPitch;
+	uint4 sum = make_uint4(0, 0, 0, 0); // 8 u16 cells; a cell never exceeds 2 max(W, H) < 65536: the packed halves cannot carry
+	for (int tile = 0; tile < v.tiles; ++tile) {
+		const int base = v.rowBase[(size_t)tile * a.T + theta]; // a multiple of 8 (planVoteTiles), like r0 and Rw
+		if (base >= rb0 + kRdThreads * kRdRows || base + v.Rw <= rb0) continue; // uniform
+		const int w0 = r0 - base;
+		if (w0 >= 0 && w0 < v.Rw) {
+			const uint4 c = *reinterpret_cast<const uint4*>(part + (size_t)tile * v.Tpad * v.rwPitch + w0);
+			sum.x += c.x; sum.y += c.y; sum.z += c.z; sum.w += c.w;
+		}
+	}
+	// accPitch is a multiple of 64; rows [R, accPitch) must stay zero and do: no window cell past row R - 1 ever receives a vote
+	if (r0 < a.accPitch) *reinterpret_cast<uint4*>(a.acc + (size_t)frame * a.accFrameStride + (size_t)theta * a.accPitch + r0) = sum;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+hipError_t launch_sht_compact_tiles(const ShtArgs& a, const ShtTileArgs& v, int frames, hipStream_t stream)
+{
+	const int chunksPerTile = (v.TH + kTcRows - 1) / kTcRows;
+	dim3 grid((unsigned)(v.tiles * chunksPerTile), frames);
+	hipLaunchKernelGGL(sht_compact_tiles_kernel, grid, dim3(kTcThreads), 0, stream, a, v);
+	return hipGetLastError();
+}
+
+size_t sht_vote_tiles_lds_bytes(int Rw) { return (size_t)Rw * 128; }
+
+hipError_t launch_sht_vote_tiles(const ShtArgs& a, const ShtTileArgs& v, int frames, hipStream_t stream)
+{
+	const size_t lds = sht_vote_tiles_lds_bytes(v.Rw);
+	if (lds > 160 * 1024) return hipErrorInvalidValue;
+	static size_t attr_lds[64] = {};
+	int dev = 0;
+	(void)hipGetDevice(&dev);
+	dev = (dev >= 0 && dev < 64) ? dev : 0;
+	if (lds > attr_lds[dev]) {
+		hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(sht_vote_tiles_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+		if (e != hipSuccess) return e;
+		attr_lds[dev] = lds;
+	}
+	const int units = frames * v.tiles;
+	dim3 grid((unsigned)(8 * ((units + 7) / 8) * v.groups));
+	hipLaunchKernelGGL(sht_vote_tiles_kernel, grid, dim3(kVtThreads), lds, stream, a, v);
+	return hipGetLastError();
+}
+
+hipError_t launch_sht_reduce_tiles(const ShtArgs& a, const ShtTileArgs& v, int frames, hipStream_t stream)
+{
+	dim3 grid((unsigned)((a.R + kRdThreads * kRdRows - 1) / (kRdThreads * kRdRows)), a.T, frames);
+	hipLaunchKernelGGL(sht_reduce_tiles_kernel, grid, dim3(kRdThreads), 0, stream, a, v);
+	return hipGetLastError();
+}
+
+} // namespace compvhip

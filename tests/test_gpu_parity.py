@@ -143,8 +143,8 @@ def test_houghsht_matches_oracle(hip_ctx, oracle, W, H, tl, th, deg, thr):
 
 @pytest.mark.parametrize("W,H", [(8000, 191), (8000, 192), (40, 8300), (12000, 48)])
 def test_houghsht_wide_rho_range(hip_ctx, oracle, W, H):
-    """W+H = 8191 is the last size on the scaled 4-VALU vote kernel, 8192 the first on the generic one; 12048 needs a
-    24 097-row LDS histogram (the limit is W+H <= 20479)."""
+    """Wide rho ranges (tens of tiles per frame in the tiled vote kernel; W+H = 8191 / 8192 straddle the two variants of the
+    first-generation kernel)."""
     rng = np.random.default_rng(W + H)
     edges = np.where(rng.random((H, W)) < 0.02, 0xff, 0).astype(np.uint8)
     edges[H // 2, :] = 0xff
@@ -156,9 +156,11 @@ def test_houghsht_wide_rho_range(hip_ctx, oracle, W, H):
     assert _lines_tuple(lines) == _orc_tuple(exp)
 
 
-def test_houghsht_four_theta_per_workgroup(oracle, monkeypatch):
-    """The 4-theta-bins-per-workgroup variant of the vote kernel (tuning knob) produces the same histogram."""
+def test_houghsht_legacy_vote_kernels(oracle, monkeypatch):
+    """The first-generation vote path (lane = edge, one workgroup per theta pair; COMPVHIP_SHT_VOTE=legacy, with its 4-theta tuning
+    knob) still produces the same histogram -- it is kept for A/B measurements."""
     from compv_amd import capi
+    monkeypatch.setenv("COMPVHIP_SHT_VOTE", "legacy")
     monkeypatch.setenv("COMPVHIP_SHT_THETA_PER_GROUP", "4")
     ctx = capi.Context(0)
     try:
@@ -172,11 +174,24 @@ def test_houghsht_four_theta_per_workgroup(oracle, monkeypatch):
         ctx.close()
 
 
-def test_houghsht_rho_range_limit(hip_ctx):
-    from compv_amd import capi
-    with pytest.raises(capi.CompvHipError) as ex:
-        hip_ctx.houghsht(np.zeros((16, 20480), np.uint8), 1.0, 10)   # 2*(W+H)+1 rho rows no longer fit the 160 KB LDS histogram
-    assert ex.value.code == capi.E_NOT_IMPLEMENTED
+@pytest.mark.parametrize("W,H", [(20480, 16), (32767, 64), (64, 32767), (8192, 8192)])
+def test_houghsht_beyond_the_first_generation_limit(hip_ctx, oracle, W, H):
+    """The reference accepts every size up to 32767 x 32767 (core/features/hough/compv_core_feature_houghsht.cxx:318-348); the
+    first-generation vote kernel stopped at W + H = 20479 (one whole rho column per workgroup in LDS).  The tiled kernel has no such
+    limit: sparse maps at the extreme sizes, accumulator and line set against the oracle."""
+    rng = np.random.default_rng(W * 3 + H)
+    edges = np.zeros((H, W), np.uint8)
+    n = 60000
+    edges[rng.integers(0, H, n), rng.integers(0, W, n)] = 0xff
+    edges[H // 2, :] = 0xff                                   # one full row and one full column: long collinear runs
+    edges[:, W // 3] = 0xff
+    edges[np.arange(min(W, H)), np.arange(min(W, H))] = 0xff  # and a diagonal
+    acc_exp = oracle.sht_acc(edges, 1.0)
+    thr = 40
+    exp = oracle.sht_lines_from_acc(acc_exp, W, H, 1.0, thr)
+    lines, acc = hip_ctx.houghsht(edges, 1.0, thr, want_acc=True, cap=max(1 << 16, len(exp)))
+    assert acc.shape == acc_exp.shape and (acc == acc_exp).all(), int((acc != acc_exp).sum())
+    assert _lines_tuple(lines) == _orc_tuple(exp)
 
 
 def test_houghsht_empty_and_full_maps(hip_ctx, oracle):
