@@ -30,11 +30,13 @@ namespace compvhip {
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kTcThreads = 256;
 constexpr int kTcRows = 64;
+constexpr int kTcStage = 6144; // entries of a chunk staged in the LDS (denser chunks store directly)
 
 __global__ __launch_bounds__(kTcThreads) void sht_compact_tiles_kernel(ShtArgs a, ShtTileArgs v)
 {
 	__shared__ int s_wave[kTcThreads / 64];
 	__shared__ int s_base;
+	__shared__ uint32_t s_stage[kTcStage];
 	const int frame = blockIdx.y;
 	const int chunksPerTile = (v.TH + kTcRows - 1) / kTcRows;
 	const int tile = blockIdx.x / chunksPerTile, chunk = blockIdx.x - tile * chunksPerTile;
@@ -83,7 +85,27 @@ __global__ __launch_bounds__(kTcThreads) void sht_compact_tiles_kernel(ShtArgs a
 	}
 	__syncthreads();
 	uint32_t* __restrict__ dst = a.edges + ((size_t)frame * v.tiles + tile) * v.tileCap;
-	size_t pos = (size_t)s_base + wbase + (incl - cnt);
+	const int first = wbase + (incl - cnt);
+	if (total <= kTcStage) {
+		// the usual case: the chunk's entries are put in order in the LDS and leave as whole 256-byte rows (a thread storing its own
+		// entries one by one touches 64 different cache lines per store instruction: the L2 request rate, not the bytes, was the cost)
+		int lp = first;
+#pragma unroll
+		for (int k = 0; k < kPer; ++k) {
+			uint32_t b = wv[k];
+			while (b) {
+				const int bit = __ffs(b) - 1;
+				b &= b - 1;
+				s_stage[lp++] = (uint32_t)(wl[k] + bit);
+			}
+		}
+		__syncthreads();
+		const size_t room = (size_t)s_base < v.tileCap ? v.tileCap - (size_t)s_base : 0;
+		const int nout = (int)min((size_t)total, room);
+		for (int i = threadIdx.x; i < nout; i += kTcThreads) dst[(size_t)s_base + i] = s_stage[i];
+		return;
+	}
+	size_t pos = (size_t)s_base + first;
 #pragma unroll
 	for (int k = 0; k < kPer; ++k) {
 		uint32_t b = wv[k];
