@@ -38,6 +38,7 @@ EXPORTS = [
     "compvhip_houghkht_u8", "compvhip_grayscale_u8", "compvhip_otsu_u8", "compvhip_plan_grayscale", "compvhip_plan_otsu",
     "compvhip_gauss_kernel_fixedpoint", "compvhip_convlt1_fixedpoint_u8", "compvhip_plan_convlt1_fixedpoint", "compvhip_plan_to_cartesian",
     "compvhip_plan_pipeline_async", "compvhip_plan_wait", "compvhip_houghsht_to_cartesian", "compvhip_houghkht_to_cartesian",
+    "compvhip_houghkht_kernels_u8", "compvhip_houghkht_stage_ms",
 ]
 
 
@@ -93,6 +94,8 @@ def load():
     L.compvhip_edge_dete_u8.argtypes = [vp, vp, sz, sz, sz, i32, vp, sz]
     L.compvhip_canny_u8.argtypes = [vp, vp, sz, sz, sz, C.c_float, C.c_float, i32, i32, vp, sz]
     L.compvhip_houghsht_u8.argtypes = [vp, vp, sz, sz, sz, C.c_float, C.c_float, i32, i32, vp, sz, C.POINTER(sz), vp, sz]
+    L.compvhip_houghkht_kernels_u8.argtypes = [vp, vp, sz, sz, sz, C.c_double, sz, vp, sz, C.POINTER(sz), C.POINTER(C.c_double)]
+    L.compvhip_houghkht_stage_ms.argtypes = [vp, vp]
     L.compvhip_houghkht_u8.argtypes = [vp, vp, sz, sz, sz, C.c_float, C.c_float, i32, i32, C.c_double, sz, C.c_double, vp, sz, C.POINTER(sz),
                                        C.POINTER(C.c_double)]
     L.compvhip_houghsht_dims.argtypes = [sz, sz, C.c_float, C.POINTER(sz), C.POINTER(sz), C.POINTER(C.c_float)]
@@ -234,6 +237,25 @@ class Context:
             return self.houghkht(edges, rho, theta_deg, threshold, max_lines, min_dev, min_size, min_height, cap=n.value)
         self._chk(rc)
         return lines[:n.value], gs.value
+
+
+    def houghkht_kernels(self, edges, min_dev=2.0, min_size=10, cap=1 << 16):
+        """Stage inspection: (kernels[n, 7] float64 in CompVHoughKhtKernel field order, before the height pruning; hmax)."""
+        H, W = edges.shape
+        out = np.zeros((cap, 7), np.float64)
+        n = C.c_size_t(0)
+        hmax = C.c_double(0.0)
+        rc = self.lib.compvhip_houghkht_kernels_u8(self.h, _ptr(edges), W, H, edges.strides[0], min_dev, min_size, _ptr(out), cap, C.byref(n), C.byref(hmax))
+        if rc == E_OUT_OF_BOUND and n.value > cap:
+            return self.houghkht_kernels(edges, min_dev, min_size, cap=n.value)
+        self._chk(rc)
+        return out[:n.value], hmax.value
+
+    def houghkht_stage_ms(self):
+        """Milliseconds of the six stages of the last houghkht() call: link, subdivide, statistics, prune, vote + peaks, sort + sweep."""
+        ms = np.zeros(6, np.float64)
+        self._chk(self.lib.compvhip_houghkht_stage_ms(self.h, _ptr(ms)))
+        return ms
 
 
 class Plan:

@@ -9,6 +9,8 @@
 #include "kernels.hpp"
 #include "kht.hpp"
 
+#include <chrono>
+
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -47,6 +49,10 @@ struct compvhip_ctx {
 	KhtVoteParams* khtParams = nullptr; size_t khtParamsCap = 0;
 	KhtCell* khtCells = nullptr; size_t khtCellsCap = 0;
 	int* khtCellCount = nullptr;
+	KhtPoint* khtPts = nullptr; size_t khtPtsCap = 0;
+	KhtSpan* khtSpans = nullptr; size_t khtSpansCap = 0;
+	KhtKernel* khtKernelsDev = nullptr;
+	double khtStageMs[6] = {};   // link, subdivide, statistics (GPU), prune + Gmin, vote + peaks (GPU), sort + sweep of the last KHT call
 };
 
 struct TimingEntry { const char* name; hipEvent_t a, b; };
@@ -582,6 +588,7 @@ void compvhip_ctx_destroy(compvhip_ctx* ctx)
 	dfree(ctx, ctx->dPacked); dfree(ctx, ctx->dHist);
 	dfree(ctx, ctx->dIn); dfree(ctx, ctx->dOut); dfree(ctx, ctx->dLines); dfree(ctx, ctx->dCounts); dfree(ctx, ctx->dAccOut);
 	dfree(ctx, ctx->khtCounts); dfree(ctx, ctx->khtParams); dfree(ctx, ctx->khtCells); dfree(ctx, ctx->khtCellCount);
+	dfree(ctx, ctx->khtPts); dfree(ctx, ctx->khtSpans); dfree(ctx, ctx->khtKernelsDev);
 	if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
 	delete ctx;
 }
@@ -1237,27 +1244,104 @@ int compvhip_houghsht_u8(compvhip_ctx* ctx, const uint8_t* edges, size_t W, size
 	return COMPVHIP_OK;
 }
 
+// host linking + subdivision, then the per-cluster statistics on the GPU (kht_stats_kernel); kernels in cluster order
+static int khtBuildKernels(compvhip_ctx* ctx, const uint8_t* edges, size_t W, size_t H, size_t S, double clusterMinDeviation, size_t clusterMinSize,
+                           std::vector<KhtKernel>& kernels, double& hmax)
+{
+	using clk = std::chrono::steady_clock;
+	auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+	kernels.clear(); hmax = 0.0;
+	const auto t0 = clk::now();
+	// clone the edges (the linker destroys them, :323-336), link, subdivide
+	std::vector<uint8_t> work(W * H);
+	for (size_t j = 0; j < H; ++j) memcpy(&work[j * W], edges + j * S, W);
+	std::vector<KhtPos> poss; std::vector<KhtRange> strings, clusters;
+	khtLink(work.data(), W, H, W, clusterMinSize, poss, strings);
+	const auto t1 = clk::now();
+	ctx->khtStageMs[0] = ms(t0, t1);
+	if (strings.empty()) return COMPVHIP_OK;
+	khtClusters(poss, strings, clusterMinSize, clusterMinDeviation, clusters);
+	const auto t2 = clk::now();
+	ctx->khtStageMs[1] = ms(t1, t2);
+	if (clusters.empty()) return COMPVHIP_OK;
+	if (poss.size() > 0xffffffffull) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "too many edge pixels");
+
+	const size_t n = clusters.size();
+	std::vector<KhtPoint> pts(poss.size());
+	for (size_t i = 0; i < poss.size(); ++i) { pts[i].x = poss[i].x; pts[i].y = poss[i].y; }
+	std::vector<KhtSpan> spans(n);
+	for (size_t i = 0; i < n; ++i) { spans[i].begin = static_cast<uint32_t>(clusters[i].begin); spans[i].end = static_cast<uint32_t>(clusters[i].end); }
+	HIPCHK(ctx, hipSetDevice(ctx->device));
+	if (ctx->khtPtsCap < pts.size()) { dfree(ctx, ctx->khtPts); ctx->khtPtsCap = 0; HIPCHK(ctx, dmalloc(ctx, &ctx->khtPts, pts.size())); ctx->khtPtsCap = pts.size(); }
+	if (ctx->khtSpansCap < n) {
+		dfree(ctx, ctx->khtSpans); dfree(ctx, ctx->khtKernelsDev); ctx->khtSpansCap = 0;
+		HIPCHK(ctx, dmalloc(ctx, &ctx->khtSpans, n)); HIPCHK(ctx, dmalloc(ctx, &ctx->khtKernelsDev, n)); ctx->khtSpansCap = n;
+	}
+	hipStream_t st = ctx->stream;
+	HIPCHK(ctx, hipMemcpyAsync(ctx->khtPts, pts.data(), pts.size() * sizeof(KhtPoint), hipMemcpyHostToDevice, st));
+	HIPCHK(ctx, hipMemcpyAsync(ctx->khtSpans, spans.data(), n * sizeof(KhtSpan), hipMemcpyHostToDevice, st));
+	KhtStatsArgs sa;
+	sa.pts = ctx->khtPts; sa.clusters = ctx->khtSpans; sa.n = static_cast<int>(n);
+	const size_t pack = n >= 4 ? 4 : (n >= 2 ? 2 : 1); // the reference's AVX (4) / SSE2 (2) kernel-height loops take n & ~(pack - 1) clusters
+	sa.simdEnd = static_cast<int>(pack > 1 ? (n & ~(pack - 1)) : 0);
+	sa.hw = static_cast<double>(W) * 0.5; sa.hh = static_cast<double>(H) * 0.5;
+	sa.out = ctx->khtKernelsDev;
+	HIPCHK(ctx, launch_kht_stats(sa, st));
+	kernels.resize(n);
+	HIPCHK(ctx, hipMemcpyAsync(kernels.data(), ctx->khtKernelsDev, n * sizeof(KhtKernel), hipMemcpyDeviceToHost, st));
+	HIPCHK(ctx, hipStreamSynchronize(st));
+	khtFinishKernels(kernels, hmax);
+	ctx->khtStageMs[2] = ms(t2, clk::now());
+	return COMPVHIP_OK;
+}
+
+int compvhip_houghkht_kernels_u8(compvhip_ctx* ctx, const uint8_t* edges, size_t W, size_t H, size_t S, double clusterMinDeviation, size_t clusterMinSize,
+                                 double* kernels7, size_t cap, size_t* n, double* hmax)
+{
+	if (!ctx) return COMPVHIP_E_INVALID_PARAMETER;
+	if (!edges || !n || (cap && !kernels7) || S < W || !W || !H || !clusterMinSize) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "null/invalid argument");
+	if (W > 32767 || H > 32767) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "image size out of range");
+	std::vector<KhtKernel> kernels; double hm = 0.0;
+	const int rc = khtBuildKernels(ctx, edges, W, H, S, clusterMinDeviation, clusterMinSize, kernels, hm);
+	if (rc) return rc;
+	*n = kernels.size();
+	if (hmax) *hmax = hm;
+	for (size_t i = 0; i < std::min(kernels.size(), cap); ++i) {
+		const KhtKernel& k = kernels[i];
+		const double v[7] = { k.rho, k.theta, k.h, k.sigmaThetaSquare, k.sigmaRhoSquare, k.m2, k.sigmaRhoTimesTheta };
+		memcpy(kernels7 + i * 7, v, sizeof(v));
+	}
+	if (kernels.size() > cap) return fail(ctx, COMPVHIP_E_OUT_OF_BOUND, "kernel buffer too small");
+	return COMPVHIP_OK;
+}
+
+int compvhip_houghkht_stage_ms(compvhip_ctx* ctx, double* ms6)
+{
+	if (!ctx || !ms6) return COMPVHIP_E_INVALID_PARAMETER;
+	memcpy(ms6, ctx->khtStageMs, sizeof(ctx->khtStageMs));
+	return COMPVHIP_OK;
+}
+
 int compvhip_houghkht_u8(compvhip_ctx* ctx, const uint8_t* edges, size_t W, size_t H, size_t S, float rho, float thetaDeg, int threshold, int maxLines,
                          double clusterMinDeviation, size_t clusterMinSize, double kernelMinHeight, compvhip_line* lines, size_t cap, size_t* n, double* gs)
 {
+	using clk = std::chrono::steady_clock;
+	auto msSince = [](clk::time_point a) { return std::chrono::duration<double, std::milli>(clk::now() - a).count(); };
 	if (!ctx) return COMPVHIP_E_INVALID_PARAMETER;
 	if (!edges || !n || (cap && !lines) || S < W || !W || !H) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "null/invalid argument"); // houghkht.cxx:210-211
 	if (!(rho > 0.f) || rho > 1.f || !(thetaDeg > 0.f) || threshold <= 0) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "rho in (0,1], theta > 0, threshold > 0"); // :146-163,491
 	if (!clusterMinSize || !(kernelMinHeight >= 0.0)) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "invalid KHT knob"); // :169-186 (the deviation is unchecked there)
 	if (W > 32767 || H > 32767) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "image size out of range");
 	*n = 0;
+	memset(ctx->khtStageMs, 0, sizeof(ctx->khtStageMs));
 	KhtAxes ax;
 	if (!khtAxes(W, H, rho, thetaDeg, ax)) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "degenerate KHT parameter space");
-	// host: clone the edges (the linker destroys them, :323-336), link, subdivide, build the kernels
-	std::vector<uint8_t> work(W * H);
-	for (size_t j = 0; j < H; ++j) memcpy(&work[j * W], edges + j * S, W);
-	std::vector<KhtPos> poss; std::vector<KhtRange> strings, clusters; std::vector<KhtKernel> kernels;
-	khtLink(work.data(), W, H, W, clusterMinSize, poss, strings);
-	if (strings.empty()) return COMPVHIP_OK;
-	khtClusters(poss, strings, clusterMinSize, clusterMinDeviation, clusters);
-	if (clusters.empty()) return COMPVHIP_OK;
+	std::vector<KhtKernel> kernels;
 	double hmax = 0.0;
-	khtKernels(poss, clusters, kernels, hmax);
+	const int rck = khtBuildKernels(ctx, edges, W, H, S, clusterMinDeviation, clusterMinSize, kernels, hmax);
+	if (rck) return rck;
+	if (kernels.empty()) return COMPVHIP_OK;
+	auto t3 = clk::now();
 	const double GS = khtPruneAndScale(kernels, hmax, kernelMinHeight);
 	if (kernels.empty()) return COMPVHIP_OK;
 	if (gs) *gs = GS;
@@ -1274,6 +1358,8 @@ int compvhip_houghkht_u8(compvhip_ctx* ctx, const uint8_t* edges, size_t W, size
 	if (ctx->khtCellsCap < cellCap) { dfree(ctx, ctx->khtCells); HIPCHK(ctx, dmalloc(ctx, &ctx->khtCells, cellCap)); ctx->khtCellsCap = cellCap; }
 	if (!ctx->khtCellCount) HIPCHK(ctx, dmalloc(ctx, &ctx->khtCellCount, 1));
 	hipStream_t st = ctx->stream;
+	ctx->khtStageMs[3] = msSince(t3);
+	t3 = clk::now();
 	HIPCHK(ctx, hipMemsetAsync(ctx->khtCounts, 0, countsElems * sizeof(int32_t), st));
 	HIPCHK(ctx, hipMemsetAsync(ctx->khtCellCount, 0, sizeof(int), st));
 	HIPCHK(ctx, hipMemcpyAsync(ctx->khtParams, params.data(), params.size() * sizeof(KhtVoteParams), hipMemcpyHostToDevice, st));
@@ -1289,9 +1375,12 @@ int compvhip_houghkht_u8(compvhip_ctx* ctx, const uint8_t* edges, size_t W, size
 	std::vector<KhtCell> cells(static_cast<size_t>(std::min<int>(cellCount, static_cast<int>(cellCap))));
 	if (!cells.empty()) HIPCHK(ctx, hipMemcpy(cells.data(), ctx->khtCells, cells.size() * sizeof(KhtCell), hipMemcpyDeviceToHost));
 
+	ctx->khtStageMs[4] = msSince(t3);
+	t3 = clk::now();
 	// host: sort + sweep (order dependent, :1195-1247)
 	std::vector<KhtLine> out;
 	khtPeaks(ax, cells, maxLines, out);
+	ctx->khtStageMs[5] = msSince(t3);
 	*n = out.size();
 	const size_t ncopy = std::min(out.size(), cap);
 	for (size_t i = 0; i < ncopy; ++i) {

@@ -24,7 +24,7 @@ bool khtAxes(size_t W, size_t H, float rho, float thetaDeg, KhtAxes& ax);
 void khtFillAxes(const KhtAxes& ax, std::vector<double>& rho, std::vector<double>& theta);
 void khtLink(uint8_t* edges, size_t W, size_t H, size_t S, size_t minSize, std::vector<KhtPos>& poss, std::vector<KhtRange>& strings);
 void khtClusters(const std::vector<KhtPos>& poss, const std::vector<KhtRange>& strings, size_t minSize, double minDev, std::vector<KhtRange>& clusters);
-void khtKernels(const std::vector<KhtPos>& poss, const std::vector<KhtRange>& clusters, std::vector<KhtKernel>& kernels, double& hmax);
+void khtFinishKernels(std::vector<KhtKernel>& kernels, double& hmax);
 double khtPruneAndScale(std::vector<KhtKernel>& kernels, double hmax, double minHeight);
 void khtVoteParams(const KhtAxes& ax, const std::vector<KhtKernel>& kernels, std::vector<KhtVoteParams>& params);
 void khtPeaks(const KhtAxes& ax, std::vector<KhtCell>& cells, int maxLines, std::vector<KhtLine>& lines);
@@ -39,6 +39,16 @@ struct KhtGpuArgs {
 	int32_t threshold;
 	KhtCell* cells; int* cellCount; int cellCap;
 };
+// Algorithm 2, per-cluster statistics (kht_stats_kernel): one thread per cluster, float64, the reference's operation order
+struct KhtPoint { int32_t x, y; };
+struct KhtSpan { uint32_t begin, end; };
+struct KhtStatsArgs {
+	const KhtPoint* pts; const KhtSpan* clusters; int n;
+	int simdEnd;              // clusters [0, simdEnd) use the SIMD operation order of the kernel height, the rest the C order
+	double hw, hh;            // W/2, H/2
+	KhtKernel* out;           // .theta holds vx: acos() is taken by the host libm (khtFinishKernels)
+};
+hipError_t launch_kht_stats(const KhtStatsArgs& a, hipStream_t stream);
 hipError_t launch_kht_vote(const KhtGpuArgs& a, hipStream_t stream);
 hipError_t launch_kht_peaks(const KhtGpuArgs& a, hipStream_t stream);
 

@@ -5,8 +5,8 @@
 // linking follows chains pixel by pixel in raster order and destroys the pixels it visits (Appendix A, :544-760), the
 // recursive cluster subdivision (:762-832) and the final sweep over the sorted vote cells (:1207-1247) are order dependent by
 // definition.  Those stages stay on the host, in float64 with the reference's operation order so that the results are
-// bit-identical; the data-parallel stages -- Algorithm-4 Gaussian voting into the (rho,theta) count map and the 3x3
-// smoothing + thresholding of that map -- run on the GPU (kht_kernels.hip).
+// bit-identical; the data-parallel stages -- the per-cluster statistics of Algorithm 2, Algorithm-4 Gaussian voting into the
+// (rho,theta) count map and the 3x3 smoothing + thresholding of that map -- run on the GPU (kht_kernels.hip).
 //
 // Compiled with -ffp-contract=off: every double operation below must round exactly once, like the SSE2 reference build.
 #include "kht.hpp"
@@ -206,58 +206,14 @@ void khtClusters(const std::vector<KhtPos>& poss, const std::vector<KhtRange>& s
 	for (const KhtRange& s : strings) sd.run(s.begin, 0, (s.end - s.begin) - 1);
 }
 
-// Algorithm 2 (:885-1026).  Kernel height: clusters [0, n & ~(pack-1)) use the SIMD operation order
-// 1/((sqrt(1-r^2)*s)*2pi) (intrin_avx.cxx:42-63, intrin_sse2.cxx:118-142), the remainder the C order 1/(2pi*s*sqrt(1-r^2)) (:849-883).
-void khtKernels(const std::vector<KhtPos>& poss, const std::vector<KhtRange>& clusters, std::vector<KhtKernel>& kernels, double& hmax)
+// Algorithm 2 (:885-1026): the per-cluster statistics run on the GPU (kht_kernels.hip, kht_stats_kernel).  What is left here is the
+// one libm call of the stage -- theta = acos(vx) in degrees (:949; the device acos is not glibc's) -- and hmax.
+void khtFinishKernels(std::vector<KhtKernel>& kernels, double& hmax)
 {
-	const size_t n = clusters.size();
-	kernels.resize(n);
 	hmax = 0.0;
-	const size_t pack = n >= 4 ? 4 : (n >= 2 ? 2 : 1);
-	const size_t simdEnd = pack > 1 ? (n & ~(pack - 1)) : 0;
-	for (size_t k = 0; k < n; ++k) {
-		const KhtPos* b = poss.data() + clusters[k].begin;
-		const size_t cnt = clusters[k].end - clusters[k].begin;
-		const double nScale = 1.0 / static_cast<double>(cnt);
-		double mx = 0, my = 0;
-		for (size_t i = 0; i < cnt; ++i) { mx += b[i].cx; my += b[i].cy; }
-		mx *= nScale; my *= nScale;
-		double cxx = 0, cyy = 0, cxy = 0;
-		for (size_t i = 0; i < cnt; ++i) {
-			const double cx = b[i].cx - mx, cy = b[i].cy - my;
-			cxx += cx * cx; cyy += cy * cy; cxy += cx * cy;
-		}
-		const double M[4] = { cxx, cxy, cxy, cyy };
-		double D[4], Q[4];
-		find2x2(M, D, Q);
-		const double ux = Q[0], uy = Q[2];
-		double vx = Q[1], vy = Q[3];
-		if (vy < 0.0) { vx = -vx; vy = -vy; }
-		KhtKernel& K = kernels[k];
-		K.rho = (vx * mx) + (vy * my);
-		K.theta = std::acos(vx) * kRadToDeg;
-		const double sq = std::sqrt(1.0 - (vx * vx));
-		const double M0 = -(ux * mx) - (uy * my);
-		const double M2 = (sq == 0.0) ? 0.0 : ((ux / sq) * kRadToDeg);
-		double r0 = 0.0;
-		for (size_t i = 0; i < cnt; ++i) {
-			const double r1 = (ux * (b[i].cx - mx)) + (uy * (b[i].cy - my));
-			r0 += r1 * r1;
-		}
-		const double inv = 1.0 / r0;
-		const double r1 = M0 * inv, r2 = M2 * inv;
-		double srs = r1 * M0 + nScale;
-		const double srt = r1 * M2;
-		const double m2 = r2 * M0;
-		double sts = r2 * M2;
-		if (sts == 0.0) sts = 0.1;
-		srs *= 4.0; sts *= 4.0;
-		const double s = std::sqrt(srs) * std::sqrt(sts);
-		const double rr = srt / s;
-		const double omr = 1.0 - (rr * rr);
-		const double h = (k < simdEnd) ? 1.0 / ((std::sqrt(omr) * s) * kTwoPi) : 1.0 / (kTwoPi * s * std::sqrt(omr));
-		K.sigmaRhoSquare = srs; K.sigmaRhoTimesTheta = srt; K.m2 = m2; K.sigmaThetaSquare = sts; K.h = h;
-		if (h > hmax) hmax = h;
+	for (KhtKernel& K : kernels) {
+		K.theta = std::acos(K.theta) * kRadToDeg;
+		if (K.h > hmax) hmax = K.h;
 	}
 }
 

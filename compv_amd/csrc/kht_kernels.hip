@@ -1,5 +1,9 @@
 // kht_kernels.hip -- GPU stages of the kernel-based Hough transform for gfx950.
 //
+//   kht_stats_kernel  voting_Algorithm2_Kernels + CompVHoughKhtKernelHeight_* + CompVMathEigen<double>::find2x2 (:849-1026,
+//                     base/math/compv_math_eigen.cxx:285-342): centroid, covariance, closed-form eigenvectors, rho, Eq. 14 terms and
+//                     the kernel height of every cluster.  One thread = one cluster: the float64 sums run in the reference's
+//                     order (a tree reduction would round differently), clusters are independent.
 //   kht_vote_kernel   vote_Algorithm4 (core/features/hough/compv_core_feature_houghkht.cxx:1088-1148): every elliptical
 //                     Gaussian kernel is rasterised into the int32 (rho,theta) count map in four quadrant walks.  One
 //                     thread = one (kernel, quadrant) walk; votes are added with global int32 atomics, exactly like the
@@ -9,7 +13,8 @@
 //                     in the reference's emission order, which the host needs for the order-dependent sweep).
 //
 // Built with -ffp-contract=off: the float64 expressions below must round once per operation, like the reference's SSE2
-// code, or the integer votes differ.  All divisions and square roots were done on the host (KhtVoteParams).
+// code, or the integer votes differ.  The voting loop has no division or square root (KhtVoteParams holds them); the statistics
+// kernel uses the correctly rounded __ddiv_rn / __dsqrt_rn, which are bit-identical to the host's IEEE operations.
 #include "kht.hpp"
 
 namespace compvhip {
@@ -20,6 +25,91 @@ __device__ __forceinline__ double exp_fast_small(double x)
 	x = 1.0 + (x * (1.0 / 1024.0));
 	x *= x; x *= x; x *= x; x *= x; x *= x; x *= x; x *= x; x *= x; x *= x; x *= x;
 	return x;
+}
+
+
+// CompVMathEigen<double>::find2x2 (base/math/compv_math_eigen.cxx:285-342), sort = norm = true
+__device__ __forceinline__ void find2x2_dev(double a0, double a1, double a2, double a3, double (&D)[4], double (&Q)[4])
+{
+	bool norm = true;
+	const double trace = a0 + a3;
+	const double traceDiv2 = __ddiv_rn(trace, 2.0);
+	const double det = (a0 * a3) - (a1 * a2);
+	const double sq = __dsqrt_rn(__ddiv_rn(trace * trace, 4.0) - det);
+	D[1] = D[2] = 0.0;
+	D[0] = traceDiv2 + sq;
+	D[3] = traceDiv2 - sq;
+	if (a2 != 0) { Q[0] = D[0] - a3; Q[2] = a2; Q[1] = D[3] - a3; Q[3] = a2; }
+	else if (a1 != 0) { Q[0] = a1; Q[2] = D[0] - a0; Q[1] = a1; Q[3] = D[3] - a0; }
+	else {
+		norm = false;
+		if (a3 != 0.0) { Q[0] = 0.0; Q[2] = 1.0; Q[1] = 1.0; Q[3] = 0.0; }
+		else { Q[0] = 1.0; Q[2] = 0.0; Q[1] = 0.0; Q[3] = 1.0; }
+	}
+	if (norm) {
+		const double m02 = __ddiv_rn(1.0, __dsqrt_rn(Q[0] * Q[0] + Q[2] * Q[2]));
+		const double m13 = __ddiv_rn(1.0, __dsqrt_rn(Q[1] * Q[1] + Q[3] * Q[3]));
+		Q[0] *= m02; Q[2] *= m02; Q[1] *= m13; Q[3] *= m13;
+	}
+	if (D[0] < D[3]) {
+		double a = Q[0], b = Q[2];
+		Q[0] = Q[1]; Q[2] = Q[3]; Q[1] = a; Q[3] = b;
+		a = D[0]; D[0] = D[3]; D[3] = a;
+	}
+}
+
+__global__ __launch_bounds__(64) void kht_stats_kernel(KhtStatsArgs a)
+{
+	const int k = blockIdx.x * blockDim.x + threadIdx.x;
+	if (k >= a.n) return;
+	const double kRadToDeg = 180.0 / 3.14159265358979323846, kTwoPi = 2.0 * 3.14159265358979323846;
+	const KhtSpan c = a.clusters[k];
+	const KhtPoint* __restrict__ b = a.pts + c.begin;
+	const uint32_t cnt = c.end - c.begin;
+	const double nScale = __ddiv_rn(1.0, (double)cnt);
+	// centred coordinates as CompVHoughKhtPos stores them (:557-560): cx = x - W/2, cy = y - H/2 (exact)
+	double mx = 0, my = 0;
+	for (uint32_t i = 0; i < cnt; ++i) { const KhtPoint p = b[i]; mx += (double)p.x - a.hw; my += (double)p.y - a.hh; }
+	mx *= nScale; my *= nScale;
+	double cxx = 0, cyy = 0, cxy = 0;
+	for (uint32_t i = 0; i < cnt; ++i) {
+		const KhtPoint p = b[i];
+		const double cx = ((double)p.x - a.hw) - mx, cy = ((double)p.y - a.hh) - my;
+		cxx += cx * cx; cyy += cy * cy; cxy += cx * cy;
+	}
+	double D[4], Q[4];
+	find2x2_dev(cxx, cxy, cxy, cyy, D, Q);
+	const double ux = Q[0], uy = Q[2];
+	double vx = Q[1], vy = Q[3];
+	if (vy < 0.0) { vx = -vx; vy = -vy; }
+	KhtKernel K;
+	K.rho = (vx * mx) + (vy * my);
+	K.theta = vx; // acos on the host
+	const double sq = __dsqrt_rn(1.0 - (vx * vx));
+	const double M0 = -(ux * mx) - (uy * my);
+	const double M2 = (sq == 0.0) ? 0.0 : (__ddiv_rn(ux, sq) * kRadToDeg);
+	double r0 = 0.0;
+	for (uint32_t i = 0; i < cnt; ++i) {
+		const KhtPoint p = b[i];
+		const double r1 = (ux * (((double)p.x - a.hw) - mx)) + (uy * (((double)p.y - a.hh) - my));
+		r0 += r1 * r1;
+	}
+	const double inv = __ddiv_rn(1.0, r0);
+	const double r1 = M0 * inv, r2 = M2 * inv;
+	double srs = r1 * M0 + nScale;
+	const double srt = r1 * M2;
+	const double m2 = r2 * M0;
+	double sts = r2 * M2;
+	if (sts == 0.0) sts = 0.1;
+	srs *= 4.0; sts *= 4.0;
+	const double s = __dsqrt_rn(srs) * __dsqrt_rn(sts);
+	const double rr = __ddiv_rn(srt, s);
+	const double omr = 1.0 - (rr * rr);
+	// kernel height: SIMD operation order 1/((sqrt(1-r^2)*s)*2pi) for the clusters the reference's vector loop takes
+	// (intrin_avx.cxx:42-63, intrin_sse2.cxx:118-142), the C order 1/(2pi*s*sqrt(1-r^2)) for its remainder (:849-883)
+	const double h = (k < a.simdEnd) ? __ddiv_rn(1.0, (__dsqrt_rn(omr) * s) * kTwoPi) : __ddiv_rn(1.0, kTwoPi * s * __dsqrt_rn(omr));
+	K.sigmaRhoSquare = srs; K.sigmaRhoTimesTheta = srt; K.m2 = m2; K.sigmaThetaSquare = sts; K.h = h;
+	a.out[k] = K;
 }
 
 __global__ __launch_bounds__(64) void kht_vote_kernel(KhtGpuArgs a)
@@ -101,6 +191,13 @@ __global__ __launch_bounds__(256) void kht_peaks_kernel(KhtGpuArgs a, int sseCov
 		KhtCell o; o.order = order; o.rhoIndex = (uint32_t)emitRho; o.thetaIndex = (uint32_t)ti; o.count = s;
 		a.cells[idx] = o;
 	}
+}
+
+hipError_t launch_kht_stats(const KhtStatsArgs& a, hipStream_t stream)
+{
+	if (a.n <= 0) return hipSuccess;
+	hipLaunchKernelGGL(kht_stats_kernel, dim3((a.n + 63) / 64), dim3(64), 0, stream, a);
+	return hipGetLastError();
 }
 
 hipError_t launch_kht_vote(const KhtGpuArgs& a, hipStream_t stream)

@@ -112,6 +112,33 @@ class Oracle:
         assert r == 0, r
         return [(buf[i].rho, buf[i].theta, buf[i].strength, buf[i].rho_index, buf[i].theta_index) for i in range(min(n.value, cap))], gs.value
 
+    def kht_kernels(self, edges, min_dev=2.0, min_size=10):
+        """linking_AppendixA + clusters_find + voting_Algorithm2_Kernels restated: (kernels[n, 7] float64 in CompVHoughKhtKernel field
+        order, before the height pruning; hmax)."""
+        H, W = edges.shape
+        L = self.lib
+        sz = C.c_size_t
+        L.orc_kht_link.argtypes = [C.c_void_p, sz, sz, sz, sz, C.POINTER(C.c_void_p), C.POINTER(sz), C.POINTER(C.c_void_p), C.POINTER(sz)]
+        L.orc_kht_clusters.argtypes = [C.c_void_p, C.c_void_p, sz, sz, C.c_double, C.POINTER(C.c_void_p), C.POINTER(sz)]
+        L.orc_kht_kernels.argtypes = [C.c_void_p, C.c_void_p, sz, C.c_void_p, C.POINTER(C.c_double)]
+        L.orc_free.argtypes = [C.c_void_p]
+        poss = C.c_void_p(); strings = C.c_void_p(); clusters = C.c_void_p()
+        npos = sz(0); ns = sz(0); nc = sz(0)
+        assert L.orc_kht_link(_p(edges), W, H, edges.strides[0], min_size, C.byref(poss), C.byref(npos), C.byref(strings), C.byref(ns)) == 0
+        try:
+            if ns.value == 0:
+                return np.zeros((0, 7)), 0.0
+            assert L.orc_kht_clusters(poss, strings, ns.value, min_size, min_dev, C.byref(clusters), C.byref(nc)) == 0
+            out = np.zeros((nc.value, 7), np.float64)
+            hmax = C.c_double(0.0)
+            if nc.value:
+                assert L.orc_kht_kernels(poss, clusters, nc.value, _p(out), C.byref(hmax)) == 0
+            return out, hmax.value
+        finally:
+            for q in (poss, strings, clusters):
+                if q.value:
+                    L.orc_free(q)
+
     def synth(self, W, H, seed=12345):
         out = np.zeros((H, W), np.uint8)
         self.lib.orc_synth_frame(_p(out), W, H, W, seed)

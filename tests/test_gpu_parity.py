@@ -391,6 +391,20 @@ def test_houghkht_matches_oracle(hip_ctx, oracle, W, H, tl, th, rho, deg, thr):
         assert _kht_tuple(top) == _kht_tuple(got[:3])
 
 
+@pytest.mark.parametrize("W,H,tl,th,min_dev,min_size", [(320, 240, 59., 119., 2.0, 10), (1282, 720, 0.8, 1.6, 2.0, 10), (641, 480, 59., 119., 0.5, 5),
+                                                         (1920, 1080, 59., 119., 2.0, 10), (333, 77, 0.8, 1.6, 4.0, 3)])
+def test_houghkht_cluster_statistics_kernel_bit_exact(hip_ctx, oracle, W, H, tl, th, min_dev, min_size):
+    """kht_stats_kernel (one thread per cluster, float64, __ddiv_rn / __dsqrt_rn) against the oracle's voting_Algorithm2_Kernels:
+    all seven fields of every kernel and hmax, bit for bit (theta goes through the host libm acos on both sides)."""
+    img = synth_frame(W, H, 4242)
+    rc, edges = oracle.canny(img, tl, th)
+    exp, hmax_exp = oracle.kht_kernels(edges, min_dev, min_size)
+    got, hmax = hip_ctx.houghkht_kernels(edges, min_dev, min_size)
+    assert got.shape == exp.shape and len(exp) > 0
+    assert np.array_equal(got.view(np.uint64), exp.view(np.uint64))
+    assert hmax == hmax_exp
+
+
 @pytest.mark.parametrize("name", ["small_320x240", "hd_1280x720", "fhd_1920x1080", "dense_1282x720", "uhd_3840x2160"])
 def test_houghkht_golden(hip_ctx, golden, name):
     """Line set (values and order) and GS recorded from the compiled reference; 4K = BASELINE config 5."""

@@ -11,6 +11,10 @@ import csv, glob, json, os, sys
 from collections import defaultdict
 
 
+# device kernel -> the stage name bench.py / compvhip_plan_get_timing use
+STAGE_NAMES = {"sht_vote_tiles_kernel": "sht_vote_kernel", "sht_reduce_tiles_kernel": "sht_reduce_kernel", "sht_compact_tiles_kernel": "sht_compact_kernel"}
+
+
 def mean_counter(d, counter):
     agg = defaultdict(lambda: [0.0, 0])
     for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
@@ -32,6 +36,7 @@ def main(prof_dir, out):
         name = k.replace("compvhip::", "")
         if not name.startswith("edge_dete_kernel"):   # the two edge_dete instantiations are the read / write calibration kernels
             name = name.split("<")[0]
+        name = STAGE_NAMES.get(name, name)
         res["kernels"][name] = {
             "FETCH_SIZE_KiB": round(f, 1), "WRITE_SIZE_KiB": round(w, 1),
             "hbm_read_bytes": int(2 * f * 1024), "hbm_write_bytes": int(w * 1024), "hbm_bytes": int((2 * f + w) * 1024)}
