@@ -24,7 +24,7 @@
 using namespace compvhip;
 
 namespace {
-constexpr int kMaxRounds = 4096;       // hysteresis resolve rounds before giving up (one per 64-row band crossed)
+constexpr int kMaxRounds = 4096;       // hysteresis round flag slots (a multiple of 4); a frame that needs more rounds reuses them (enqueueResolve)
 constexpr int kSpecRounds = 3;         // rounds enqueued speculatively between two convergence checks
 constexpr size_t kMinLineCap = 1u << 16;  // per-frame line-key slots: max(caller's lineCap, 65536), clamped to R*T (include/compv_hip.h, compvhip_plan_houghsht)
 constexpr int kAsyncDepth = 4;            // outstanding compvhip_plan_pipeline_async steps per plan
@@ -69,6 +69,7 @@ struct compvhip_plan {
 	size_t nCounts = 0;       // ints in front of the flags
 	int* flags = nullptr; int* hFlags = nullptr; // device (inside counters) / pinned host (kAsyncDepth + 1 slots)
 	int roundsUsed = 0;
+	int maxRounds = kMaxRounds; // flag slots in use (COMPVHIP_RESOLVE_WRAP lowers it: tests of the slot reuse)
 	bool countersFresh = false; // the step's memset already zeroed the edge/line counts (no second fill in front of the SHT stage)
 	int2* thrDev = nullptr; unsigned int* sums = nullptr;
 	uint8_t* dirty = nullptr;  // per-workgroup change flags of the resolve rounds
@@ -480,7 +481,14 @@ int enqueueResolve(compvhip_plan* p, uint8_t* d_out, int rounds, hipStream_t st)
 	r.outFrameStride = p->S * p->H; r.bitsFrameStride = p->bitsFrameStride;
 	r.H = static_cast<int>(p->H); r.So = static_cast<int>(p->S); r.wb = p->wb;
 	for (int i = 0; i < rounds; ++i) {
-		if (p->roundsUsed >= kMaxRounds) return fail(ctx, COMPVHIP_E_INVALID_STATE, "hysteresis did not converge");
+		if (p->roundsUsed >= p->maxRounds) {
+			// More border crossings than flag slots (a weak chain that zigzags across a band border needs one round per crossing): the
+			// slots are reused.  The flood only ever adds pixels, so it terminates however many rounds that takes.  The sequence
+			// continues as round 4 -- same dirty-flag generation as round maxRounds, a multiple of 4 -- behind a "changed" in slot 3.
+			HIPCHK(ctx, hipMemsetAsync(p->flags + 3, 0, sizeof(int) * (p->maxRounds - 3), st));
+			HIPCHK(ctx, hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(p->flags + 3), 1, 1, st));
+			p->roundsUsed = 4;
+		}
 		r.round = p->roundsUsed++;
 		Stamp s(p, st, "canny_resolve_kernel");
 		HIPCHK(ctx, launch_canny_resolve(r, static_cast<int>(p->frames), st));
@@ -673,6 +681,7 @@ int compvhip_plan_create(compvhip_ctx* ctx, size_t W, size_t H, size_t S, size_t
 		}
 		if (dmalloc(ctx, &p->counters, p->nCounts + kMaxRounds) != hipSuccess) { rc = COMPVHIP_E_OUT_OF_MEMORY; break; }
 		p->edgeCounts = p->counters; p->lineCounts = p->counters + frames; p->tileCounts = p->counters + 2 * frames; p->flags = p->counters + p->nCounts;
+		if (const char* e = getenv("COMPVHIP_RESOLVE_WRAP")) { const int v = atoi(e); if (v >= 8 && v <= kMaxRounds && (v & 3) == 0) p->maxRounds = v; }
 		if (hipMemset(p->counters, 0, sizeof(int) * (p->nCounts + kMaxRounds)) != hipSuccess) { rc = COMPVHIP_E_HIP; break; }
 		if (dmalloc(ctx, &p->thrDev, frames) != hipSuccess) { rc = COMPVHIP_E_OUT_OF_MEMORY; break; }
 		if (dmalloc(ctx, &p->dirty, canny_resolve_dirty_bytes(static_cast<int>(H), p->wb, static_cast<int>(frames))) != hipSuccess) { rc = COMPVHIP_E_OUT_OF_MEMORY; break; }
@@ -1196,6 +1205,29 @@ int compvhip_otsu_u8(compvhip_ctx* ctx, const uint8_t* in, size_t W, size_t H, s
 	return COMPVHIP_OK;
 }
 
+// CompVHoughSht::process ends with std::sort(lines, strength >) and keeps the first maxLines (houghsht.cxx:241-249).  std::sort is
+// unstable, but deterministic for one libstdc++ and one input order, and the input order is nms_apply's emission order: accumulator
+// rows ascending, columns ascending (:546-562; per-thread vectors are concatenated in row order, :228-234).  Re-creating that order
+// and calling the same std::sort gives the reference's list element by element -- callers such as CompVCalibCamera (line grouping,
+// core/calib/compv_core_calib_camera.cxx:200-) depend on the order inside equal-strength groups.  The permutation only depends on
+// the strengths, so it is computed on (strength, index) pairs.
+static void referenceLineOrder(std::vector<compvhip_line>& lines, size_t T)
+{
+	const size_t n = lines.size();
+	if (n < 2) return;
+	std::vector<uint64_t> byCell(n);
+	for (size_t i = 0; i < n; ++i)
+		byCell[i] = ((static_cast<uint64_t>(lines[i].row) * T + static_cast<uint64_t>(lines[i].col)) << 32) | static_cast<uint64_t>(i);
+	std::sort(byCell.begin(), byCell.end()); // emission order (cells are unique)
+	struct Item { int32_t strength; uint32_t idx; };
+	std::vector<Item> items(n);
+	for (size_t i = 0; i < n; ++i) { const uint32_t j = static_cast<uint32_t>(byCell[i] & 0xffffffffu); items[i].strength = lines[j].strength; items[i].idx = j; }
+	std::sort(items.begin(), items.end(), [](const Item& a, const Item& b) { return a.strength > b.strength; });
+	std::vector<compvhip_line> out(n);
+	for (size_t i = 0; i < n; ++i) out[i] = lines[items[i].idx];
+	lines.swap(out);
+}
+
 int compvhip_houghsht_u8(compvhip_ctx* ctx, const uint8_t* edges, size_t W, size_t H, size_t S, float rho, float thetaDeg, int threshold, int maxLines,
                          compvhip_line* lines, size_t cap, size_t* n, int32_t* acc, size_t accStride)
 {
@@ -1214,11 +1246,13 @@ int compvhip_houghsht_u8(compvhip_ctx* ctx, const uint8_t* edges, size_t W, size
 	if (acc && accStride < p->T) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "accStride < theta bins");
 	HIPCHK(ctx, hipMemcpy2DAsync(ctx->dIn, p->S, edges, S, W, H, hipMemcpyHostToDevice, ctx->stream));
 	if (!ctx->dCounts) HIPCHK(ctx, dmalloc(ctx, &ctx->dCounts, 1));
-	size_t want = std::max<size_t>(cap, 1);
+	// ALL lines of the frame come back (device order: strength, then cell), because the order the reference returns them in -- and which
+	// equal-strength lines survive maxLines -- is decided by its unstable std::sort over the whole list (referenceLineOrder).
+	size_t want = std::max<size_t>(p->lineCap, kMinLineCap); // = the device key capacity planShtImpl will use
 	int32_t count = 0;
 	for (int attempt = 0; attempt < 2; ++attempt) {
-		if (ctx->dLinesCap < want) { dfree(ctx, ctx->dLines); HIPCHK(ctx, dmalloc(ctx, &ctx->dLines, want)); ctx->dLinesCap = want; }
-		rc = compvhip_plan_houghsht(p, ctx->dIn, threshold, maxLines, ctx->dLines, want, ctx->dCounts, ctx->stream);
+		if (ctx->dLinesCap < want) { dfree(ctx, ctx->dLines); ctx->dLinesCap = 0; HIPCHK(ctx, dmalloc(ctx, &ctx->dLines, want)); ctx->dLinesCap = want; }
+		rc = compvhip_plan_houghsht(p, ctx->dIn, threshold, 0, ctx->dLines, want, ctx->dCounts, ctx->stream);
 		if (rc) return rc;
 		HIPCHK(ctx, hipMemcpyAsync(&count, ctx->dCounts, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
 		HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -1226,12 +1260,16 @@ int compvhip_houghsht_u8(compvhip_ctx* ctx, const uint8_t* edges, size_t W, size
 		// more candidate lines than the device key buffer holds: grow it and redo the line stage
 		rc = ensureLineCap(p, static_cast<size_t>(count));
 		if (rc) return rc;
+		want = p->lineCap;
 	}
-	size_t found = static_cast<size_t>(count);
+	std::vector<compvhip_line> all(static_cast<size_t>(count));
+	if (count) HIPCHK(ctx, hipMemcpy(all.data(), ctx->dLines, all.size() * sizeof(compvhip_line), hipMemcpyDeviceToHost));
+	referenceLineOrder(all, p->T);
+	size_t found = all.size();
 	if (maxLines > 0 && found > static_cast<size_t>(maxLines)) found = static_cast<size_t>(maxLines);
 	*n = found;
 	const size_t ncopy = std::min(found, cap);
-	if (ncopy) HIPCHK(ctx, hipMemcpy(lines, ctx->dLines, ncopy * sizeof(compvhip_line), hipMemcpyDeviceToHost));
+	if (ncopy) memcpy(lines, all.data(), ncopy * sizeof(compvhip_line));
 	if (acc) {
 		const size_t elems = p->R * p->T;
 		if (ctx->dAccOutElems < elems) { dfree(ctx, ctx->dAccOut); HIPCHK(ctx, dmalloc(ctx, &ctx->dAccOut, elems)); ctx->dAccOutElems = elems; }

@@ -69,7 +69,7 @@ typedef enum compvhip_pixfmt { /* packed input formats of CompVImage::convertGra
 } compvhip_pixfmt;
 
 /* One Hough line.  rho/theta/strength are CompVHoughLine's fields (compv_common.h:686-693); row/col are the
- * accumulator cell (rho = barrier - row, theta = col * thetaStepRad) and define the canonical tie order. */
+ * accumulator cell (rho = barrier - row, theta = col * thetaStepRad) and define the canonical tie order of the plan API. */
 typedef struct compvhip_line {
 	float rho;
 	float theta;
@@ -130,8 +130,11 @@ COMPVHIP_API int compvhip_convlt1_fixedpoint_u8(compvhip_ctx* ctx, const uint8_t
 /* CompVHoughSht::process (core/features/hough/compv_core_feature_houghsht.cxx:96-262).  rho must be 1 (:306-316),
  * thetaDeg in degrees, threshold > 0 is the NMS/line threshold, maxLines <= 0 keeps every line.
  * lines: caller-allocated, capacity cap; *n receives the number of lines found (after the maxLines cut); if *n > cap
- * only cap lines are written and COMPVHIP_E_OUT_OF_BOUND is returned.  Lines are sorted by strength descending; equal
- * strengths (order unspecified in the reference: unstable std::sort, :243-249) are ordered by (row, col) ascending.
+ * only cap lines are written and COMPVHIP_E_OUT_OF_BOUND is returned.  Lines come back in the REFERENCE's order: sorted by strength
+ * descending, and inside equal-strength groups -- also at the maxLines cut -- exactly as the reference's unstable std::sort (:241-249)
+ * leaves them when it is built with this C++ runtime (the whole list is brought to the host in the (row, col) emission order of
+ * nms_apply and put through the same std::sort; callers such as CompVCalibCamera's line grouping depend on that order).  The
+ * device-resident plan API keeps the canonical order instead (strength, then (row, col) ascending), see compvhip_plan_houghsht.
  * acc (optional): int32 accumulator in the reference layout, R rows of accStride elements, R = 2(W+H)+1. */
 COMPVHIP_API int compvhip_houghsht_u8(compvhip_ctx* ctx, const uint8_t* edges, size_t W, size_t H, size_t S,
                                       float rho, float thetaDeg, int threshold, int maxLines,

@@ -16,6 +16,7 @@
 #include <compv/base/compv_debug.h>
 #include <compv/base/image/compv_image.h>
 #include <compv/core/compv_core.h>
+#include <compv/core/calib/compv_core_calib_camera.h>
 
 #include <algorithm>
 #include <chrono>
@@ -148,6 +149,52 @@ static COMPV_ERROR_CODE runSamples(size_t W, size_t H, uint32_t seed, Result& r)
 	return COMPV_ERROR_CODE_S_OK;
 }
 
+// A CONSUMER of the line set: CompVCalibCamera builds its Canny and Hough objects through the same factories
+// (core/calib/compv_core_calib_camera.cxx:1255-1279: SHT, theta = 0.5 deg, maxLines = 60 per pattern line, Canny(1.33, 2.66)) and runs
+// Canny -> SHT -> toCartesian -> line subdivision / grouping -> intersections on a chessboard view (:127-..).  Same application
+// code against whatever factories are registered; every stage output is kept for the comparison.
+struct CalibResult {
+	int code; size_t rawLines, groupedLines;
+	std::vector<uint8_t> edges;
+	std::vector<std::tuple<float, float, size_t> > raw;          // canonical order
+	std::vector<float> grouped, corners;                          // in the order the calibration produced them
+};
+static COMPV_ERROR_CODE runCalibration(size_t W, size_t H, CalibResult& r)
+{
+	CompVMatPtr image;
+	COMPV_CHECK_CODE_RETURN(CompVImage::newObj8u(&image, COMPV_SUBTYPE_PIXELS_Y, W, H));
+	// chessboard of COMPV_CALIB_PATTERN_ROWS_COUNT x COMPV_CALIB_PATTERN_COLS_COUNT squares, slightly sheared, on a light background
+	const size_t rows = COMPV_CALIB_PATTERN_ROWS_COUNT, cols = COMPV_CALIB_PATTERN_COLS_COUNT;
+	const double sq = (double)(H * 8 / 10) / (double)rows;
+	const double ox = ((double)W - sq * cols) * 0.5, oy = (double)H * 0.1;
+	for (size_t j = 0; j < H; ++j) {
+		uint8_t* p = image->ptr<uint8_t>(j);
+		for (size_t i = 0; i < W; ++i) {
+			const double y = ((double)j - oy), x = ((double)i - ox) - 0.04 * y; // shear: the vertical lines lean by 2.3 deg
+			uint8_t v = 200;
+			if (x >= 0 && y >= 0 && x < sq * cols && y < sq * rows) v = ((((size_t)(x / sq)) + ((size_t)(y / sq))) & 1) ? 230 : 25;
+			p[i] = v;
+		}
+	}
+	CompVCalibCameraPtr calib;
+	COMPV_CHECK_CODE_RETURN(CompVCalibCamera::newObj(&calib));
+	CompVCalibContex ctx;
+	COMPV_CHECK_CODE_RETURN(calib->process(image, ctx));
+	r.code = (int)ctx.code;
+	r.rawLines = ctx.lines_raw.lines_hough.size(); r.groupedLines = ctx.lines_grouped.lines_cartesian.size();
+	r.edges.clear();
+	if (ctx.edges) { r.edges.resize(W * H); for (size_t j = 0; j < H; ++j) memcpy(&r.edges[j * W], ctx.edges->ptr<const uint8_t>(j), W); }
+	r.raw.clear();
+	for (const auto& l : ctx.lines_raw.lines_hough) r.raw.push_back(std::make_tuple(l.rho, l.theta, l.strength));
+	std::sort(r.raw.begin(), r.raw.end());
+	r.grouped.clear();
+	for (const auto& l : ctx.lines_grouped.lines_cartesian) { r.grouped.push_back(l.a.x); r.grouped.push_back(l.a.y); r.grouped.push_back(l.b.x); r.grouped.push_back(l.b.y); }
+	r.corners.clear();
+	for (const auto& q : ctx.plane_curr.intersections) { r.corners.push_back(q.x); r.corners.push_back(q.y); }
+	return COMPV_ERROR_CODE_S_OK;
+}
+
+
 // The option contract of the detector classes: the same set() / get() calls -- accepted and refused ones (wrong value size,
 // out-of-range value, unknown id) -- against whatever factories are registered; the return codes are compared CPU vs HIP.
 static std::vector<int> probeOptions()
@@ -242,9 +289,12 @@ int main(int argc, char** argv)
 		if (COMPV_ERROR_CODE_IS_NOK(runSamples(W, H, 12345u + f, cpu[f]))) { fprintf(stderr, "CPU run failed\n"); return 3; }
 	}
 	resetObjects();
+	CalibResult calCpu, calHip;
+	if (COMPV_ERROR_CODE_IS_NOK(runCalibration(1280, 720, calCpu))) { fprintf(stderr, "CPU calibration run failed\n"); return 6; }
 	const std::vector<int> optCpu = probeOptions();
 	if (compv_hip_plugin_register() != 0) { fprintf(stderr, "HIP plugin registration failed (no GPU?)\n"); return 4; }
 	const std::vector<int> optHip = probeOptions();
+	if (COMPV_ERROR_CODE_IS_NOK(runCalibration(1280, 720, calHip))) { fprintf(stderr, "HIP calibration run failed\n"); return 7; }
 	for (int f = 0; f < frames; ++f) {
 		if (COMPV_ERROR_CODE_IS_NOK(runSamples(W, H, 12345u + f, gpu[f]))) { fprintf(stderr, "HIP run failed\n"); return 5; }
 	}
@@ -265,6 +315,13 @@ int main(int argc, char** argv)
 		diff += optCpu.size() != optHip.size();
 		printf("option contract (%zu set/get/newObj/toCartesian probes): %s\n", optCpu.size(), diff ? "DIFF" : "==");
 		bad += diff != 0;
+	}
+	{
+		const bool okE = calCpu.edges == calHip.edges, okR = calCpu.raw == calHip.raw, okG = calCpu.grouped == calHip.grouped;
+		const bool okC = calCpu.code == calHip.code && calCpu.corners == calHip.corners;
+		printf("calibration client (CompVCalibCamera::process, 1280x720 chessboard): edges %s, raw lines %s [%zu], grouped lines %s [%zu], result code %d/%d + %zu corners %s\n",
+			okE ? "==" : "DIFF", okR ? "==" : "DIFF", calCpu.rawLines, okG ? "==" : "DIFF", calCpu.groupedLines, calCpu.code, calHip.code, calCpu.corners.size() / 2, okC ? "==" : "DIFF");
+		bad += !(okE && okR && okG && okC);
 	}
 	bad += checkPreproc(W, H, 4242u) != 0;
 	printf(bad ? "DROP-IN PARITY FAILED\n" : "DROP-IN PARITY OK\n");

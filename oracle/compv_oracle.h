@@ -57,6 +57,8 @@ int orc_sht_lines(const int32_t* acc, size_t R, size_t T, size_t accStride, int3
                   int maxLines, orc_line* lines, size_t cap, size_t* n);
 int orc_sht(const uint8_t* edges, size_t W, size_t H, size_t S, float thetaDeg, int32_t threshold, int maxLines,
             orc_line* lines, size_t cap, size_t* n);
+/* all n lines of a frame (canonical order in) -> the order the reference's unstable std::sort leaves them in (kht_sort.cpp) */
+void orc_sht_reference_order(orc_line* lines, size_t n);
 
 /* ---- caller-side pre-processing of the samples (samples/hough_lines/main.cxx:102-105) ---- */
 /* Pixel formats, numbered as compvhip_pixfmt in include/compv_hip.h. */

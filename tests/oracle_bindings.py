@@ -301,9 +301,26 @@ class Oracle:
         assert r == 0, r
         return [(buf[i].rho, buf[i].theta, buf[i].strength, buf[i].row, buf[i].col) for i in range(min(n.value, cap))]
 
-    def sht(self, edges, theta_deg=1.0, threshold=100, max_lines=0):
+    def sht_lines_from_acc_reference_order(self, acc, W, H, theta_deg, threshold, max_lines=0):
+        """The line list in the order the reference returns it (its unstable std::sort on the strength alone, applied to the
+        (row, col) emission order, then the first max_lines): all lines -> orc_sht_reference_order -> truncation."""
+        R, T = acc.shape
+        _, _, th = self.sht_dims(W, H, theta_deg)
+        cap = max(1, int((acc > threshold).sum()))
+        buf = (OrcLine * cap)()
+        n = C.c_size_t(0)
+        r = self.lib.orc_sht_lines(_p(acc), R, T, acc.strides[0] // 4, threshold, W + H, th, 0, buf, cap, C.byref(n))
+        assert r == 0 and n.value <= cap, (r, n.value, cap)
+        self.lib.orc_sht_reference_order.argtypes = [C.c_void_p, C.c_size_t]
+        self.lib.orc_sht_reference_order(buf, n.value)
+        keep = n.value if max_lines <= 0 else min(n.value, max_lines)
+        return [(buf[i].rho, buf[i].theta, buf[i].strength, buf[i].row, buf[i].col) for i in range(keep)]
+
+    def sht(self, edges, theta_deg=1.0, threshold=100, max_lines=0, reference_order=False):
         acc = self.sht_acc(edges, theta_deg)
         H, W = edges.shape
+        if reference_order:
+            return self.sht_lines_from_acc_reference_order(acc, W, H, theta_deg, threshold, max_lines)
         return self.sht_lines_from_acc(acc, W, H, theta_deg, threshold, max_lines)
 
 

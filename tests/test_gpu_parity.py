@@ -6,6 +6,8 @@ Bars: bit-exact for the uint8 Sobel / Canny maps, the int32 Hough accumulator an
 bit patterns, strength); there is no floating-point tolerance on this path (the only f32 operations are one
 division + one multiply in the Sobel normalisation and col*thetaStep, all correctly rounded single operations).
 """
+import os
+
 import numpy as np
 import pytest
 
@@ -90,6 +92,30 @@ def test_canny_long_weak_chains(hip_ctx, oracle):
     assert (got == exp).all(), int((got != exp).sum())
 
 
+def test_canny_more_hysteresis_rounds_than_flag_slots(oracle, monkeypatch):
+    """A weak chain that zigzags across band borders needs one resolve round per crossing; when the rounds outnumber the flag slots
+    (4096; lowered to 8 here) the slots are reused instead of giving up -- the reference has no such limit."""
+    from compv_amd import capi
+    W, H = 1100, 700
+    img = np.full((H, W), 100, np.uint8)
+    for k, yy in enumerate(range(20, H - 20, 12)):
+        img[yy:yy + 3, 15:W - 15] = 112
+        xs = W - 30 if (k % 2 == 0) else 15
+        img[yy:yy + 15, xs:xs + 3] = 112
+    img[18:26, 10:20] = 255
+    rc, exp = oracle.canny(img, 10.0, 200.0)
+    assert rc == 0 and exp.any()
+    monkeypatch.setenv("COMPVHIP_RESOLVE_WRAP", "8")
+    ctx = capi.Context(0)
+    try:
+        got = ctx.canny(img, 10.0, 200.0)
+        assert (got == exp).all(), int((got != exp).sum())
+        again = ctx.canny(img, 10.0, 200.0)
+        assert (again == exp).all()
+    finally:
+        ctx.close()
+
+
 def test_canny_in_place_and_strided(hip_ctx, oracle):
     W, H, S = 300, 200, 384
     buf = np.zeros((H, S), np.uint8)
@@ -131,7 +157,7 @@ def test_houghsht_matches_oracle(hip_ctx, oracle, W, H, tl, th, deg, thr):
     img = synth_frame(W, H)
     rc, edges = oracle.canny(img, tl, th)
     acc_exp = oracle.sht_acc(edges, deg)
-    exp = oracle.sht_lines_from_acc(acc_exp, W, H, deg, thr)
+    exp = oracle.sht_lines_from_acc_reference_order(acc_exp, W, H, deg, thr)
     lines, acc = hip_ctx.houghsht(edges, deg, thr, want_acc=True)
     assert acc.shape == acc_exp.shape and (acc == acc_exp).all(), int((acc != acc_exp).sum())   # vote histogram bit-exact
     assert _lines_tuple(lines) == _orc_tuple(exp)
@@ -150,7 +176,7 @@ def test_houghsht_wide_rho_range(hip_ctx, oracle, W, H):
     edges[H // 2, :] = 0xff
     edges[:, W // 3] = 0xff
     acc_exp = oracle.sht_acc(edges, 1.0)
-    exp = oracle.sht_lines_from_acc(acc_exp, W, H, 1.0, 30)
+    exp = oracle.sht_lines_from_acc_reference_order(acc_exp, W, H, 1.0, 30)
     lines, acc = hip_ctx.houghsht(edges, 1.0, 30, want_acc=True)
     assert (acc == acc_exp).all(), int((acc != acc_exp).sum())
     assert _lines_tuple(lines) == _orc_tuple(exp)
@@ -169,7 +195,7 @@ def test_houghsht_legacy_vote_kernels(oracle, monkeypatch):
         acc_exp = oracle.sht_acc(edges, 1.0)
         lines, acc = ctx.houghsht(edges, 1.0, 100, want_acc=True)
         assert (acc == acc_exp).all()
-        assert _lines_tuple(lines) == _orc_tuple(oracle.sht_lines_from_acc(acc_exp, W, H, 1.0, 100))
+        assert _lines_tuple(lines) == _orc_tuple(oracle.sht_lines_from_acc_reference_order(acc_exp, W, H, 1.0, 100))
     finally:
         ctx.close()
 
@@ -188,7 +214,7 @@ def test_houghsht_beyond_the_first_generation_limit(hip_ctx, oracle, W, H):
     edges[np.arange(min(W, H)), np.arange(min(W, H))] = 0xff  # and a diagonal
     acc_exp = oracle.sht_acc(edges, 1.0)
     thr = 40
-    exp = oracle.sht_lines_from_acc(acc_exp, W, H, 1.0, thr)
+    exp = oracle.sht_lines_from_acc_reference_order(acc_exp, W, H, 1.0, thr)
     lines, acc = hip_ctx.houghsht(edges, 1.0, thr, want_acc=True, cap=max(1 << 16, len(exp)))
     assert acc.shape == acc_exp.shape and (acc == acc_exp).all(), int((acc != acc_exp).sum())
     assert _lines_tuple(lines) == _orc_tuple(exp)
@@ -203,7 +229,7 @@ def test_houghsht_empty_and_full_maps(hip_ctx, oracle):
     acc_exp = oracle.sht_acc(full, 1.0)
     lines, acc = hip_ctx.houghsht(full, 1.0, 50, want_acc=True)
     assert (acc == acc_exp).all()
-    assert _lines_tuple(lines) == _orc_tuple(oracle.sht_lines_from_acc(acc_exp, W, H, 1.0, 50))
+    assert _lines_tuple(lines) == _orc_tuple(oracle.sht_lines_from_acc_reference_order(acc_exp, W, H, 1.0, 50))
 
 
 def test_houghsht_error_behaviour(hip_ctx):
@@ -242,8 +268,10 @@ def test_golden(hip_ctx, golden, name):
         assert len(lines) == s["lines"]
         assert int(lines["strength"].astype(np.int64).sum()) == s["sum_strength"]
         exp = arrays[name + "/sht_lines"]
-        got = np.stack([lines["rho"][:len(exp)].astype(np.float64), lines["theta"][:len(exp)].astype(np.float64),
-                        lines["strength"][:len(exp)].astype(np.float64)], axis=1)
+        # the fixture holds the canonical order (strength desc, rho desc, theta asc); the host entry point returns the reference's own
+        # order (test_houghsht_host_path_returns_the_references_line_order checks that one): canonicalise before comparing
+        o = np.lexsort((lines["theta"], -lines["rho"], -lines["strength"].astype(np.int64)))[:len(exp)]
+        got = np.stack([lines["rho"][o].astype(np.float64), lines["theta"][o].astype(np.float64), lines["strength"][o].astype(np.float64)], axis=1)
         assert (got == exp).all()
 
 
@@ -501,7 +529,7 @@ def test_random_shape_sweep(hip_ctx, oracle):
         acc_exp = oracle.sht_acc(exp, deg)
         lines, acc = hip_ctx.houghsht(exp, deg, thr, want_acc=True)
         assert (acc == acc_exp).all(), (it, W, H, deg)
-        assert _lines_tuple(lines) == _orc_tuple(oracle.sht_lines_from_acc(acc_exp, W, H, deg, thr)), (it, W, H, deg, thr)
+        assert _lines_tuple(lines) == _orc_tuple(oracle.sht_lines_from_acc_reference_order(acc_exp, W, H, deg, thr)), (it, W, H, deg, thr)
 
 
 def test_full_size_properties_linearity_and_monotonicity(hip_ctx):
@@ -550,7 +578,7 @@ def test_houghsht_line_buffer_contract(hip_ctx, oracle):
     rng = np.random.default_rng(5)
     edges = np.where(rng.random((H, W)) < 0.3, 0xff, 0).astype(np.uint8)
     acc = oracle.sht_acc(edges, deg)
-    exp = oracle.sht_lines_from_acc(acc, W, H, deg, 1)
+    exp = oracle.sht_lines_from_acc_reference_order(acc, W, H, deg, 1)
     assert len(exp) > (1 << 16)                                # more than the initial device key capacity
     got = hip_ctx.houghsht(edges, deg, 1)                      # the wrapper retries with the reported size
     assert _lines_tuple(got) == _orc_tuple(exp)
@@ -635,7 +663,7 @@ def test_houghsht_reference_unittest_parameters_small(hip_ctx, oracle):
         R, T, _ = hip_ctx.houghsht_dims(W, H, m["theta_deg"])
         assert T == 10313 and R == 2 * (W + H) + 1
         acc_exp = oracle.sht_acc(can, m["theta_deg"])
-        exp = oracle.sht_lines_from_acc(acc_exp, W, H, m["theta_deg"], m["threshold"])
+        exp = oracle.sht_lines_from_acc_reference_order(acc_exp, W, H, m["theta_deg"], m["threshold"])
         lines, acc = hip_ctx.houghsht(can, m["theta_deg"], m["threshold"], cap=max(1, m["lines"]), want_acc=True)
         assert (acc == acc_exp).all(), int((acc != acc_exp).sum())
         assert len(lines) == m["lines"] == len(exp)
@@ -643,6 +671,24 @@ def test_houghsht_reference_unittest_parameters_small(hip_ctx, oracle):
         assert float(lines["rho"].astype(np.float64).sum()) == m["sum_rho"]
         assert abs(float(lines["theta"].astype(np.float64).sum()) - m["sum_theta"]) <= 0.0009765625      # the unit test's own tolerance
         assert int(lines["strength"].astype(np.int64).sum()) == m["sum_strength"]
+
+
+@pytest.mark.parametrize("name", ["vga_all", "vga_top100", "hd_halfdeg", "ragged_top40", "calib_like"])
+def test_houghsht_host_path_returns_the_references_line_order(hip_ctx, name):
+    """compvhip_houghsht_u8 against the compiled reference's list, element by element -- the order inside equal-strength groups and the
+    survivors of the maxLines cut included (fixture: tests/golden/make_golden_sht_order.py)."""
+    import hashlib, json
+    m = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_sht_order.json")))[name]
+    can = hip_ctx.canny(synth_frame(m["W"], m["H"], m["seed"]), m["tLow"], m["tHigh"])
+    assert md5_rows(can) == m["canny_md5"]
+    lines = hip_ctx.houghsht(can, m["theta_deg"], m["threshold"], max_lines=m["max_lines"])
+    a = np.zeros((len(lines), 3), np.uint32)
+    a[:, 0] = lines["rho"].astype(np.float32).view(np.uint32)
+    a[:, 1] = lines["theta"].astype(np.float32).view(np.uint32)
+    a[:, 2] = lines["strength"].astype(np.uint32)
+    assert len(a) == m["lines"]
+    assert a[:64].tolist() == m["head"] and a[-64:].tolist() == m["tail"]
+    assert hashlib.md5(a.tobytes()).hexdigest() == m["md5"]
 
 
 def test_houghsht_reference_unittest_parameters_1282x720(hip_ctx):

@@ -112,3 +112,32 @@ def test_sht_vote_total_and_dims(oracle):
     acc = oracle.sht_acc(can, 1.0)
     assert acc.sum() == int((can != 0).sum()) * T      # every edge votes once per theta
     assert oracle.sht_dims(1920, 1080, 1.0)[:2] == (6001, 180)
+
+
+def _sht_order_golden():
+    import json, os
+    return json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_sht_order.json")))
+
+
+def _pack_lines(rho, theta, strength):
+    import numpy as np
+    a = np.zeros((len(rho), 3), np.uint32)
+    a[:, 0] = np.asarray(rho, np.float32).view(np.uint32)
+    a[:, 1] = np.asarray(theta, np.float32).view(np.uint32)
+    a[:, 2] = np.asarray(strength, np.uint32)
+    return a
+
+
+@pytest.mark.parametrize("name", ["vga_all", "vga_top100", "hd_halfdeg", "ragged_top40", "calib_like"])
+def test_sht_reference_line_order_fixture(oracle, name):
+    """The compiled reference's line list, element by element (tests/golden/make_golden_sht_order.py): thousands of equal-strength
+    pairs, with and without a maxLines cut."""
+    import hashlib
+    m = _sht_order_golden()[name]
+    rc, can = oracle.canny(synth_frame(m["W"], m["H"], m["seed"]), m["tLow"], m["tHigh"])
+    assert md5_rows(can) == m["canny_md5"]
+    lines = oracle.sht(can, m["theta_deg"], m["threshold"], m["max_lines"], reference_order=True)
+    a = _pack_lines([l[0] for l in lines], [l[1] for l in lines], [l[2] for l in lines])
+    assert len(a) == m["lines"] and m["equal_strength_pairs"] > 20
+    assert a[:64].tolist() == m["head"] and a[-64:].tolist() == m["tail"]
+    assert hashlib.md5(a.tobytes()).hexdigest() == m["md5"]

@@ -52,6 +52,20 @@ def test_sht_acc_and_lines(oracle, refshim, W, H, tl, th, thr, deg):
     assert _canon_orc(oracle.sht_lines_from_acc(acc, W, H, deg, thr)) == _canon_ref(refshim.sht(e, deg, thr))
 
 
+@pytest.mark.parametrize("W,H,tl,th,thr,deg,maxl", [(640, 480, 59., 119., 30, 1.0, 0), (640, 480, 59., 119., 30, 1.0, 100), (1282, 720, 0.8, 1.6, 100, 1.0, 0),
+                                                     (333, 77, 0.8, 1.6, 5, 0.5, 40), (1280, 720, 59., 119., 60, 0.5, 0)])
+def test_sht_line_order_is_the_references_order(oracle, refshim, W, H, tl, th, thr, deg, maxl):
+    """The reference orders its lines with an unstable std::sort on the strength alone (houghsht.cxx:241-249): the order inside
+    equal-strength groups -- and which of them survive maxLines -- is what libstdc++'s introsort makes of the (row, col) emission
+    order.  orc_sht_reference_order (oracle/kht_sort.cpp) must reproduce the compiled reference's list element by element."""
+    img = synth_frame(W, H, 77)
+    rc, edges = oracle.canny(img, tl, th)
+    got = oracle.sht(edges, deg, thr, maxl, reference_order=True)
+    exp = refshim.sht(edges, deg, thr, maxl)
+    assert len(exp) > 20 and len({l[2] for l in exp}) < len(exp)                 # there ARE equal-strength groups
+    assert [(np.float32(l[0]), np.float32(l[1]), int(l[2])) for l in got] == [(np.float32(l[0]), np.float32(l[1]), int(l[2])) for l in exp]
+
+
 @pytest.mark.parametrize("W,H", [(64, 64), (129, 130), (640, 480), (641, 333), (20, 20), (9, 9)])
 def test_canny_5x5_sobel(oracle, refshim, W, H):
     """COMPV_CANNY_SET_INT_KERNEL_SIZE = 5 (kernels compv_features.h:129-130)."""
