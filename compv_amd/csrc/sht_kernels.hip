@@ -7,7 +7,7 @@
 //
 // Data layout in HBM (per frame):
 //   edge bit mask   u32 [H][wb]            produced by the Canny kernels (or by bytes_to_bits for foreign edge maps)
-//   edge list       u32 [E]   (y<<16)|x    compacted with wave ballot/popcount prefix sums
+//   edge list       u32 [E]   (y<<16)|x    compacted with wave ballot/popcount prefix sums (first generation; per-tile lists: sht_tiles_kernels.hip)
 //   accumulator     u16 [T][accPitch]      THETA-major (the reference is int32 rho-major [R][192]); each vote workgroup
 //                                          owns kShtThetaPerGroup whole theta columns, so the accumulator is
 //                                          written exactly once, coalesced, with no global atomics
@@ -15,11 +15,13 @@
 //                                          descending radix sort over all frames
 //
 // Voting: rho = (x*cosQ[t] + y*sinQ[t]) >> 16 (int32, arithmetic shift), acc[barrier - rho][t]++ for every edge and
-// every t -- E*T scattered increments, the whole cost of the reference's SHT.  Each workgroup privatises the (rho)
-// histogram of 2 theta bins (4 via a tuning knob) in LDS (two u16 counters per dword: a cell can never exceed the number of
-// pixels in a 1-px-wide band < 65536 for W,H <= 32767) and votes with ds_add_u32.  The edge list is stored transposed per
-// compaction block (sht_compact_kernel) so that a wave's 64 simultaneous votes land on different image rows: raster
-// neighbours share rho around theta = 90 deg and would otherwise serialise on one LDS address.
+// every t -- E*T scattered increments, the whole cost of the reference's SHT.  The DEFAULT voting path is the second generation in
+// sht_tiles_kernels.hip (lane = theta over image tiles).  The first generation kept in this file (COMPVHIP_SHT_VOTE=legacy; the
+// A/B reference, limited to W + H <= 20 479): each workgroup privatises the rho histogram of 2 theta bins in LDS (two u16 counters
+// per dword: a cell can never exceed the number of pixels in a 1-px-wide band < 65536 for W,H <= 32767) and votes with ds_add_u32;
+// its edge list is stored transposed per compaction block (sht_compact_kernel) so that a wave's 64 simultaneous votes land on
+// different image rows: raster neighbours share rho around theta = 90 deg and would otherwise serialise on one LDS address.
+// Shared by both generations: sht_nms_kernel, the key sort, sht_decode_kernel, sht_cartesian_kernel, the accumulator export.
 #include "kernels.hpp"
 
 #include <cstring>
