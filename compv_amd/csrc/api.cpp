@@ -52,7 +52,11 @@ struct compvhip_ctx {
 	KhtPoint* khtPts = nullptr; size_t khtPtsCap = 0;
 	KhtSpan* khtSpans = nullptr; size_t khtSpansCap = 0;
 	KhtKernel* khtKernelsDev = nullptr;
-	double khtStageMs[6] = {};   // link, subdivide, statistics (GPU), prune + Gmin, vote + peaks (GPU), sort + sweep of the last KHT call
+	KhtStringDesc* khtStrings = nullptr; size_t khtStringsCap = 0;
+	uint32_t* khtCounts32 = nullptr;
+	KhtSpan* khtScratch = nullptr;
+	KhtSubdivFrame* khtStack = nullptr;
+	double khtStageMs[6] = {};   // link, subdivide (GPU), statistics (GPU), prune + Gmin, vote + peaks (GPU), sort + sweep of the last KHT call
 };
 
 struct TimingEntry { const char* name; hipEvent_t a, b; };
@@ -597,6 +601,7 @@ void compvhip_ctx_destroy(compvhip_ctx* ctx)
 	dfree(ctx, ctx->dIn); dfree(ctx, ctx->dOut); dfree(ctx, ctx->dLines); dfree(ctx, ctx->dCounts); dfree(ctx, ctx->dAccOut);
 	dfree(ctx, ctx->khtCounts); dfree(ctx, ctx->khtParams); dfree(ctx, ctx->khtCells); dfree(ctx, ctx->khtCellCount);
 	dfree(ctx, ctx->khtPts); dfree(ctx, ctx->khtSpans); dfree(ctx, ctx->khtKernelsDev);
+	dfree(ctx, ctx->khtStrings); dfree(ctx, ctx->khtCounts32); dfree(ctx, ctx->khtScratch); dfree(ctx, ctx->khtStack);
 	if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
 	delete ctx;
 }
@@ -1282,7 +1287,7 @@ int compvhip_houghsht_u8(compvhip_ctx* ctx, const uint8_t* edges, size_t W, size
 	return COMPVHIP_OK;
 }
 
-// host linking + subdivision, then the per-cluster statistics on the GPU (kht_stats_kernel); kernels in cluster order
+// host linking, then cluster subdivision (kht_subdivide_kernel) and per-cluster statistics (kht_stats_kernel) on the GPU; kernels in cluster order
 static int khtBuildKernels(compvhip_ctx* ctx, const uint8_t* edges, size_t W, size_t H, size_t S, double clusterMinDeviation, size_t clusterMinSize,
                            std::vector<KhtKernel>& kernels, double& hmax)
 {
@@ -1293,31 +1298,49 @@ static int khtBuildKernels(compvhip_ctx* ctx, const uint8_t* edges, size_t W, si
 	// clone the edges (the linker destroys them, :323-336), link, subdivide
 	std::vector<uint8_t> work(W * H);
 	for (size_t j = 0; j < H; ++j) memcpy(&work[j * W], edges + j * S, W);
-	std::vector<KhtPos> poss; std::vector<KhtRange> strings, clusters;
+	std::vector<KhtPos> poss; std::vector<KhtRange> strings;
 	khtLink(work.data(), W, H, W, clusterMinSize, poss, strings);
 	const auto t1 = clk::now();
 	ctx->khtStageMs[0] = ms(t0, t1);
 	if (strings.empty()) return COMPVHIP_OK;
-	khtClusters(poss, strings, clusterMinSize, clusterMinDeviation, clusters);
-	const auto t2 = clk::now();
-	ctx->khtStageMs[1] = ms(t1, t2);
-	if (clusters.empty()) return COMPVHIP_OK;
-	if (poss.size() > 0xffffffffull) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "too many edge pixels");
+	if (poss.size() > 0x7fffffffull) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "too many edge pixels");
 
-	const size_t n = clusters.size();
+	// device: cluster subdivision (one thread per string), per-cluster statistics (one thread per cluster)
 	std::vector<KhtPoint> pts(poss.size());
 	for (size_t i = 0; i < poss.size(); ++i) { pts[i].x = poss[i].x; pts[i].y = poss[i].y; }
-	std::vector<KhtSpan> spans(n);
-	for (size_t i = 0; i < n; ++i) { spans[i].begin = static_cast<uint32_t>(clusters[i].begin); spans[i].end = static_cast<uint32_t>(clusters[i].end); }
+	std::vector<KhtStringDesc> descs(strings.size());
+	size_t slots = 0;
+	for (size_t i = 0; i < strings.size(); ++i) {
+		descs[i].begin = static_cast<uint32_t>(strings[i].begin); descs[i].end = static_cast<uint32_t>(strings[i].end);
+		descs[i].slot = static_cast<uint32_t>(slots);
+		slots += khtSubdivSlots(strings[i].end - strings[i].begin, clusterMinSize);
+	}
 	HIPCHK(ctx, hipSetDevice(ctx->device));
 	if (ctx->khtPtsCap < pts.size()) { dfree(ctx, ctx->khtPts); ctx->khtPtsCap = 0; HIPCHK(ctx, dmalloc(ctx, &ctx->khtPts, pts.size())); ctx->khtPtsCap = pts.size(); }
-	if (ctx->khtSpansCap < n) {
-		dfree(ctx, ctx->khtSpans); dfree(ctx, ctx->khtKernelsDev); ctx->khtSpansCap = 0;
-		HIPCHK(ctx, dmalloc(ctx, &ctx->khtSpans, n)); HIPCHK(ctx, dmalloc(ctx, &ctx->khtKernelsDev, n)); ctx->khtSpansCap = n;
+	if (ctx->khtStringsCap < descs.size()) {
+		dfree(ctx, ctx->khtStrings); dfree(ctx, ctx->khtCounts32); ctx->khtStringsCap = 0;
+		HIPCHK(ctx, dmalloc(ctx, &ctx->khtStrings, descs.size())); HIPCHK(ctx, dmalloc(ctx, &ctx->khtCounts32, descs.size() + 1)); ctx->khtStringsCap = descs.size();
+	}
+	if (ctx->khtSpansCap < slots) {
+		dfree(ctx, ctx->khtSpans); dfree(ctx, ctx->khtScratch); dfree(ctx, ctx->khtStack); dfree(ctx, ctx->khtKernelsDev); ctx->khtSpansCap = 0;
+		HIPCHK(ctx, dmalloc(ctx, &ctx->khtSpans, slots)); HIPCHK(ctx, dmalloc(ctx, &ctx->khtScratch, slots)); HIPCHK(ctx, dmalloc(ctx, &ctx->khtStack, slots));
+		HIPCHK(ctx, dmalloc(ctx, &ctx->khtKernelsDev, slots)); ctx->khtSpansCap = slots;
 	}
 	hipStream_t st = ctx->stream;
 	HIPCHK(ctx, hipMemcpyAsync(ctx->khtPts, pts.data(), pts.size() * sizeof(KhtPoint), hipMemcpyHostToDevice, st));
-	HIPCHK(ctx, hipMemcpyAsync(ctx->khtSpans, spans.data(), n * sizeof(KhtSpan), hipMemcpyHostToDevice, st));
+	HIPCHK(ctx, hipMemcpyAsync(ctx->khtStrings, descs.data(), descs.size() * sizeof(KhtStringDesc), hipMemcpyHostToDevice, st));
+	KhtSubdivArgs sv;
+	sv.pts = ctx->khtPts; sv.strings = ctx->khtStrings; sv.nStrings = static_cast<int>(descs.size());
+	sv.minSize = static_cast<int>(std::min<size_t>(clusterMinSize, 0x7fffffff)); sv.minDev = clusterMinDeviation;
+	sv.scratch = ctx->khtScratch; sv.stack = ctx->khtStack; sv.counts = ctx->khtCounts32; sv.clusters = ctx->khtSpans; sv.total = ctx->khtCounts32 + descs.size();
+	HIPCHK(ctx, launch_kht_subdivide(sv, st));
+	uint32_t nClusters = 0;
+	HIPCHK(ctx, hipMemcpyAsync(&nClusters, sv.total, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+	HIPCHK(ctx, hipStreamSynchronize(st));
+	const auto t2 = clk::now();
+	ctx->khtStageMs[1] = ms(t1, t2);
+	if (!nClusters) return COMPVHIP_OK;
+	const size_t n = nClusters;
 	KhtStatsArgs sa;
 	sa.pts = ctx->khtPts; sa.clusters = ctx->khtSpans; sa.n = static_cast<int>(n);
 	const size_t pack = n >= 4 ? 4 : (n >= 2 ? 2 : 1); // the reference's AVX (4) / SSE2 (2) kernel-height loops take n & ~(pack - 1) clusters

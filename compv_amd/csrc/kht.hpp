@@ -23,7 +23,6 @@ struct KhtCell { uint32_t order; uint32_t rhoIndex; uint32_t thetaIndex; int32_t
 bool khtAxes(size_t W, size_t H, float rho, float thetaDeg, KhtAxes& ax);
 void khtFillAxes(const KhtAxes& ax, std::vector<double>& rho, std::vector<double>& theta);
 void khtLink(uint8_t* edges, size_t W, size_t H, size_t S, size_t minSize, std::vector<KhtPos>& poss, std::vector<KhtRange>& strings);
-void khtClusters(const std::vector<KhtPos>& poss, const std::vector<KhtRange>& strings, size_t minSize, double minDev, std::vector<KhtRange>& clusters);
 void khtFinishKernels(std::vector<KhtKernel>& kernels, double& hmax);
 double khtPruneAndScale(std::vector<KhtKernel>& kernels, double hmax, double minHeight);
 void khtVoteParams(const KhtAxes& ax, const std::vector<KhtKernel>& kernels, std::vector<KhtVoteParams>& params);
@@ -49,6 +48,22 @@ struct KhtStatsArgs {
 	KhtKernel* out;           // .theta holds vx: acos() is taken by the host libm (khtFinishKernels)
 };
 hipError_t launch_kht_stats(const KhtStatsArgs& a, hipStream_t stream);
+
+// clusters_find / clusters_subdivision (houghkht.cxx:762-832) on the GPU: one thread per string, explicit recursion stack
+struct KhtStringDesc { uint32_t begin, end, slot; }; // points [begin, end) of the string; slot = first cluster / stack slot of its private regions
+struct KhtSubdivFrame { int32_t s, e, m, keep, state; double ratio, rl; };
+struct KhtSubdivArgs {
+	const KhtPoint* pts; const KhtStringDesc* strings; int nStrings;
+	int minSize; double minDev;
+	KhtSpan* scratch;          // per-string cluster regions (capacity: see khtSubdivSlots)
+	KhtSubdivFrame* stack;     // per-string recursion stacks (same slot layout, + 2 frames per string)
+	uint32_t* counts;          // [nStrings] clusters found per string
+	KhtSpan* clusters;         // compacted, string order
+	uint32_t* total;           // [1]
+};
+// upper bound on the clusters (and on the recursion depth) of a string of `len` points
+__host__ __device__ inline size_t khtSubdivSlots(size_t len, size_t minSize) { const size_t m = minSize < 2 ? 2 : minSize; return (len > m ? (len - 1) / (m - 1) : 1) + 2; }
+hipError_t launch_kht_subdivide(const KhtSubdivArgs& a, hipStream_t stream);
 hipError_t launch_kht_vote(const KhtGpuArgs& a, hipStream_t stream);
 hipError_t launch_kht_peaks(const KhtGpuArgs& a, hipStream_t stream);
 

@@ -2,10 +2,9 @@
 //
 // Replaces, behind compvhip_houghkht_u8 (include/compv_hip.h), CompVHoughKht::process
 // (core/features/hough/compv_core_feature_houghkht.cxx:208-447).  KHT is a sequential, latency-bound algorithm: edge
-// linking follows chains pixel by pixel in raster order and destroys the pixels it visits (Appendix A, :544-760), the
-// recursive cluster subdivision (:762-832) and the final sweep over the sorted vote cells (:1207-1247) are order dependent by
-// definition.  Those stages stay on the host, in float64 with the reference's operation order so that the results are
-// bit-identical; the data-parallel stages -- the per-cluster statistics of Algorithm 2, Algorithm-4 Gaussian voting into the
+// linking follows chains pixel by pixel in raster order and destroys the pixels it visits (Appendix A, :544-760) and the final
+// sweep over the sorted vote cells (:1207-1247) is order dependent by definition.  Those stages stay on the host, in float64 with the reference's operation order so that the results are
+// bit-identical; the data-parallel stages -- the cluster subdivision of every string, the per-cluster statistics of Algorithm 2, Algorithm-4 Gaussian voting into the
 // (rho,theta) count map and the 3x3 smoothing + thresholding of that map -- run on the GPU (kht_kernels.hip).
 //
 // Compiled with -ffp-contract=off: every double operation below must round exactly once, like the SSE2 reference build.
@@ -119,34 +118,7 @@ void khtLink(uint8_t* e, size_t W, size_t H, size_t S, size_t minSize, std::vect
 	}
 }
 
-// ---- cluster subdivision (:762-832) ------------------------------------------------------------------------------------
 namespace {
-struct Subdivider {
-	const KhtPos* poss; std::vector<KhtRange>* out; size_t minSize; double minDev;
-	double run(size_t sbegin, size_t s, size_t e)
-	{
-		const size_t keep = out->size();
-		const KhtPos* P = poss + sbegin;
-		const int diffx = P[s].x - P[e].x, diffy = P[s].y - P[e].y;
-		const double length = std::sqrt(static_cast<double>((diffx * diffx) + (diffy * diffy)));
-		size_t maxIndex = s;
-		int maxDev = 0;
-		for (size_t i = s + 1; i < e; ++i) {
-			const int dev = std::abs(((P[s].x - P[i].x) * diffy) - ((P[s].y - P[i].y) * diffx));
-			if (dev > maxDev) { maxIndex = i; maxDev = dev; }
-		}
-		const double ratio = length / std::max(static_cast<double>(maxDev) / length, minDev);
-		if ((maxIndex - s + 1) >= minSize && (e - maxIndex + 1) >= minSize) {
-			const double rl = run(sbegin, s, maxIndex);
-			const double rr = run(sbegin, maxIndex, e);
-			if (rl > ratio || rr > ratio) return rl > rr ? rl : rr;
-		}
-		out->resize(keep);
-		KhtRange r; r.begin = sbegin + s; r.end = sbegin + e + 1; out->push_back(r);
-		return ratio;
-	}
-};
-
 // CompVMathEigen<double>::find2x2 (base/math/compv_math_eigen.cxx:285-342), sort = norm = true
 void find2x2(const double (&A)[4], double (&D)[4], double (&Q)[4])
 {
@@ -198,13 +170,6 @@ double gaussEq15(double rho, double theta, const KhtKernel& k)
 	return x * expFastSmall(-z * y);
 }
 } // namespace
-
-void khtClusters(const std::vector<KhtPos>& poss, const std::vector<KhtRange>& strings, size_t minSize, double minDev, std::vector<KhtRange>& clusters)
-{
-	clusters.clear();
-	Subdivider sd; sd.poss = poss.data(); sd.out = &clusters; sd.minSize = minSize; sd.minDev = minDev;
-	for (const KhtRange& s : strings) sd.run(s.begin, 0, (s.end - s.begin) - 1);
-}
 
 // Algorithm 2 (:885-1026): the per-cluster statistics run on the GPU (kht_kernels.hip, kht_stats_kernel).  What is left here is the
 // one libm call of the stage -- theta = acos(vx) in degrees (:949; the device acos is not glibc's) -- and hmax.

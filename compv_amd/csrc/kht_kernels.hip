@@ -1,5 +1,10 @@
 // kht_kernels.hip -- GPU stages of the kernel-based Hough transform for gfx950.
 //
+//   kht_subdivide_kernel  clusters_find / clusters_subdivision (:762-832): every string is split recursively at its point of largest
+//                     deviation from the chord while a half scores a better length / deviation ratio.  One thread = one string, the
+//                     recursion unrolled onto an explicit stack in global memory (depth <= the number of clusters the string can
+//                     have); float64 with __ddiv_rn / __dsqrt_rn, integer deviations as the reference computes them.
+//                     kht_gather_clusters_kernel puts the strings' clusters into one list, in string order.
 //   kht_stats_kernel  voting_Algorithm2_Kernels + CompVHoughKhtKernelHeight_* + CompVMathEigen<double>::find2x2 (:849-1026,
 //                     base/math/compv_math_eigen.cxx:285-342): centroid, covariance, closed-form eigenvectors, rho, Eq. 14 terms and
 //                     the kernel height of every cluster.  One thread = one cluster: the float64 sums run in the reference's
@@ -27,6 +32,93 @@ __device__ __forceinline__ double exp_fast_small(double x)
 	return x;
 }
 
+
+__global__ __launch_bounds__(64) void kht_subdivide_kernel(KhtSubdivArgs a)
+{
+	const int sidx = blockIdx.x * blockDim.x + threadIdx.x;
+	if (sidx >= a.nStrings) return;
+	const KhtStringDesc sd = a.strings[sidx];
+	const KhtPoint* __restrict__ P = a.pts + sd.begin;
+	KhtSpan* __restrict__ out = a.scratch + sd.slot;
+	KhtSubdivFrame* __restrict__ st = a.stack + sd.slot;
+	const int maxDepth = (int)khtSubdivSlots(sd.end - sd.begin, (size_t)a.minSize);
+	int outCount = 0, sp = 0;
+	double ret = 0.0;
+	st[0].s = 0; st[0].e = (int)(sd.end - sd.begin) - 1; st[0].state = 0;
+	sp = 1;
+	while (sp > 0) {
+		KhtSubdivFrame& f = st[sp - 1];
+		if (f.state == 0) {
+			const int s = f.s, e = f.e;
+			const KhtPoint ps = P[s], pe = P[e];
+			const int diffx = ps.x - pe.x, diffy = ps.y - pe.y;
+			const double length = __dsqrt_rn((double)((diffx * diffx) + (diffy * diffy)));
+			int maxIndex = s, maxDev = 0;
+			for (int i = s + 1; i < e; ++i) {
+				const KhtPoint pi = P[i];
+				const int d = ((ps.x - pi.x) * diffy) - ((ps.y - pi.y) * diffx);
+				const int dev = d < 0 ? -d : d;
+				if (dev > maxDev) { maxIndex = i; maxDev = dev; }
+			}
+			const double q = __ddiv_rn((double)maxDev, length);
+			f.ratio = __ddiv_rn(length, q > a.minDev ? q : a.minDev); // length / std::max(maxDev / length, minDev)
+			f.keep = outCount; f.m = maxIndex;
+			if ((maxIndex - s + 1) >= a.minSize && (e - maxIndex + 1) >= a.minSize && maxIndex > s && sp < maxDepth) {
+				f.state = 1;
+				st[sp].s = s; st[sp].e = maxIndex; st[sp].state = 0; ++sp;
+				continue;
+			}
+			outCount = f.keep;
+			out[outCount].begin = sd.begin + (uint32_t)s; out[outCount].end = sd.begin + (uint32_t)e + 1u; ++outCount;
+			ret = f.ratio; --sp;
+		}
+		else if (f.state == 1) {
+			f.rl = ret; f.state = 2;
+			st[sp].s = f.m; st[sp].e = f.e; st[sp].state = 0; ++sp;
+		}
+		else {
+			const double rl = f.rl, rr = ret;
+			if (rl > f.ratio || rr > f.ratio) ret = rl > rr ? rl : rr; // the halves stay
+			else {
+				outCount = f.keep;
+				out[outCount].begin = sd.begin + (uint32_t)f.s; out[outCount].end = sd.begin + (uint32_t)f.e + 1u; ++outCount;
+				ret = f.ratio;
+			}
+			--sp;
+		}
+	}
+	a.counts[sidx] = (uint32_t)outCount;
+}
+
+// one workgroup: exclusive scan of the per-string counts, then the clusters are copied into one list in string order
+__global__ __launch_bounds__(1024) void kht_gather_clusters_kernel(KhtSubdivArgs a)
+{
+	__shared__ uint32_t s_part[1024];
+	__shared__ uint32_t s_carry;
+	if (threadIdx.x == 0) s_carry = 0;
+	__syncthreads();
+	for (int base = 0; base < a.nStrings; base += 1024) {
+		const int i = base + (int)threadIdx.x;
+		const uint32_t c = i < a.nStrings ? a.counts[i] : 0u;
+		s_part[threadIdx.x] = c;
+		__syncthreads();
+		for (int o = 1; o < 1024; o <<= 1) { // Hillis-Steele inclusive scan
+			const uint32_t v = threadIdx.x >= (unsigned)o ? s_part[threadIdx.x - o] : 0u;
+			__syncthreads();
+			s_part[threadIdx.x] += v;
+			__syncthreads();
+		}
+		const uint32_t off = s_carry + s_part[threadIdx.x] - c;
+		if (i < a.nStrings) {
+			const KhtSpan* __restrict__ src = a.scratch + a.strings[i].slot;
+			for (uint32_t k = 0; k < c; ++k) a.clusters[off + k] = src[k];
+		}
+		__syncthreads();
+		if (threadIdx.x == 1023) s_carry += s_part[1023];
+		__syncthreads();
+	}
+	if (threadIdx.x == 0) *a.total = s_carry;
+}
 
 // CompVMathEigen<double>::find2x2 (base/math/compv_math_eigen.cxx:285-342), sort = norm = true
 __device__ __forceinline__ void find2x2_dev(double a0, double a1, double a2, double a3, double (&D)[4], double (&Q)[4])
@@ -191,6 +283,14 @@ __global__ __launch_bounds__(256) void kht_peaks_kernel(KhtGpuArgs a, int sseCov
 		KhtCell o; o.order = order; o.rhoIndex = (uint32_t)emitRho; o.thetaIndex = (uint32_t)ti; o.count = s;
 		a.cells[idx] = o;
 	}
+}
+
+hipError_t launch_kht_subdivide(const KhtSubdivArgs& a, hipStream_t stream)
+{
+	if (a.nStrings <= 0) return hipSuccess;
+	hipLaunchKernelGGL(kht_subdivide_kernel, dim3((a.nStrings + 63) / 64), dim3(64), 0, stream, a);
+	hipLaunchKernelGGL(kht_gather_clusters_kernel, dim3(1), dim3(1024), 0, stream, a);
+	return hipGetLastError();
 }
 
 hipError_t launch_kht_stats(const KhtStatsArgs& a, hipStream_t stream)

@@ -147,9 +147,9 @@ COMPVHIP_API int compvhip_houghsht_u8(compvhip_ctx* ctx, const uint8_t* edges, s
  * houghkht.cxx:38-40; ranges as CompVHoughKht::set checks them, :169-186).  Lines come back in the reference's order (descending smoothed count, the reference's own
  * std::sort tie order); rho is measured from the image centre (toCartesian, :1249-1280); row/col of compvhip_line hold
  * the rho/theta indices.  *gs receives COMPV_HOUGHKHT_GET_FLT64_GS when kernels survive (left untouched otherwise, like
- * the reference's m_dGS).  Hybrid: edge linking (Appendix A follows chains pixel by pixel in raster order and erases what it visits),
- * cluster subdivision and the final sweep are order dependent and run on the host inside this library; the per-cluster statistics
- * (Algorithm 2), Gaussian voting (Algorithm 4) and vote-map smoothing run on the GPU. */
+ * the reference's m_dGS).  Hybrid: edge linking (Appendix A follows chains pixel by pixel in raster order and erases what it visits)
+ * and the final sweep are order dependent and run on the host inside this library; cluster subdivision (one thread per string), the
+ * per-cluster statistics (Algorithm 2), Gaussian voting (Algorithm 4) and vote-map smoothing run on the GPU. */
 COMPVHIP_API int compvhip_houghkht_u8(compvhip_ctx* ctx, const uint8_t* edges, size_t W, size_t H, size_t S,
                                       float rho, float thetaDeg, int threshold, int maxLines,
                                       double clusterMinDeviation, size_t clusterMinSize, double kernelMinHeight,
@@ -159,7 +159,7 @@ COMPVHIP_API int compvhip_houghkht_u8(compvhip_ctx* ctx, const uint8_t* edges, s
  * pruning, in cluster order, 7 doubles each in the field order of CompVHoughKhtKernel (houghkht.h:52-62): rho, theta (degrees), h,
  * sigma_theta_square, sigma_rho_square, m2, sigma_rho_times_theta; *hmax = the largest height.  COMPVHIP_E_OUT_OF_BOUND (with *n = the
  * number of kernels) when cap is too small.  compvhip_houghkht_stage_ms: wall-clock milliseconds of the six stages of this context's
- * last compvhip_houghkht_u8 call -- linking, subdivision, statistics (upload + GPU + download), pruning + Gmin, voting + peaks (GPU),
+ * last compvhip_houghkht_u8 call -- linking, subdivision (upload + GPU), statistics (GPU + download), pruning + Gmin, voting + peaks (GPU),
  * sort + sweep. */
 COMPVHIP_API int compvhip_houghkht_kernels_u8(compvhip_ctx* ctx, const uint8_t* edges, size_t W, size_t H, size_t S,
                                               double clusterMinDeviation, size_t clusterMinSize,

@@ -20,7 +20,7 @@ for _ in range(reps):
     wall.append((time.perf_counter() - t0) * 1e3)
     stages.append(ctx.houghkht_stage_ms())
 st = np.median(np.array(stages), axis=0)
-names = ["link (host)", "subdivide (host)", "statistics (upload + kht_stats_kernel + download)", "prune + Gmin (host)",
+names = ["link (host)", "subdivide (upload + kht_subdivide_kernel + kht_gather_clusters_kernel)", "statistics (kht_stats_kernel + download)", "prune + Gmin (host)",
          "vote + peaks (kht_vote_kernel, kht_peaks_kernel, download)", "sort + sweep (host)"]
 print(json.dumps({"workload": "KHT(rho=1, theta=1deg, thr=100) on one %dx%d Canny(59,119) edge map, %d edge pixels" % (W, H, int((edges != 0).sum())),
                   "lines": int(len(lines)), "gs": gs, "ms_per_call_median": round(float(np.median(wall)), 3),
