@@ -93,6 +93,7 @@ def main():
     ap.add_argument("--inflight", type=int, default=2,
                     help="batches in flight: N plans (own buffers) on N HIP streams take the steps in turn, so the latency-bound kernels of one "
                          "batch (key sort, decode, hysteresis rounds) run under the wide kernels of the other; 1 = one stream, kernels never overlap")
+    ap.add_argument("--depth", type=int, default=2, help="steps enqueued per batch in flight before the host waits for the oldest one")
     ap.add_argument("--sync-steps", action="store_true", help="experiment: the synchronous step (one host round trip per step)")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (nccl = RCCL) even for a world of one rank: exercises init / barrier / all_reduce / "
@@ -160,7 +161,7 @@ def main():
                 t = q["plan"].pipeline_async(d_in.data_ptr(), T_LOW, T_HIGH, SHT_THRESHOLD, 0, q["edges"].data_ptr(), q["lines"].data_ptr(),
                                              line_cap, q["counts"].data_ptr(), q["stream"].cuda_stream)
                 pend.append((q, t))
-                if len(pend) > 2 * len(lanes):
+                if len(pend) > max(1, min(args.depth, 3)) * len(lanes):   # the library keeps at most 4 steps of a plan in flight
                     q0, t0 = pend.pop(0)
                     q0["plan"].wait(t0)
             for q0, t0 in pend:
