@@ -244,7 +244,7 @@ bool planVoteTiles(size_t W, size_t H, const std::vector<int32_t>& sinQ, const s
 				rowBase[(static_cast<size_t>(ty) * nx + tx) * T + t] = static_cast<int32_t>(base - d);
 			}
 		}
-		if (alignUp(static_cast<size_t>(worst), 8) <= static_cast<size_t>(kShtMaxWindow) && TW <= 2048 && static_cast<long long>(TW - 1) * 65535 + static_cast<long long>(TH - 1) * 65535 < 0x7f000000LL) {
+		if (alignUp(static_cast<size_t>(worst), 8) <= static_cast<size_t>(kShtMaxWindow) && TW <= 1280 && static_cast<long long>(TW - 1) * 65535 + static_cast<long long>(TH - 1) * 65535 < 0x7f000000LL) {
 			v.nx = nx; v.ny = ny; v.TW = TW; v.TH = TH; v.tiles = tiles;
 			v.Rw = static_cast<int>(alignUp(static_cast<size_t>(worst), 8)); v.rwPitch = v.Rw;
 			v.groups = static_cast<int>((T + 63) / 64); v.Tpad = v.groups * 64;
