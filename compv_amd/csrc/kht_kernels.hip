@@ -1,9 +1,9 @@
 // kht_kernels.hip -- GPU stages of the kernel-based Hough transform for gfx950.
 //
 //   kht_subdivide_kernel  clusters_find / clusters_subdivision (:762-832): every string is split recursively at its point of largest
-//                     deviation from the chord while a half scores a better length / deviation ratio.  One thread = one string, the
-//                     recursion unrolled onto an explicit stack in global memory (depth <= the number of clusters the string can
-//                     have); float64 with __ddiv_rn / __dsqrt_rn, integer deviations as the reference computes them.
+//                     deviation from the chord while a half scores a better length / deviation ratio.  One wave = one string: lane 0
+//                     runs the recursion on an explicit stack in global memory (depth <= the number of clusters the string can have;
+//                     float64 with __ddiv_rn / __dsqrt_rn), all 64 lanes scan the points for the largest integer deviation.
 //                     kht_gather_clusters_kernel puts the strings' clusters into one list, in string order.
 //   kht_stats_kernel  voting_Algorithm2_Kernels + CompVHoughKhtKernelHeight_* + CompVMathEigen<double>::find2x2 (:849-1026,
 //                     base/math/compv_math_eigen.cxx:285-342): centroid, covariance, closed-form eigenvectors, rho, Eq. 14 terms and
@@ -35,59 +35,79 @@ __device__ __forceinline__ double exp_fast_small(double x)
 
 __global__ __launch_bounds__(64) void kht_subdivide_kernel(KhtSubdivArgs a)
 {
-	const int sidx = blockIdx.x * blockDim.x + threadIdx.x;
-	if (sidx >= a.nStrings) return;
+	// One WAVE per string.  Lane 0 runs the recursion (explicit stack and cluster list in global memory, float64 ratios); the only
+	// O(length) part of a call -- the point of largest deviation from the chord, first index on ties (:779-787) -- is scanned by all 64
+	// lanes and reduced (integer arithmetic: order independent).
+	const int sidx = blockIdx.x;
+	const int lane = threadIdx.x;
 	const KhtStringDesc sd = a.strings[sidx];
 	const KhtPoint* __restrict__ P = a.pts + sd.begin;
 	KhtSpan* __restrict__ out = a.scratch + sd.slot;
 	KhtSubdivFrame* __restrict__ st = a.stack + sd.slot;
 	const int maxDepth = (int)khtSubdivSlots(sd.end - sd.begin, (size_t)a.minSize);
-	int outCount = 0, sp = 0;
+	int outCount = 0, sp = 0; // lane 0 only
 	double ret = 0.0;
-	st[0].s = 0; st[0].e = (int)(sd.end - sd.begin) - 1; st[0].state = 0;
-	sp = 1;
-	while (sp > 0) {
-		KhtSubdivFrame& f = st[sp - 1];
-		if (f.state == 0) {
-			const int s = f.s, e = f.e;
-			const KhtPoint ps = P[s], pe = P[e];
-			const int diffx = ps.x - pe.x, diffy = ps.y - pe.y;
-			const double length = __dsqrt_rn((double)((diffx * diffx) + (diffy * diffy)));
-			int maxIndex = s, maxDev = 0;
-			for (int i = s + 1; i < e; ++i) {
-				const KhtPoint pi = P[i];
-				const int d = ((ps.x - pi.x) * diffy) - ((ps.y - pi.y) * diffx);
-				const int dev = d < 0 ? -d : d;
-				if (dev > maxDev) { maxIndex = i; maxDev = dev; }
+	if (lane == 0) { st[0].s = 0; st[0].e = (int)(sd.end - sd.begin) - 1; st[0].state = 0; sp = 1; }
+	for (;;) {
+		// lane 0 unwinds until the frame on top needs its scan (state 0) or the stack is empty
+		int s = -1, e = -1;
+		if (lane == 0) {
+			while (sp > 0 && st[sp - 1].state != 0) {
+				KhtSubdivFrame& f = st[sp - 1];
+				if (f.state == 1) {
+					f.rl = ret; f.state = 2;
+					st[sp].s = f.m; st[sp].e = f.e; st[sp].state = 0; ++sp;
+				}
+				else {
+					const double rl = f.rl, rr = ret;
+					if (rl > f.ratio || rr > f.ratio) ret = rl > rr ? rl : rr; // the halves stay
+					else {
+						outCount = f.keep;
+						out[outCount].begin = sd.begin + (uint32_t)f.s; out[outCount].end = sd.begin + (uint32_t)f.e + 1u; ++outCount;
+						ret = f.ratio;
+					}
+					--sp;
+				}
 			}
+			if (sp > 0) { s = st[sp - 1].s; e = st[sp - 1].e; }
+		}
+		s = __builtin_amdgcn_readfirstlane(s); e = __builtin_amdgcn_readfirstlane(e);
+		if (s < 0) break;
+		const KhtPoint ps = P[s], pe = P[e];
+		const int diffx = ps.x - pe.x, diffy = ps.y - pe.y;
+		// key = deviation << 32 | ~index: the largest key is the largest deviation at its FIRST index
+		unsigned long long best = 0ull;
+		for (int i = s + 1 + lane; i < e; i += 64) {
+			const KhtPoint pi = P[i];
+			const int d = ((ps.x - pi.x) * diffy) - ((ps.y - pi.y) * diffx);
+			const unsigned long long key = ((unsigned long long)(uint32_t)(d < 0 ? -d : d) << 32) | (uint32_t)~(uint32_t)i;
+			best = key > best ? key : best;
+		}
+#pragma unroll
+		for (int o = 32; o > 0; o >>= 1) {
+			const unsigned long long other = __shfl_xor(best, o);
+			best = other > best ? other : best;
+		}
+		if (lane == 0) {
+			KhtSubdivFrame& f = st[sp - 1];
+			const int maxDev = (int)(best >> 32);
+			const int maxIndex = maxDev > 0 ? (int)~(uint32_t)(best & 0xffffffffull) : s;
+			const double length = __dsqrt_rn((double)((diffx * diffx) + (diffy * diffy)));
 			const double q = __ddiv_rn((double)maxDev, length);
 			f.ratio = __ddiv_rn(length, q > a.minDev ? q : a.minDev); // length / std::max(maxDev / length, minDev)
 			f.keep = outCount; f.m = maxIndex;
 			if ((maxIndex - s + 1) >= a.minSize && (e - maxIndex + 1) >= a.minSize && maxIndex > s && sp < maxDepth) {
 				f.state = 1;
 				st[sp].s = s; st[sp].e = maxIndex; st[sp].state = 0; ++sp;
-				continue;
 			}
-			outCount = f.keep;
-			out[outCount].begin = sd.begin + (uint32_t)s; out[outCount].end = sd.begin + (uint32_t)e + 1u; ++outCount;
-			ret = f.ratio; --sp;
-		}
-		else if (f.state == 1) {
-			f.rl = ret; f.state = 2;
-			st[sp].s = f.m; st[sp].e = f.e; st[sp].state = 0; ++sp;
-		}
-		else {
-			const double rl = f.rl, rr = ret;
-			if (rl > f.ratio || rr > f.ratio) ret = rl > rr ? rl : rr; // the halves stay
 			else {
 				outCount = f.keep;
-				out[outCount].begin = sd.begin + (uint32_t)f.s; out[outCount].end = sd.begin + (uint32_t)f.e + 1u; ++outCount;
-				ret = f.ratio;
+				out[outCount].begin = sd.begin + (uint32_t)s; out[outCount].end = sd.begin + (uint32_t)e + 1u; ++outCount;
+				ret = f.ratio; --sp;
 			}
-			--sp;
 		}
 	}
-	a.counts[sidx] = (uint32_t)outCount;
+	if (lane == 0) a.counts[sidx] = (uint32_t)outCount;
 }
 
 // one workgroup: exclusive scan of the per-string counts, then the clusters are copied into one list in string order
@@ -288,7 +308,7 @@ __global__ __launch_bounds__(256) void kht_peaks_kernel(KhtGpuArgs a, int sseCov
 hipError_t launch_kht_subdivide(const KhtSubdivArgs& a, hipStream_t stream)
 {
 	if (a.nStrings <= 0) return hipSuccess;
-	hipLaunchKernelGGL(kht_subdivide_kernel, dim3((a.nStrings + 63) / 64), dim3(64), 0, stream, a);
+	hipLaunchKernelGGL(kht_subdivide_kernel, dim3(a.nStrings), dim3(64), 0, stream, a);
 	hipLaunchKernelGGL(kht_gather_clusters_kernel, dim3(1), dim3(1024), 0, stream, a);
 	return hipGetLastError();
 }
