@@ -578,7 +578,10 @@ hipError_t launch_sht_nms(const ShtArgs& a, int frames, hipStream_t stream)
 hipError_t sht_sort_keys(void* temp, size_t& tempBytes, const uint64_t* keysIn, uint64_t* keysOut, size_t lineCap, int frames, int keyBits,
                          hipStream_t stream)
 {
-	return rocprim::radix_sort_keys_desc(temp, tempBytes, keysIn, keysOut, lineCap * (size_t)frames, 0u, (unsigned int)keyBits, stream);
+	// 10-bit digits: the 40-bit key of the 4K benchmark takes 4 onesweep passes instead of the 5 of the library's 8-bit default
+	using Onesweep = rocprim::radix_sort_onesweep_config<rocprim::kernel_config<1024, 8>, rocprim::kernel_config<1024, 10>, 10, rocprim::block_radix_rank_algorithm::match>;
+	using Config = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, Onesweep>;
+	return rocprim::radix_sort_keys_desc<Config>(temp, tempBytes, keysIn, keysOut, lineCap * (size_t)frames, 0u, (unsigned int)keyBits, stream);
 }
 
 hipError_t launch_sht_decode(const uint64_t* keys, const int* counts, size_t lineCap, int frames, int T, int barrier, float thetaStep,
