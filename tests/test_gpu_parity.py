@@ -319,6 +319,46 @@ def test_plan_pipeline_batch_matches_oracle(hip_ctx, oracle):
         assert _lines_tuple(got) == _orc_tuple(exp)
 
 
+def test_plan_houghsht_foreign_edge_maps_with_empty_and_full_frames(hip_ctx, oracle):
+    """compvhip_plan_houghsht on caller-provided edge maps (any non-zero byte is an edge, houghsht.cxx:159-165): a batch that mixes
+    an EMPTY frame (no tile has an edge), a frame with every pixel set (the densest possible tile lists) and sparse frames -- the
+    frames of a batch must not influence each other."""
+    import torch
+    from compv_amd import capi
+    W, H = 704, 200
+    rng = np.random.default_rng(7)
+    frames = np.zeros((4, H, W), np.uint8)
+    frames[1][:] = 0xff
+    frames[2] = (rng.random((H, W)) < 0.03).astype(np.uint8) * 7          # non-zero, not 0xff
+    frames[3][H // 2, :] = 1
+    dev = torch.device("cuda:0")
+    d_edges = torch.from_numpy(frames).to(dev)
+    cap = 1 << 16
+    d_lines = torch.zeros((4, cap, 5), dtype=torch.int32, device=dev)
+    d_counts = torch.zeros(4, dtype=torch.int32, device=dev)
+    plan = capi.Plan(hip_ctx, W, H, W, 4, 1.0)
+    st = torch.cuda.current_stream().cuda_stream
+    thr = 25
+    for _ in range(2):                                                     # twice: no state may leak between calls either
+        plan.houghsht(d_edges.data_ptr(), thr, 0, d_lines.data_ptr(), cap, d_counts.data_ptr(), st)
+        torch.cuda.synchronize()
+        counts = d_counts.cpu().numpy()
+        raw = d_lines.cpu().numpy().view(np.uint8).reshape(4, cap, 20)
+        _, R, T, _ = plan.acc(0)
+        for f in range(4):
+            a = torch.zeros((R, T), dtype=torch.int32, device=dev)
+            plan.acc_export(f, a.data_ptr(), T, st)
+            torch.cuda.synchronize()
+            acc = oracle.sht_acc(frames[f], 1.0)
+            assert (a.cpu().numpy() == acc).all(), f
+            exp = oracle.sht_lines_from_acc(acc, W, H, 1.0, thr)
+            assert counts[f] == len(exp), (f, counts[f], len(exp))
+            got = np.frombuffer(raw[f].tobytes(), dtype=capi.LINE_DTYPE)[:len(exp)]
+            assert _lines_tuple(got) == _orc_tuple(exp), f
+        assert counts[0] == 0
+    plan.close()
+
+
 @pytest.mark.parametrize("name", ["fhd_1920x1080", "uhd_3840x2160"])
 def test_plan_full_size_golden_and_properties(hip_ctx, golden, name):
     """BASELINE configs 2-4: full Canny and SHT at 1080p / 4K through the batched plan: MD5/sums from the compiled
