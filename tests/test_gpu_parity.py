@@ -460,10 +460,14 @@ def test_houghkht_matches_oracle(hip_ctx, oracle, W, H, tl, th, rho, deg, thr):
 
 
 @pytest.mark.parametrize("W,H,tl,th,min_dev,min_size", [(320, 240, 59., 119., 2.0, 10), (1282, 720, 0.8, 1.6, 2.0, 10), (641, 480, 59., 119., 0.5, 5),
-                                                         (1920, 1080, 59., 119., 2.0, 10), (333, 77, 0.8, 1.6, 4.0, 3)])
+                                                         (1920, 1080, 59., 119., 2.0, 10), (333, 77, 0.8, 1.6, 4.0, 3),
+                                                         (320, 240, 59., 119., 2.0, 2),      # smallest clusters the recursion can produce
+                                                         (641, 480, 59., 119., 0.0, 4),      # no deviation floor: ratios may be +inf
+                                                         (3840, 2160, 59., 119., 2.0, 10)])
 def test_houghkht_cluster_statistics_kernel_bit_exact(hip_ctx, oracle, W, H, tl, th, min_dev, min_size):
-    """kht_stats_kernel (one thread per cluster, float64, __ddiv_rn / __dsqrt_rn) against the oracle's voting_Algorithm2_Kernels:
-    all seven fields of every kernel and hmax, bit for bit (theta goes through the host libm acos on both sides)."""
+    """kht_subdivide_kernel (one wave per string) + kht_stats_kernel (one thread per cluster, float64, __ddiv_rn / __dsqrt_rn) against the
+    oracle's clusters_find + voting_Algorithm2_Kernels: the same clusters in the same order, all seven fields of every kernel and hmax,
+    bit for bit (theta goes through the host libm acos on both sides)."""
     img = synth_frame(W, H, 4242)
     rc, edges = oracle.canny(img, tl, th)
     exp, hmax_exp = oracle.kht_kernels(edges, min_dev, min_size)
