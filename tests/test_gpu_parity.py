@@ -834,3 +834,44 @@ def test_plan_pipeline_async_matches_sync(hip_ctx, oracle):
             plan.wait(tickets[0])                                 # a ticket can be waited for once
     finally:
         plan.close()
+
+
+def test_two_plans_in_flight_on_two_streams(hip_ctx, oracle):
+    """bench.py's default step mode: two plans, each with its own buffers and HIP stream, take asynchronous steps in turn so that kernels
+    of different batches overlap on the GPU.  Different inputs per plan, several steps each; every plan's LAST result is compared with
+    the oracle (nothing may leak between plans that share a context)."""
+    import torch
+    from compv_amd import capi
+    W, H, n, cap, steps = 1104, 620, 3, 8192, 4
+    dev = torch.device("cuda:0")
+    lanes = []
+    for k in range(2):
+        frames = np.stack([synth_frame(W, H, 100 * k + f) for f in range(n)])
+        lanes.append({"frames": frames, "plan": capi.Plan(hip_ctx, W, H, W, n, 1.0), "st": torch.cuda.Stream(device=dev),
+                      "in": torch.from_numpy(frames).to(dev), "e": torch.empty((n, H, W), dtype=torch.uint8, device=dev),
+                      "l": torch.zeros((n, cap, 5), dtype=torch.int32, device=dev), "c": torch.zeros(n, dtype=torch.int32, device=dev)})
+    torch.cuda.synchronize()
+    try:
+        pend = []
+        for s in range(steps):
+            for q in lanes:
+                t = q["plan"].pipeline_async(q["in"].data_ptr(), 59.0, 119.0, 45, 0, q["e"].data_ptr(), q["l"].data_ptr(), cap, q["c"].data_ptr(),
+                                             q["st"].cuda_stream)
+                pend.append((q, t))
+                if len(pend) > 2:
+                    q0, t0 = pend.pop(0)
+                    q0["plan"].wait(t0)
+        for q0, t0 in pend:
+            q0["plan"].wait(t0)
+        torch.cuda.synchronize()
+        for k, q in enumerate(lanes):
+            edges = q["e"].cpu().numpy(); counts = q["c"].cpu().numpy(); raw = q["l"].cpu().numpy().view(np.uint8).reshape(n, cap, 20)
+            for f in range(n):
+                rc, e = oracle.canny(q["frames"][f], 59.0, 119.0)
+                assert (edges[f] == e).all(), (k, f)
+                exp = oracle.sht(e, 1.0, 45)
+                assert counts[f] == len(exp) and len(exp) <= cap
+                assert _lines_tuple(np.frombuffer(raw[f].tobytes(), dtype=capi.LINE_DTYPE)[:len(exp)]) == _orc_tuple(exp), (k, f)
+    finally:
+        for q in lanes:
+            q["plan"].close()
