@@ -3,19 +3,29 @@
 
     python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
 
-One "step" = one pass of the whole hot path (compvhip_plan_pipeline: fused Sobel+NMS+tile hysteresis, cross-tile
-resolve, edge compaction, Hough voting, Hough NMS, line sort/decode) over a batch of FRAMES_PER_GPU frames that are
-already resident in HBM.  Frames are independent units: ranks process disjoint frame shards, no data-path collective
-(weak scaling: per-GPU batch fixed).  Timing: barrier + synchronize, K steps, synchronize + barrier, MAX over ranks.
+One "step" = one pass of the whole hot path (compvhip_plan_pipeline_async: fused Sobel+NMS, hysteresis rounds, edge compaction, Hough
+voting, Hough NMS, line sort/decode) over ONE batch of FRAMES_PER_GPU frames already resident in HBM.  The job holds BASELINE config 4's
+256 distinct frames (seeds 12345 .. 12345+255) as 8 resident batches of 32 and rotates over them: step k of rank r processes batch
+(r + k) mod 8, so no step re-reads the previous step's input (nothing of the 265 MB a step reads can still sit in the 256 MiB Infinity
+Cache from the step before last, and the two batches in flight are always different ones).  Frames are independent units: ranks
+process disjoint batches, no data-path collective (weak scaling: per-GPU batch fixed).  --scatter adds the RCCL data path of SURVEY 8(e):
+the step's batch is born on rank 0 and scattered, the per-frame line counts and strongest lines are all-gathered.
+Timing: barrier + synchronize, K steps, synchronize + barrier, MAX over ranks; median of --reps repetitions.
+
+After the timed region every one of the 256 frames is checked against tests/golden/golden_batch.json (edge-map MD5, edge count, line
+count, strength sum, line-set hash -- all produced by the real CompV library, tests/golden/make_golden_batch.py), in the same two-lane
+asynchronous mode the timed steps use; a mismatch raises and NO number is printed.
 
 Extra objects on the JSON line:
-  roofline      dominant kernel (by measured time): algorithmic bytes / average launch duration, durations measured
-                with HIP events recorded by the library on the stream the kernels run on, during the timed steps
-  roofline_canny  the fused Sobel->Canny tile kernel on the same basis (north_star's 40 % target is quoted on it)
-  cpu_baseline  the REAL CompV CPU library (oracle/_ref, AVX2 intrinsics path, all host cores) -- or the C port --
-                timed on a bounded sample of the same workload on rank 0 at N=1
+  roofline        dominant kernel (by measured time): algorithmic bytes / average launch duration (HIP events on the launch stream)
+  roofline_canny  the fused Sobel->Canny tile kernel on the same basis (north_star's 40 % target is quoted on it) + its VALU-issue floor
+  cpu_baseline    the REAL CompV CPU library (oracle/_ref, AVX2 intrinsics path) timed on a bounded sample of the same workload, at its
+                  best thread count and frame-parallel (P processes x T threads over independent frames)
+  host_api        latency of the host-pointer (drop-in) entry points on one 4K frame, PCIe transfers included
+  kht             the batched KHT path on this run's edge maps (BASELINE config 5)
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
@@ -28,14 +38,66 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E peak, /opt/skills/guides/MI355X_MICROARCH.md
+SIMDS, CLOCK_GHZ = 1024, 2.4
 TIMING_MODES = {"sht_vote_kernel": 3, "canny_tile_kernel": 4}   # compvhip_plan_set_timing: HIP events around one kernel only
 T_LOW, T_HIGH = 59.0, 119.0
 THETA_DEG, SHT_THRESHOLD = 1.0, 100
+GOLDEN_FRAMES = 256
+M64 = (1 << 64) - 1
 
 
-def synth_batch(n, W, H, first_seed):
-    from oracle_bindings import synth_frame
-    return np.stack([synth_frame(W, H, first_seed + f) for f in range(n)])
+# ------------------------------------------------------------------------------------------------------------------------------------
+# synthetic frames on the device (bit-identical to tests/oracle_bindings.synth_frame / oracle/compv_oracle.c::orc_synth_frame)
+# ------------------------------------------------------------------------------------------------------------------------------------
+def lcg_tables(n):
+    """s_k = a^k s_0 + c_k (mod 2^32) for k = 1..n: the LCG jump-ahead tables of synth_frame."""
+    M = np.uint64(0xFFFFFFFF)
+    a = np.uint64(1664525)
+    c = np.uint64(1013904223)
+    ap = np.array([1], dtype=np.uint64)
+    cp = np.array([0], dtype=np.uint64)
+    while len(ap) <= n:
+        aL = (ap[-1] * a) & M
+        cL = (cp[-1] * a + c) & M
+        ap, cp = np.concatenate([ap, (ap * aL) & M]), np.concatenate([cp, (ap * cL + cp) & M])
+    return ap[1:n + 1].astype(np.int64), cp[1:n + 1].astype(np.int64)
+
+
+class FrameSynth:
+    def __init__(self, torch, dev, W, H):
+        self.torch, self.W, self.H = torch, W, H
+        ap, cp = lcg_tables(W * H)
+        self.ap = torch.from_numpy(ap).to(dev).reshape(H, W)
+        self.cp = torch.from_numpy(cp).to(dev).reshape(H, W)
+        i = torch.arange(W, dtype=torch.int64, device=dev)[None, :]
+        j = torch.arange(H, dtype=torch.int64, device=dev)[:, None]
+        self.base = 40 + (((i // 64 + j // 64) & 1) * 150)
+        self.diag = ((i + 2 * j) % 257) < 3
+
+    def frame(self, seed):
+        t = self.torch
+        s = (self.ap * int(seed & 0xFFFFFFFF) + self.cp) & 0xFFFFFFFF     # int64 wrap-around keeps the low 32 bits exact
+        v = self.base + (s >> 28)
+        v = t.where(self.diag, t.full_like(v, 255), v)
+        return v.to(t.uint8)
+
+    def batch(self, seeds):
+        return self.torch.stack([self.frame(s) for s in seeds])
+
+
+# ------------------------------------------------------------------------------------------------------------------------------------
+# CPU baseline
+# ------------------------------------------------------------------------------------------------------------------------------------
+def _ref_worker(args):
+    """One process of the frame-parallel baseline: its own CompV instance with `threads` workers, its own frames."""
+    threads, first_seed, n, W, H = args
+    from oracle_bindings import RefShim, synth_frame
+    ref = RefShim(threads)
+    frames = np.stack([synth_frame(W, H, first_seed + f) for f in range(n)])
+    ref.bench_pipeline(frames[:1], T_LOW, T_HIGH, THETA_DEG, SHT_THRESHOLD)   # warm the pool and the scratch buffers
+    t0 = time.time()
+    ms, e, l = ref.bench_pipeline(frames, T_LOW, T_HIGH, THETA_DEG, SHT_THRESHOLD)
+    return t0, time.time(), n
 
 
 def cpu_baseline(W, H, budget_s=20.0):
@@ -45,7 +107,7 @@ def cpu_baseline(W, H, budget_s=20.0):
     if have_refshim():
         # CompVBase::init(numThreads): -1 = one worker per logical CPU.  The best of a short thread-count sweep is used
         # for the main sample, so that an over-subscribed thread pool does not flatter the GPU.
-        probe = synth_batch(2, W, H, 12345)
+        probe = np.stack([synth_frame(W, H, 12345 + f) for f in range(2)])
         sweep = {}
         ref = None
         for t in (-1, 1, 8, 32):
@@ -59,13 +121,29 @@ def cpu_baseline(W, H, budget_s=20.0):
             sweep[ref.threads] = round(ms / 2, 2)
         best = min(sweep, key=sweep.get)
         ref.reinit(best)
-        n = int(max(2, min(64, budget_s * 1000.0 / max(sweep[best], 1e-3))))
-        frames = synth_batch(n, W, H, 12345)
+        n = int(max(2, min(64, 0.5 * budget_s * 1000.0 / max(sweep[best], 1e-3))))
+        frames = np.stack([synth_frame(W, H, 12345 + f) for f in range(n)])
         ms, edges, lines = ref.bench_pipeline(frames, T_LOW, T_HIGH, THETA_DEG, SHT_THRESHOLD)
-        return {"value": round(n * W * H / (ms * 1e-3) / 1e6, 2), "unit": "Mpixels/s", "cores": ref.threads, "host_cpus": cores,
-                "kind": "reference",
-                "sample": "%d frames %dx%d, CompV AVX2 intrinsics path (COMPV_ASM=0), %d threads (best of sweep), Canny(59,119)+SHT(1deg,100)" % (n, W, H, ref.threads),
-                "ms_per_frame": round(ms / n, 3), "ms_per_frame_by_threads": sweep}
+        out = {"value": round(n * W * H / (ms * 1e-3) / 1e6, 2), "unit": "Mpixels/s", "cores": ref.threads, "host_cpus": cores,
+               "kind": "reference",
+               "sample": "%d frames %dx%d, CompV AVX2 intrinsics path (COMPV_ASM=0), %d threads (best of sweep), Canny(59,119)+SHT(1deg,100)" % (n, W, H, ref.threads),
+               "ms_per_frame": round(ms / n, 3), "ms_per_frame_by_threads": sweep}
+        # frame-parallel: CompV's row-band pool stops scaling at ~8 threads, independent frames do not -- P processes x T threads
+        # ("all host cores via row-band / frame-parallel threads").  Throughput = frames / (last finish - first start).
+        try:
+            import multiprocessing as mp
+            tt = max(1, min(best, 8))
+            procs = max(1, min(cores // tt, 32))
+            per = max(1, int(0.5 * budget_s * 1000.0 / max(sweep[best] * (best / tt if best > tt else 1.0), 1e-3) / 2))
+            per = min(per, 8)
+            with mp.get_context("spawn").Pool(procs) as pool:
+                res = pool.map(_ref_worker, [(tt, 20000 + 100 * i, per, W, H) for i in range(procs)])
+            span = max(r[1] for r in res) - min(r[0] for r in res)
+            out["frame_parallel"] = {"value": round(procs * per * W * H / span / 1e6, 2), "unit": "Mpixels/s", "processes": procs,
+                                     "threads_per_process": tt, "cores": procs * tt, "frames": procs * per}
+        except Exception as e:  # reporting only
+            out["frame_parallel"] = {"error": str(e)}
+        return out
     orc = Oracle()
     img = synth_frame(W, H, 12345)
     t0 = time.time()
@@ -79,15 +157,61 @@ def cpu_baseline(W, H, budget_s=20.0):
             "sample": "%d frames %dx%d, scalar C restatement (oracle/compv_oracle.c)" % (n, W, H), "ms_per_frame": round(dt / n * 1e3, 3)}
 
 
+def host_api_latency(capi, dev_index, frame):
+    """Latency of the drop-in (host pointer) entry points on one frame: upload + kernels + download (+ host sorts), best of 3."""
+    ctx = capi.Context(dev_index)
+    out = {}
+    try:
+        def best(fn, n=3):
+            fn()
+            ts = []
+            for _ in range(n):
+                t0 = time.perf_counter(); r = fn(); ts.append(time.perf_counter() - t0)
+            return round(min(ts) * 1e3, 3), r
+        out["canny_u8_ms"], edges = best(lambda: ctx.canny(frame, T_LOW, T_HIGH))
+        out["houghsht_u8_ms"], lines = best(lambda: ctx.houghsht(edges, THETA_DEG, SHT_THRESHOLD))
+        out["houghkht_u8_ms"], kl = best(lambda: ctx.houghkht(edges, 1.0, THETA_DEG, 1))
+        out["sht_lines"] = int(len(lines[0]) if isinstance(lines, tuple) else len(lines))
+        out["note"] = "one %dx%d frame per call, host pointers (what CompVEdgeDete::process / CompVHough::process hand over): PCIe both ways included" % (frame.shape[1], frame.shape[0])
+    finally:
+        ctx.close()
+    return out
+
+
+def so_sha256():
+    h = hashlib.sha256()
+    with open(os.path.join(ROOT, "compv_amd", "lib", "libcompv_hip.so"), "rb") as f:
+        h.update(f.read())
+    return h.hexdigest()
+
+
+def committed_counters(W, H, F):
+    """PMC results committed under profiles/ (rocprofv3 --pmc passes, tools/pmc_pass.sh + tools/traffic_from_pmc.py).  They are only
+    valid for the library build they were collected with: the file stores that build's sha256 and a stale file is ignored."""
+    try:
+        rounds = sorted(d for d in os.listdir(os.path.join(ROOT, "profiles")) if os.path.exists(os.path.join(ROOT, "profiles", d, "traffic.json")))
+        t = json.load(open(os.path.join(ROOT, "profiles", rounds[-1], "traffic.json")))
+        if t.get("workload") != {"W": W, "H": H, "frames": F}:
+            return None, "profiles/%s/traffic.json is for another workload" % rounds[-1]
+        if t.get("so_sha256") != so_sha256():
+            return None, "profiles/%s/traffic.json was collected with another build of libcompv_hip.so (stale): traffic = null" % rounds[-1]
+        return t, "committed PMC pass profiles/%s/traffic.json (rocprofv3 --pmc, separate runs, same library build: sha256 %s...)" % (rounds[-1], t["so_sha256"][:12])
+    except Exception as e:
+        return None, "no committed PMC pass (%s)" % e
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=16)
+    ap.add_argument("--warmup", type=int, default=4)
     ap.add_argument("--frames-per-gpu", type=int, default=32)   # BASELINE config 4: 256 frames over 8 GPUs
+    ap.add_argument("--batches", type=int, default=8, help="distinct resident batches the steps rotate over (8 x 32 = config 4's 256 frames)")
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the host_api / kht objects")
+    ap.add_argument("--no-verify", action="store_true", help="experiment only: skip the golden check of all frames (the JSON line says so)")
     ap.add_argument("--no-kernel-events", action="store_true", help="experiment: no per-kernel HIP events in the timed steps")
     ap.add_argument("--reps", type=int, default=5, help="repetitions of the timed K-step loop; the MEDIAN repetition is reported")
     ap.add_argument("--inflight", type=int, default=2,
@@ -95,96 +219,117 @@ def main():
                          "batch (key sort, decode, hysteresis rounds) run under the wide kernels of the other; 1 = one stream, kernels never overlap")
     ap.add_argument("--depth", type=int, default=2, help="steps enqueued per batch in flight before the host waits for the oldest one")
     ap.add_argument("--sync-steps", action="store_true", help="experiment: the synchronous step (one host round trip per step)")
+    ap.add_argument("--scatter", action="store_true",
+                    help="RCCL data path (SURVEY 8e): every step's global batch is born on rank 0 and scattered (grouped send/recv), line counts "
+                         "and the strongest lines of every frame are all-gathered; inside the timed region")
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise torch.distributed (nccl = RCCL) even for a world of one rank: exercises init / barrier / all_reduce / "
                          "all_gather on real hardware where only one GPU is available")
+    ap.add_argument("--shared-gpu", action="store_true", help="test mode: every rank uses cuda:0 (two HIP contexts + an RCCL ring on ONE leased GPU)")
+    ap.add_argument("--dist-backend", default="nccl")
     args = ap.parse_args()
 
     import torch
-    from compv_amd import capi
+    from compv_amd import capi, sharding
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    local_rank = 0 if args.shared_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     dist_on = world > 1 or (args.force_dist and "RANK" in os.environ)
+    dist = None
     if dist_on:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on these hosts (RCCL needs it)
         torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.shared_gpu:
+            dist.init_process_group(backend=args.dist_backend)
+        else:
+            dist.init_process_group(backend=args.dist_backend, device_id=torch.device("cuda", local_rank))
     else:
         torch.cuda.set_device(0)
     dev = torch.device("cuda", local_rank if dist_on else 0)
+    comm_dev = dev if args.dist_backend == "nccl" else torch.device("cpu")
 
-    from compv_amd import sharding
-    W, H, F = args.width, args.height, args.frames_per_gpu
-    # weak scaling: the global batch is world*F frames, frame f uses seed 12345+f, rank r owns a contiguous block
-    mine = sharding.shard_range(world * F, world, rank)
-    assert len(mine) == F
-    frames = synth_batch(F, W, H, sharding.frame_seed(mine[0]))
-    d_in = torch.from_numpy(frames).to(dev)
-    d_edges = torch.empty_like(d_in)
+    W, H, F, NB = args.width, args.height, args.frames_per_gpu, max(1, args.batches)
+    synth = FrameSynth(torch, dev, W, H)
+    # frame f of block b has the global index b * F + f and the seed 12345 + (index mod 256); rank r runs block (r + k) % NB at step k
+    block_seeds = [[sharding.frame_seed((b * F + f) % GOLDEN_FRAMES) for f in range(F)] for b in range(NB)]
+    blocks = [synth.batch(s) for s in block_seeds]
+    if rank == 0:   # the device generator against the host one (one frame: the generators are checked exhaustively in tests/)
+        from oracle_bindings import synth_frame
+        if not np.array_equal(blocks[0][0].cpu().numpy(), synth_frame(W, H, block_seeds[0][0])):
+            raise RuntimeError("device frame generator disagrees with tests/oracle_bindings.synth_frame")
+    del synth
     line_cap = 1 << 16
-    d_lines = torch.zeros((F, line_cap, 5), dtype=torch.int32, device=dev)
-    d_counts = torch.zeros(F, dtype=torch.int32, device=dev)
-
     ctx = capi.Context(local_rank if dist_on else 0)
-    plan = capi.Plan(ctx, W, H, W, F, THETA_DEG)
-    # a dedicated HIP stream (not the legacy null stream, whose implicit synchronisation costs ~3 % here); the library records its
-    # kernel events on this same stream, and the timed region is bracketed by device-wide synchronisations
-    launch_stream = torch.cuda.Stream(device=dev)
-    stream = launch_stream.cuda_stream
-    torch.cuda.synchronize()
 
-    lanes = [{"plan": plan, "edges": d_edges, "lines": d_lines, "counts": d_counts, "stream": launch_stream}]
-    for _ in range(1, max(1, args.inflight)):
-        lanes.append({"plan": capi.Plan(ctx, W, H, W, F, THETA_DEG), "edges": torch.empty_like(d_in), "lines": torch.zeros_like(d_lines),
-                      "counts": torch.zeros_like(d_counts), "stream": torch.cuda.Stream(device=dev)})
+    def make_lane():
+        return {"plan": capi.Plan(ctx, W, H, W, F, THETA_DEG), "edges": torch.empty_like(blocks[0]),
+                "lines": torch.zeros((F, line_cap, 5), dtype=torch.int32, device=dev), "counts": torch.zeros(F, dtype=torch.int32, device=dev),
+                # a dedicated HIP stream (not the legacy null stream, whose implicit synchronisation costs ~3 % here); the library records
+                # its kernel events on this same stream, and the timed region is bracketed by device-wide synchronisations
+                "stream": torch.cuda.Stream(device=dev), "in": torch.empty_like(blocks[0]) if args.scatter else None}
+    lanes = [make_lane() for _ in range(max(1, 1 if args.sync_steps else args.inflight))]
+    plan = lanes[0]["plan"]
     torch.cuda.synchronize()
+    TOPK = 64
 
-    def step():
-        plan.pipeline(d_in.data_ptr(), T_LOW, T_HIGH, SHT_THRESHOLD, 0, d_edges.data_ptr(), d_lines.data_ptr(), line_cap,
-                      d_counts.data_ptr(), stream)
+    def my_block(k):
+        return (rank + k) % NB
+
+    def enqueue(q, k):
+        """step k on lane q (asynchronous); returns the ticket"""
+        d_in = blocks[my_block(k)]
+        if args.scatter:
+            # the global batch of step k lives on rank 0 (its resident blocks): rank r receives block (r + k) % NB over RCCL
+            # (grouped send/recv), ordered on the lane's stream in front of the step's kernels
+            with torch.cuda.stream(q["stream"]):
+                sharding.scatter_blocks(dist if dist_on else None, lambda r: blocks[(r + k) % NB], q["in"], src=0)
+            d_in = q["in"]
+        return q["plan"].pipeline_async(d_in.data_ptr(), T_LOW, T_HIGH, SHT_THRESHOLD, 0, q["edges"].data_ptr(), q["lines"].data_ptr(), line_cap,
+                                        q["counts"].data_ptr(), q["stream"].cuda_stream)
+
+    def finish(q, t):
+        q["plan"].wait(t)
+        if args.scatter:
+            with torch.cuda.stream(q["stream"]):
+                sharding.gather_lines(dist if dist_on else None, q["counts"], q["lines"][:, :TOPK].contiguous())
+
+    step_no = [0]
 
     def run_steps(k):
         """k steps.  Default: each step is enqueued with compvhip_plan_pipeline_async and waited for while the NEXT one is already
         running (the hysteresis convergence flag is read one step late; a miss replays that step) -- no host round trip per step."""
         if args.sync_steps:
+            q = lanes[0]
             for _ in range(k):
-                step()
+                q["plan"].pipeline(blocks[my_block(step_no[0])].data_ptr(), T_LOW, T_HIGH, SHT_THRESHOLD, 0, q["edges"].data_ptr(), q["lines"].data_ptr(),
+                                   line_cap, q["counts"].data_ptr(), q["stream"].cuda_stream)
+                step_no[0] += 1
             return
-        if args.inflight > 1:
-            pend = []
-            for i in range(k):
-                q = lanes[i % len(lanes)]
-                t = q["plan"].pipeline_async(d_in.data_ptr(), T_LOW, T_HIGH, SHT_THRESHOLD, 0, q["edges"].data_ptr(), q["lines"].data_ptr(),
-                                             line_cap, q["counts"].data_ptr(), q["stream"].cuda_stream)
-                pend.append((q, t))
-                if len(pend) > max(1, min(args.depth, 3)) * len(lanes):   # the library keeps at most 4 steps of a plan in flight
-                    q0, t0 = pend.pop(0)
-                    q0["plan"].wait(t0)
-            for q0, t0 in pend:
-                q0["plan"].wait(t0)
-            return
-        prev = None
+        pend = []
         for _ in range(k):
-            t = plan.pipeline_async(d_in.data_ptr(), T_LOW, T_HIGH, SHT_THRESHOLD, 0, d_edges.data_ptr(), d_lines.data_ptr(), line_cap,
-                                    d_counts.data_ptr(), stream)
-            if prev is not None:
-                plan.wait(prev)
-            prev = t
-        if prev is not None:
-            plan.wait(prev)
+            q = lanes[step_no[0] % len(lanes)]
+            pend.append((q, enqueue(q, step_no[0])))
+            step_no[0] += 1
+            if len(pend) > max(1, min(args.depth, 3)) * len(lanes):   # the library keeps at most 4 steps of a plan in flight
+                finish(*pend.pop(0))
+        for q0, t0 in pend:
+            finish(q0, t0)
 
     run_steps(args.warmup)
     torch.cuda.synchronize()
     # which kernel dominates a step?  One extra untimed, fully instrumented step decides which single kernel carries HIP events
     # during the timed steps (events around every launch would cost ~0.1 ms per step, around two kernels ~0.04 ms).
+    def one_sync_step(q, b):
+        q["plan"].pipeline(blocks[b].data_ptr(), T_LOW, T_HIGH, SHT_THRESHOLD, 0, q["edges"].data_ptr(), q["lines"].data_ptr(), line_cap,
+                           q["counts"].data_ptr(), q["stream"].cuda_stream)
+
     dominant = "sht_vote_kernel"
     if not args.no_kernel_events:
         plan.set_timing(1)
-        step()
+        one_sync_step(lanes[0], 0)
         per = {}
         for name, ms in plan.get_timing():
             per[name] = per.get(name, 0.0) + ms
@@ -208,7 +353,7 @@ def main():
                 a[1] += 1
 
     # The timed region is EXACTLY K steps between barrier + synchronize brackets; it is repeated `reps` times inside this run and
-    # the MEDIAN repetition is reported (one 20-step region lasts ~20 ms: a single one is a thin measurement).
+    # the MEDIAN repetition is reported (one 16-step region lasts ~15 ms: a single one is a thin measurement).
     rep_elapsed = []
     for _ in range(max(1, args.reps)):
         if dist_on:
@@ -220,7 +365,7 @@ def main():
         if dist_on:
             dist.barrier()
         e = time.perf_counter() - t0
-        rep_elapsed.append(sharding.max_over_ranks(e, dist if dist_on else None, dev))
+        rep_elapsed.append(sharding.max_over_ranks(e, dist if dist_on else None, comm_dev))
         collect(per_kernel)   # the dominant kernel's events of this repetition's K steps (read after the closing bracket)
     elapsed = sorted(rep_elapsed)[len(rep_elapsed) // 2]
 
@@ -231,21 +376,78 @@ def main():
     breakdown = {}
     if rank == 0 and not args.no_kernel_events:
         plan.set_timing(1)
-        for _ in range(args.steps):
-            step()
+        for k in range(args.steps):
+            one_sync_step(lanes[0], k % NB)
             collect(breakdown, [plan])
     plan.set_timing(0)
-    n_edges = int((d_edges != 0).sum().item())
-    for q in lanes[1:]:   # every batch in flight produced the same result
-        if not torch.equal(q["counts"], d_counts) or not torch.equal(q["edges"], d_edges):
-            raise RuntimeError("the batches in flight disagree")
-    if int(d_counts.max().item()) > line_cap:
-        raise RuntimeError("a frame produced %d lines, more than the line capacity %d: its line set would be an arbitrary subset" % (int(d_counts.max().item()), line_cap))
 
-    counts = d_counts.cpu().numpy()
-    # the only result exchange of the job: all-gather of the tiny per-frame line counts, outside the timed region
+    # ---- verification: every frame of every resident batch against the reference-derived fixture, in the mode the timed steps use ----
+    golden = None
+    verify_note = None
+    gpath = os.path.join(ROOT, "tests", "golden", "golden_batch.json")
+    if args.no_verify:
+        verify_note = "skipped (--no-verify)"
+    elif (W, H) != (3840, 2160) or not os.path.exists(gpath):
+        verify_note = "no reference-derived fixture for this geometry: outputs of the two lanes compared with each other only"
+    else:
+        golden = json.load(open(gpath))
+        assert (golden["W"], golden["H"], golden["tLow"], golden["tHigh"], golden["threshold"]) == (W, H, T_LOW, T_HIGH, SHT_THRESHOLD)
+        golden = {g["seed"]: g for g in golden["frames"]}
+    barrier_rows = W + H
+    total_edges = 0
+    total_lines = 0
+    lines_frame0 = None
+    checked = 0
+    for b0 in range(0, NB, len(lanes)):
+        todo = [(lanes[i], b0 + i) for i in range(len(lanes)) if b0 + i < NB]
+        if args.sync_steps:
+            for q, b in todo:
+                one_sync_step(q, b)
+        else:
+            tickets = [(q, q["plan"].pipeline_async(blocks[b].data_ptr(), T_LOW, T_HIGH, SHT_THRESHOLD, 0, q["edges"].data_ptr(), q["lines"].data_ptr(), line_cap,
+                                                    q["counts"].data_ptr(), q["stream"].cuda_stream)) for q, b in todo]   # both lanes in flight, as in the timed steps
+            for q, t in tickets:
+                q["plan"].wait(t)
+        torch.cuda.synchronize()
+        for q, b in todo:
+            counts = q["counts"].cpu().numpy()
+            if int(counts.max()) > line_cap:
+                raise RuntimeError("a frame produced %d lines, more than the line capacity %d: its line set would be an arbitrary subset" % (int(counts.max()), line_cap))
+            n_e = (q["edges"] != 0).sum(dim=(1, 2)).cpu().numpy()
+            total_edges += int(n_e.sum())
+            total_lines += int(counts.sum())
+            if b == 0:
+                lines_frame0 = int(counts[0])
+            if golden is None:
+                continue
+            ln = q["lines"].to(torch.int64)
+            idx = torch.arange(line_cap, device=dev)[None, :]
+            valid = idx < q["counts"].to(torch.int64)[:, None]
+            st = torch.where(valid, ln[:, :, 2], torch.zeros_like(ln[:, :, 2]))
+            hv = (barrier_rows - ln[:, :, 3] + 32768) * 1000003 + ln[:, :, 4] * 7919 + ln[:, :, 2] * 31337
+            hv = torch.where(valid, hv, torch.zeros_like(hv)).sum(dim=1).cpu().numpy()
+            sums = st.sum(dim=1).cpu().numpy()
+            edges_host = q["edges"].cpu().numpy()
+            for f in range(F):
+                g = golden[block_seeds[b][f]]
+                got = {"canny_md5": hashlib.md5(edges_host[f].tobytes()).hexdigest(), "edges": int(n_e[f]), "lines": int(counts[f]),
+                       "sum_strength": int(sums[f]), "line_hash": "%016x" % (int(hv[f]) & M64)}
+                exp = {k: g[k] for k in got}
+                if got != exp:
+                    raise RuntimeError("frame seed %d (batch %d, frame %d) differs from the CompV reference: got %r, expected %r" % (block_seeds[b][f], b, f, got, exp))
+                checked += 1
+    if golden is None and len(lanes) > 1 and not args.no_verify:
+        # no fixture: at least the lanes must agree on one common batch
+        for q in lanes:
+            one_sync_step(q, 0)
+        torch.cuda.synchronize()
+        for q in lanes[1:]:
+            if not torch.equal(q["counts"], lanes[0]["counts"]) or not torch.equal(q["edges"], lanes[0]["edges"]):
+                raise RuntimeError("the batches in flight disagree")
+
+    # the only result exchange of the default job: all-gather of the tiny per-frame line counts, outside the timed region
     try:
-        all_counts = sharding.gather_frame_results([int(c) for c in counts], dist if dist_on else None, dev)
+        all_counts = sharding.gather_frame_results([int(c) for c in lanes[0]["counts"].cpu().numpy()], dist if dist_on else None, comm_dev)
     except Exception:  # reporting only: never let it hide the throughput number
         all_counts = None
     n_ranks = dist.get_world_size() if dist_on else 1
@@ -265,21 +467,11 @@ def main():
             "canny_tile_kernel": F * W * H * 1.0,
             "sht_vote_kernel": F * (W * H + R * T * 4.0),
         }
+        counters, counters_src = committed_counters(W, H, F)
 
-        traffic_src = [None]
-
-        def measured_traffic(name):
-            # HBM bytes per launch from the COMMITTED rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE, KiB; see
-            # tools/traffic_from_pmc.py for the calibration) -- not a counter of this run, and only valid for the workload they
-            # were collected on; the JSON line says which file the number comes from
-            try:
-                rounds = sorted(d for d in os.listdir(os.path.join(ROOT, "profiles")) if os.path.exists(os.path.join(ROOT, "profiles", d, "traffic.json")))
-                t = json.load(open(os.path.join(ROOT, "profiles", rounds[-1], "traffic.json")))
-                if t["workload"] == {"W": W, "H": H, "frames": F} and name in t["kernels"]:
-                    traffic_src[0] = "committed PMC pass profiles/%s/traffic.json (rocprofv3 --pmc, separate runs; not measured in this run)" % rounds[-1]
-                    return t["kernels"][name]["hbm_bytes"]
-            except Exception:
-                pass
+        def counter(name, key):
+            if counters and name in counters["kernels"] and key in counters["kernels"][name]:
+                return counters["kernels"][name][key]
             return None
 
         def roof(name, nbytes, ms=None):
@@ -287,10 +479,21 @@ def main():
                 return None
             ms = kern[name]["ms_per_launch"] if ms is None else ms
             ach = nbytes / (ms * 1e-3) / 1e9
-            tr = measured_traffic(name)
+            tr = counter(name, "hbm_bytes")
             return {"kernel": name, "bound": "hbm", "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": tr, "traffic_source": traffic_src[0] if tr is not None else None,
+                    "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": tr, "traffic_source": counters_src,
                     "ms_per_launch": round(ms, 4), "algorithmic_bytes_per_launch": int(nbytes)}
+
+        def valu_floor(name, ms):
+            """issue floor of the kernel's own instruction mix: SQ_INSTS_VALU (PMC, per launch) x cycles per wave64 instruction
+            (tools/isa_cost.py over the kernel's main loop with the microbenchmark costs 2.3 / 4.3) / SIMDs / clock"""
+            n = counter(name, "SQ_INSTS_VALU")
+            cpi = counter(name, "valu_cycles_per_instruction")
+            if n is None or cpi is None:
+                return None
+            floor_ms = n * cpi / SIMDS / (CLOCK_GHZ * 1e9) * 1e3
+            return {"SQ_INSTS_VALU": int(n), "cycles_per_wave_instruction": cpi, "simds": SIMDS, "clock_ghz": CLOCK_GHZ,
+                    "floor_ms": round(floor_ms, 4), "frac": round(floor_ms / ms, 4)}
         overlapped = len(lanes) > 1 and not args.sync_steps
         iso = {k: v[0] / v[1] for k, v in breakdown.items()}
         roofline = None
@@ -312,18 +515,24 @@ def main():
             if dom == "sht_vote_kernel":
                 # what actually bounds it: one ds_add_u32 wave-instruction (64 votes) per 4.1 LDS cycles per CU when conflict-free
                 # (tools/microbench/lds_atomic_bench2), 256 CUs
-                votes = float(n_edges) * T
+                votes = float(total_edges) / NB * T
                 floor_ms = votes / 64.0 * 4.1 / 256.0 / 2.4e9 * 1e3
                 roofline["lds_atomic_roofline"] = {"votes_per_launch": int(votes), "cycles_per_wave_instruction": 4.1, "cus": 256, "clock_ghz": 2.4,
                                                    "floor_ms": round(floor_ms, 4), "frac": round(floor_ms / roofline["ms_per_launch"], 4)}
                 roofline["note"] = ("the voting kernel is bound by the LDS atomic pipe, not by HBM (lds_atomic_roofline); the HBM fraction is reported "
                                     "because the contract prices every kernel of this path against the HBM roofline")
+            vf = valu_floor(dom, roofline["ms_per_launch"])
+            if vf:
+                roofline["valu_issue"] = vf
         rc = None
         if "canny_tile_kernel" in iso:
             rc = roof("canny_tile_kernel", alg["canny_tile_kernel"], iso["canny_tile_kernel"])
             rc["timing"] = "HIP events in the single-stream instrumented pass after the timed steps"
         if rc:
             rc["frac_read_plus_write"] = round(2 * rc["frac"], 4)
+            vf = valu_floor("canny_tile_kernel", rc["ms_per_launch"])
+            if vf:
+                rc["valu_issue"] = vf
         out = {
             "metric": "Mpixels/s Sobel->Canny->HoughSHT on 4K uint8",
             "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -333,20 +542,35 @@ def main():
             "step_mode": "synchronous (host reads the hysteresis flag every step)" if args.sync_steps else
                          "pipelined (compvhip_plan_pipeline_async: step k's hysteresis flag is read while step k+1 runs), %d batch(es) in flight "
                          "(one plan + HIP stream each, steps dealt round-robin)" % len(lanes),
-            "batches_in_flight": 1 if args.sync_steps else len(lanes),
+            "batches_in_flight": len(lanes),
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "dist_backend": (dist.get_backend() if dist_on else None),
-            "config": {"workload": "batched %dx%d uint8 frames, Sobel3x3 -> Canny(59,119) -> HoughSHT(rho=1, theta=1deg, thr=100)" % (W, H),
-                       "frames_per_gpu": F, "global_frames": world * F,
-                       "parallelism": "frames sharded across %d GPU(s), no data-path collective" % world},
+            "config": {"workload": "batched %dx%d uint8 frames, Sobel3x3 -> Canny(59,119) -> HoughSHT(rho=1, theta=1deg, thr=100); %d distinct frames "
+                                   "resident per GPU as %d batches of %d, a step processes one batch, steps rotate over the batches"
+                                   % (W, H, min(NB * F, GOLDEN_FRAMES), NB, F),
+                       "frames_per_gpu": F, "resident_batches": NB, "global_frames_per_step": world * F,
+                       "parallelism": ("frames sharded across %d GPU(s), no data-path collective" % world) if not args.scatter else
+                                      ("step batch scattered from rank 0 over %s (grouped send/recv), line counts + top-%d lines all-gathered" % (args.dist_backend, TOPK))},
+            "verified": ({"frames_checked": checked, "against": "tests/golden/golden_batch.json (real CompV: edge-map MD5, edge count, line count, strength sum, line-set hash)",
+                          "mode": "two lanes in flight, asynchronous steps" if overlapped else "one lane"} if golden is not None else verify_note),
             "roofline": roofline, "roofline_canny": rc,
             # every kernel of a step, from the instrumented pass AFTER the timed steps (same process, same buffers)
             "kernels_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in sorted(breakdown.items())},
             "kernels_ms_per_step_source": "second pass of %d steps, one batch at a time on one stream, HIP events around every launch (not in the timed region)" % args.steps,
-            "edge_pixels_all_frames": n_edges,
-            "lines_frame0": int(counts[0]),
-            "lines_all_frames": (int(sum(all_counts)) if all_counts is not None else None),
+            "edge_pixels_per_batch": total_edges // NB,
+            "lines_frame0": lines_frame0,
+            "lines_per_batch": total_lines // NB,
+            "lines_last_step_all_ranks": (int(sum(all_counts)) if all_counts is not None else None),
         }
+        if world == 1 and not args.no_extras:
+            try:
+                out["host_api"] = host_api_latency(capi, local_rank if dist_on else 0, blocks[0][0].cpu().numpy())
+            except Exception as e:
+                out["host_api"] = {"error": str(e)}
+            try:
+                out["kht"] = kht_figure(capi, ctx, torch, lanes[0], blocks, W, H, F)
+            except Exception as e:
+                out["kht"] = {"error": str(e)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(W, H)
@@ -358,6 +582,24 @@ def main():
     ctx.close()
     if dist_on:
         dist.destroy_process_group()
+
+
+def kht_figure(capi, ctx, torch, lane, blocks, W, H, F):
+    """BASELINE config 5 as a throughput figure: the batched KHT path on the edge maps of one resident batch."""
+    if not hasattr(capi.Plan, "houghkht"):
+        return {"error": "batched KHT not built"}
+    q = lane
+    q["plan"].pipeline(blocks[0].data_ptr(), T_LOW, T_HIGH, SHT_THRESHOLD, 0, q["edges"].data_ptr(), q["lines"].data_ptr(), q["lines"].shape[1],
+                       q["counts"].data_ptr(), q["stream"].cuda_stream)
+    torch.cuda.synchronize()
+    res = q["plan"].houghkht(q["edges"].data_ptr(), 1.0, THETA_DEG, 1)          # warm-up (allocations, thread pool)
+    t0 = time.perf_counter()
+    res = q["plan"].houghkht(q["edges"].data_ptr(), 1.0, THETA_DEG, 1)
+    dt = time.perf_counter() - t0
+    stages = q["plan"].houghkht_stage_ms()
+    return {"ms_per_frame": round(dt * 1e3 / F, 3), "frames": F, "lines_frame0": int(len(res[0][0])), "host_threads": stages.get("threads"),
+            "host_share": stages.get("host_share"), "stages_ms_per_frame": stages.get("stages"),
+            "note": "compvhip_plan_houghkht on the device edge maps of one batch: one download, host linking on a thread pool pipelined with the GPU stages (subdivision, statistics, voting, peaks) of the previous frames"}
 
 
 if __name__ == "__main__":

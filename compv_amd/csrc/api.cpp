@@ -77,10 +77,9 @@ struct compvhip_plan {
 	bool countersFresh = false; // the step's memset already zeroed the edge/line counts (no second fill in front of the SHT stage)
 	int2* thrDev = nullptr; unsigned int* sums = nullptr;
 	uint8_t* dirty = nullptr;  // per-workgroup change flags of the resolve rounds
-	uint8_t* patchOut = nullptr; uint8_t* copyBack = nullptr; // byte map the resolve rounds patch (or null: masks only) / in-place target of the last Canny call
-	uint8_t* tmpOut = nullptr; // aliasing (in == out) scratch of the first-generation tile kernel (kernel size 5), which writes bytes itself
-	hipStream_t side = nullptr; hipEvent_t evFork = nullptr, evJoin = nullptr; // side stream of the pipeline: edge-byte expansion next to the Hough stage
-	bool joinPending = false;
+	uint8_t* patchOut = nullptr; uint8_t* copyBack = nullptr; // byte map the tile kernel writes and the resolve rounds patch / in-place target of the last Canny call
+	uint8_t* tmpOut = nullptr; // aliasing (in == out) scratch: a tile may still read the row halo a neighbour has overwritten
+	int cannyImpl = 0;         // kernel size 3: 0 = SWAR + candidate-list tile kernel, 1 = register-ring kernel (COMPVHIP_CANNY_IMPL=ring at plan creation)
 	bool bitsValid = false;
 	// sht
 	bool shtReady = false;
@@ -88,15 +87,14 @@ struct compvhip_plan {
 	uint8_t* blurTmp = nullptr;                       // u8 intermediate of the fixed-point convolution
 	uint32_t* hist = nullptr; int32_t* otsu = nullptr; // pre-processing scratch: partial histograms, [frames] Otsu level
 	float* cosT = nullptr; float* invSinT = nullptr; // toCartesian tables: cosf(theta_col), 1/sinf(theta_col)
-	int32_t* sinQ = nullptr; int32_t* cosQ = nullptr; int32_t* groupOrder = nullptr; int thetaPerGroup = 4;
+	int32_t* sinQ = nullptr; int32_t* cosQ = nullptr;
 	uint32_t* edges = nullptr; size_t edgeCap = 0; int* edgeCounts = nullptr;
 	uint16_t* acc = nullptr; size_t accFrameStride = 0;
 	uint64_t* keysA = nullptr; uint64_t* keysB = nullptr; size_t lineCap = 0; int* lineCounts = nullptr;
 	void* sortTemp = nullptr; size_t sortTempBytes = 0;
 	int cellBits = 0, strengthBits = 16, keyBits = 0;
-	int shards = 1;
-	// second-generation voting: image tiles (planned at plan creation: the per-tile edge counters live in `counters`)
-	bool voteTiles = true;                       // COMPVHIP_SHT_VOTE=legacy selects the first-generation kernels
+	// voting over image tiles (planned at plan creation: the per-tile edge counters live in `counters`)
+	bool voteTiles = false;                      // the tile grid exists
 	ShtTileArgs vt = {};                         // geometry + device tables
 	std::vector<int32_t> vtKt, vtRowBase;        // host copies of the [tiles][T] tables
 	int32_t* dKt = nullptr; int32_t* dRowBase = nullptr; uint16_t* partial = nullptr; int* tileCounts = nullptr;
@@ -209,7 +207,7 @@ bool planVoteTiles(size_t W, size_t H, const std::vector<int32_t>& sinQ, const s
 {
 	const size_t T = sinQ.size();
 	const long long barrier = static_cast<long long>(W + H);
-	for (int split = 0; split < 64; ++split) {
+	for (int split = 0; split < 512; ++split) {
 		// try grids in order of tile count: split the dimension with the longer tile side
 		int nx = 1, ny = 1;
 		for (int k = 0; k < split; ++k) {
@@ -309,16 +307,13 @@ int ensureSht(compvhip_plan* p)
 	if (p->shtReady) return COMPVHIP_OK;
 	compvhip_ctx* ctx = p->ctx;
 	// a previous attempt may have failed half way (out of memory): start from a clean slate instead of leaking its buffers
-	dfree(ctx, p->sinQ); dfree(ctx, p->cosQ); dfree(ctx, p->cosT); dfree(ctx, p->invSinT); dfree(ctx, p->groupOrder);
+	dfree(ctx, p->sinQ); dfree(ctx, p->cosQ); dfree(ctx, p->cosT); dfree(ctx, p->invSinT);
 	dfree(ctx, p->edges); dfree(ctx, p->acc);
 	size_t R, T; float step;
 	int rc = shtDims(p->W, p->H, p->thetaDeg, &R, &T, &step);
 	if (rc) return fail(ctx, rc, "invalid SHT geometry");
 	if (T < 5) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "theta step too large (fewer than 5 theta bins)");
-	if (!p->voteTiles) {
-		if (p->W + p->H >= 65536) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "W+H must be < 65536 (u16 LDS vote counters)");
-		if (sht_vote_lds_bytes(static_cast<int>(R), 2) > 160 * 1024) return fail(ctx, COMPVHIP_E_NOT_IMPLEMENTED, "rho range does not fit the LDS histogram");
-	}
+	if (!p->voteTiles) return fail(ctx, COMPVHIP_E_NOT_IMPLEMENTED, "no tile grid fits the vote windows of this geometry");
 	p->R = R; p->T = T; p->thetaStep = step;
 	p->accPitch = static_cast<int>(alignUp(R, 64));
 	p->accFrameStride = static_cast<size_t>(p->accPitch) * T;
@@ -343,30 +338,6 @@ int ensureSht(compvhip_plan* p)
 		HIPCHK(ctx, hipMemcpy(p->invSinT, ist.data(), T * sizeof(float), hipMemcpyHostToDevice));
 	}
 	{
-		// theta bins per vote workgroup: 2 (two 16-wave workgroups per CU; measured 0.53 ms vs 0.60 ms per 32 4K frames), 4 via the tuning knob
-		const char* e = getenv("COMPVHIP_SHT_THETA_PER_GROUP");
-		p->thetaPerGroup = ((e && atoi(e) == 4) && sht_vote_lds_bytes(static_cast<int>(R), 4) <= 160 * 1024) ? 4 : 2;
-		// Launch order of the theta groups: the bins next to 90 deg (then 0/180 deg) collect the votes of the horizontal (vertical)
-		// structures of man-made scenes in a handful of rho cells, and same-address LDS atomics serialise (2 clk per lane on gfx950),
-		// so those workgroups run longest: dispatch them first instead of leaving them for the tail of the launch.
-		const int tg = p->thetaPerGroup, groups = static_cast<int>((T + tg - 1) / tg);
-		std::vector<int32_t> order(groups);
-		for (int g = 0; g < groups; ++g) order[g] = g;
-		auto axisDist = [&](int g) { // distance (in bins) of the group's nearest bin to 0, T/2 or T
-			double best = 1e30;
-			for (int k = 0; k < tg; ++k) {
-				const double t = g * tg + k;
-				const double d = std::min(std::min(std::fabs(t), std::fabs(t - 0.5 * T)), std::fabs(t - 1.0 * T));
-				best = std::min(best, d);
-			}
-			return best;
-		};
-		std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return axisDist(a) < axisDist(b); });
-		HIPCHK(ctx, dmalloc(ctx, &p->groupOrder, static_cast<size_t>(groups)));
-		HIPCHK(ctx, hipMemcpy(p->groupOrder, order.data(), groups * sizeof(int32_t), hipMemcpyHostToDevice));
-	}
-	p->edgeCap = p->W * p->H;
-	if (p->voteTiles) {
 		if (p->vt.tiles <= 0 || p->vtKt.size() != static_cast<size_t>(p->vt.tiles) * T) return fail(ctx, COMPVHIP_E_INVALID_STATE, "vote tiles were not planned");
 		dfree(ctx, p->dKt); dfree(ctx, p->dRowBase); dfree(ctx, p->partial);
 		HIPCHK(ctx, dmalloc(ctx, &p->dKt, p->vtKt.size()));
@@ -427,10 +398,8 @@ ShtArgs shtArgs(compvhip_plan* p, int threshold)
 	a.R = static_cast<int>(p->R); a.T = static_cast<int>(p->T); a.accPitch = p->accPitch; a.barrier = static_cast<int>(p->W + p->H);
 	a.threshold = threshold;
 	a.nmsLastCol = static_cast<int>((p->T - 1) & ~static_cast<size_t>(3)); // quirk Q2: NMS covers theta columns [1, (T-1)&~3]
-	a.shards = p->shards;
 	a.frames = static_cast<int>(p->frames);
 	a.cellBits = p->cellBits; a.strengthBits = p->strengthBits;
-	a.thetaPerGroup = p->thetaPerGroup; a.groupOrder = p->groupOrder;
 	return a;
 }
 
@@ -451,7 +420,7 @@ int enqueueCanny(compvhip_plan* p, const uint8_t* d_in, uint8_t* d_out, int tLow
 	a.in = d_in; a.out = d_out; a.ebits = p->ebits; a.ubits = p->ubits; a.thrDev = (thrMode != COMPVHIP_CANNY_THRESHOLD_COMPARE_TO_GRADIENT) ? p->thrDev : nullptr;
 	a.inFrameStride = p->S * p->H; a.outFrameStride = p->S * p->H; a.bitsFrameStride = p->bitsFrameStride;
 	a.W = static_cast<int>(p->W); a.H = static_cast<int>(p->H); a.S = static_cast<int>(p->S); a.So = static_cast<int>(p->S);
-	a.wb = p->wb; a.tilesX = p->tilesX; a.tilesY = p->tilesY; a.tLow = tLow; a.tHigh = tHigh; a.ksize = ksize;
+	a.wb = p->wb; a.tilesX = p->tilesX; a.tilesY = p->tilesY; a.tLow = tLow; a.tHigh = tHigh; a.ksize = ksize; a.impl = p->cannyImpl;
 	cannyCoverage(p->W, &a.simdEnd, &a.cStart);
 	// coverage [1,simdEnd) U [cStart,W-1) equals the whole interior unless the two pieces leave a hole (W = 1 mod 16 ...)
 	const bool gap = !((a.simdEnd >= a.W - 1) || (a.cStart <= a.simdEnd));
@@ -476,7 +445,7 @@ int enqueueCanny(compvhip_plan* p, const uint8_t* d_in, uint8_t* d_out, int tLow
 	return COMPVHIP_OK;
 }
 
-// d_out: the byte map to patch with the promoted pixels, or nullptr when the bytes are rebuilt from the final E masks (enqueueExpand)
+// d_out: the byte map to patch with the promoted pixels
 int enqueueResolve(compvhip_plan* p, uint8_t* d_out, int rounds, hipStream_t st)
 {
 	compvhip_ctx* ctx = p->ctx;
@@ -497,39 +466,6 @@ int enqueueResolve(compvhip_plan* p, uint8_t* d_out, int rounds, hipStream_t st)
 		Stamp s(p, st, "canny_resolve_kernel");
 		HIPCHK(ctx, launch_canny_resolve(r, static_cast<int>(p->frames), st));
 	}
-	return COMPVHIP_OK;
-}
-
-// Edge bytes from the final E masks.  side == false: on `st`.  side == true (the pipeline): on the plan's side stream, forked
-// behind everything enqueued on `st` so far; joinSide() makes `st` wait for it again.
-int enqueueExpand(compvhip_plan* p, uint8_t* d_edges, hipStream_t st, bool side)
-{
-	compvhip_ctx* ctx = p->ctx;
-	hipStream_t es = st;
-	if (side) {
-		if (!p->side) {
-			HIPCHK(ctx, hipStreamCreateWithFlags(&p->side, hipStreamNonBlocking));
-			HIPCHK(ctx, hipEventCreateWithFlags(&p->evFork, hipEventDisableTiming));
-			HIPCHK(ctx, hipEventCreateWithFlags(&p->evJoin, hipEventDisableTiming));
-		}
-		HIPCHK(ctx, hipEventRecord(p->evFork, st));
-		HIPCHK(ctx, hipStreamWaitEvent(p->side, p->evFork, 0));
-		es = p->side;
-	}
-	{
-		Stamp s(p, es, "canny_expand_kernel");
-		HIPCHK(ctx, launch_canny_expand(p->ebits, p->wb, p->bitsFrameStride, static_cast<int>(p->H), static_cast<int>(p->S), d_edges, p->S * p->H,
-		                                static_cast<int>(p->frames), es));
-	}
-	if (side) { HIPCHK(ctx, hipEventRecord(p->evJoin, p->side)); p->joinPending = true; }
-	return COMPVHIP_OK;
-}
-
-int joinSide(compvhip_plan* p, hipStream_t st)
-{
-	if (!p->joinPending) return COMPVHIP_OK;
-	p->joinPending = false;
-	HIPCHK(p->ctx, hipStreamWaitEvent(st, p->evJoin, 0));
 	return COMPVHIP_OK;
 }
 
@@ -673,8 +609,9 @@ int compvhip_plan_create(compvhip_ctx* ctx, size_t W, size_t H, size_t S, size_t
 		// the fills run on the null stream; the plan's kernels may be enqueued on non-blocking streams that do not wait for it
 		if (hipDeviceSynchronize() != hipSuccess) { rc = COMPVHIP_E_HIP; break; }
 		{
-			static const bool legacy = [] { const char* e = getenv("COMPVHIP_SHT_VOTE"); return e && !strcmp(e, "legacy"); }();
-			p->voteTiles = !legacy;
+			// tuning / A-B knobs are read at EVERY plan creation (a process-wide static would freeze the first plan's choice)
+			p->voteTiles = true;
+			{ const char* e = getenv("COMPVHIP_CANNY_IMPL"); p->cannyImpl = (e && !strcmp(e, "ring")) ? 1 : 0; }
 			size_t R = 0, T = 0; float step = 0.f;
 			if (p->voteTiles && shtDims(W, H, thetaDeg, &R, &T, &step) == COMPVHIP_OK && T >= 5) {
 				std::vector<int32_t> sq, cq;
@@ -706,16 +643,13 @@ void compvhip_plan_destroy(compvhip_plan* p)
 	timelineClear(p);
 	for (hipEvent_t e : p->eventPool) (void)hipEventDestroy(e);
 	for (auto& stp : p->steps) if (stp.done) (void)hipEventDestroy(stp.done);
-	if (p->evFork) (void)hipEventDestroy(p->evFork);
-	if (p->evJoin) (void)hipEventDestroy(p->evJoin);
-	if (p->side) (void)hipStreamDestroy(p->side);
 	dfree(ctx, p->dirty);
 	dfree(ctx, p->ebits); dfree(ctx, p->ubits); dfree(ctx, p->counters); dfree(ctx, p->thrDev); dfree(ctx, p->sums); dfree(ctx, p->tmpOut);
 	if (p->hFlags) (void)hipHostFree(p->hFlags);
 	dfree(ctx, p->hist); dfree(ctx, p->otsu); dfree(ctx, p->blurTmp);
 	dfree(ctx, p->cosT); dfree(ctx, p->invSinT);
 	dfree(ctx, p->dKt); dfree(ctx, p->dRowBase); dfree(ctx, p->partial);
-	dfree(ctx, p->sinQ); dfree(ctx, p->cosQ); dfree(ctx, p->groupOrder); dfree(ctx, p->edges); dfree(ctx, p->acc);
+	dfree(ctx, p->sinQ); dfree(ctx, p->cosQ); dfree(ctx, p->edges); dfree(ctx, p->acc);
 	dfree(ctx, p->keysA); dfree(ctx, p->keysB);
 	dfree(ctx, p->sortTemp);
 	delete p;
@@ -733,7 +667,7 @@ int compvhip_plan_get_timing(compvhip_plan* p, const char** names, float* ms, in
 	if (!p) return COMPVHIP_E_INVALID_PARAMETER;
 	(void)hipSetDevice(p->ctx->device);
 	if (!p->timeline.empty()) {
-		for (auto& t : p->timeline) (void)hipEventSynchronize(t.b); // main and side stream events
+		for (auto& t : p->timeline) (void)hipEventSynchronize(t.b);
 		timelineCollect(p);
 	}
 	const int n = std::min<int>(cap, static_cast<int>(p->timingMs.size()));
@@ -741,13 +675,11 @@ int compvhip_plan_get_timing(compvhip_plan* p, const char** names, float* ms, in
 	return n;
 }
 
-// Two ways to the edge bytes (launch_canny_tiles picks the tile kernel):
-//  * the tile kernel writes them and the resolve rounds patch the promoted pixels (p->patchOut = that byte map; when in and out
-//    alias it is a scratch copy: a tile may still read the row halo a neighbour has overwritten);
-//  * the tile kernel writes masks only and canny_expand_kernel rebuilds the bytes from the final E masks (p->patchOut = nullptr).
-//    expand: 0 = the caller enqueues that expansion itself (pipeline: on the side stream), 1 = here, on `st`.
+// The tile kernel writes E (edges so far), U (weak, unresolved) and the bytes of E; the resolve rounds finish the hysteresis on the
+// masks and patch the promoted pixels into the byte map (p->patchOut; when in and out alias it is a scratch copy: a tile may still
+// read the row halo a neighbour has overwritten).
 static int planCannyImpl(compvhip_plan* p, const uint8_t* d_in, float tLow, float tHigh, int ksize, int type, uint8_t* d_edges, hipStream_t st,
-                         bool waitConverged, bool clearTimeline = true, int expand = 1)
+                         bool waitConverged, bool clearTimeline = true)
 {
 	compvhip_ctx* ctx = p->ctx;
 	if (!d_in || !d_edges) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "null frame pointer");
@@ -756,16 +688,15 @@ static int planCannyImpl(compvhip_plan* p, const uint8_t* d_in, float tLow, floa
 	if (rc) return rc;
 	HIPCHK(ctx, hipSetDevice(ctx->device));
 	if (p->timing && clearTimeline) timelineClear(p);
-	const bool tileBytes = canny_tiles_write_bytes(ksize);
 	uint8_t* out = d_edges;
 	const size_t bytes = p->S * p->H * p->frames;
 	const bool alias = (d_in < d_edges + bytes) && (d_edges < d_in + bytes);
-	if (alias && tileBytes) {
+	if (alias) {
 		if (!p->tmpOut) HIPCHK(ctx, dmalloc(ctx, &p->tmpOut, bytes));
 		out = p->tmpOut;
 	}
-	p->patchOut = tileBytes ? out : nullptr;
-	p->copyBack = (alias && tileBytes) ? d_edges : nullptr;
+	p->patchOut = out;
+	p->copyBack = alias ? d_edges : nullptr;
 	if (p->W < static_cast<size_t>(ksize) || p->H < static_cast<size_t>(ksize)) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "image smaller than the kernel"); // compv_math_convlt.h:100
 	rc = enqueueCanny(p, d_in, out, lo, hi, ksize, type, tLow, tHigh, st);
 	if (rc) return rc;
@@ -781,8 +712,7 @@ static int planCannyImpl(compvhip_plan* p, const uint8_t* d_in, float tLow, floa
 			if (rc) return rc;
 		}
 	}
-	if (tileBytes) { if (p->copyBack) HIPCHK(ctx, hipMemcpyAsync(p->copyBack, out, bytes, hipMemcpyDeviceToDevice, st)); }
-	else if (expand == 1) { rc = enqueueExpand(p, d_edges, st, false); if (rc) return rc; }
+	if (p->copyBack) HIPCHK(ctx, hipMemcpyAsync(p->copyBack, out, bytes, hipMemcpyDeviceToDevice, st));
 	p->bitsValid = true;
 	return COMPVHIP_OK;
 }
@@ -882,10 +812,8 @@ int compvhip_plan_edge_dete(compvhip_plan* p, const uint8_t* d_in, int op, uint8
 	return COMPVHIP_OK;
 }
 
-// expandTo != NULL (the pipeline): the edge bytes are expanded from the E masks on the side stream, forked behind the vote launch so
-// that the 1 B/px of stores overlaps the small kernels of the line stage (NMS, radix sort passes, decode) instead of the LDS-bound vote.
 static int planShtImpl(compvhip_plan* p, const uint8_t* d_edges, int threshold, int maxLines, compvhip_line* d_lines, size_t lineCap, int32_t* d_counts,
-                       hipStream_t st, bool clearTimeline, uint8_t* expandTo = nullptr)
+                       hipStream_t st, bool clearTimeline)
 {
 	compvhip_ctx* ctx = p->ctx;
 	if (threshold <= 0) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "threshold must be > 0"); // houghsht.cxx:82
@@ -906,16 +834,9 @@ static int planShtImpl(compvhip_plan* p, const uint8_t* d_edges, int threshold, 
 	ShtArgs a = shtArgs(p, threshold);
 	if (!p->countersFresh) HIPCHK(ctx, hipMemsetAsync(p->counters, 0, sizeof(int) * p->nCounts, st)); // edge, line and tile counts
 	p->countersFresh = false;
-	if (p->voteTiles) {
-		{ Stamp s(p, st, "sht_compact_kernel"); HIPCHK(ctx, launch_sht_compact_tiles(a, p->vt, frames, st)); }
-		{ Stamp s(p, st, "sht_vote_kernel"); HIPCHK(ctx, launch_sht_vote_tiles(a, p->vt, frames, st)); }
-		{ Stamp s(p, st, "sht_reduce_kernel"); HIPCHK(ctx, launch_sht_reduce_tiles(a, p->vt, frames, st)); }
-	}
-	else {
-		{ Stamp s(p, st, "sht_compact_kernel"); HIPCHK(ctx, launch_sht_compact(a, frames, st)); }
-		{ Stamp s(p, st, "sht_vote_kernel"); HIPCHK(ctx, launch_sht_vote(a, frames, st)); }
-	}
-	if (expandTo) { rc = enqueueExpand(p, expandTo, st, true); if (rc) return rc; }
+	{ Stamp s(p, st, "sht_compact_kernel"); HIPCHK(ctx, launch_sht_compact_tiles(a, p->vt, frames, st)); }
+	{ Stamp s(p, st, "sht_vote_kernel"); HIPCHK(ctx, launch_sht_vote_tiles(a, p->vt, frames, st)); }
+	{ Stamp s(p, st, "sht_reduce_kernel"); HIPCHK(ctx, launch_sht_reduce_tiles(a, p->vt, frames, st)); }
 	{ Stamp s(p, st, "sht_nms_kernel"); HIPCHK(ctx, launch_sht_nms(a, frames, st)); }
 	{
 		Stamp s(p, st, "sht_sort_lines");
@@ -944,17 +865,13 @@ int compvhip_plan_pipeline(compvhip_plan* p, const uint8_t* d_in, float tLow, fl
 {
 	if (!p) return COMPVHIP_E_INVALID_PARAMETER;
 	hipStream_t st = static_cast<hipStream_t>(stream);
-	// Everything is enqueued back to back (speculative resolve rounds included); the edge bytes are expanded from the E masks on a
-	// side stream while the Hough stage runs; the convergence flag is checked once at the end and, in the rare case the hysteresis
-	// needed more rounds, the tail is replayed.
-	int rc = planCannyImpl(p, d_in, tLow, tHigh, 3, COMPVHIP_CANNY_THRESHOLD_COMPARE_TO_GRADIENT, d_edges, st, false, true, 0);
+	// Everything is enqueued back to back (speculative resolve rounds included); the convergence flag is checked once at the end and,
+	// in the rare case the hysteresis needed more rounds, the tail is replayed.
+	int rc = planCannyImpl(p, d_in, tLow, tHigh, 3, COMPVHIP_CANNY_THRESHOLD_COMPARE_TO_GRADIENT, d_edges, st, false, true);
 	if (rc) return rc;
-	uint8_t* const expandTo = p->patchOut ? nullptr : d_edges; // masks-only tile kernel: the bytes are expanded next to the line stage
 	const size_t bytes = p->S * p->H * p->frames;
 	for (;;) {
-		rc = planShtImpl(p, nullptr, threshold, maxLines, d_lines, lineCap, d_counts, st, false, expandTo);
-		if (rc) return rc;
-		rc = joinSide(p, st);
+		rc = planShtImpl(p, nullptr, threshold, maxLines, d_lines, lineCap, d_counts, st, false);
 		if (rc) return rc;
 		bool done = false;
 		rc = resolveConverged(p, st, &done);
@@ -967,7 +884,7 @@ int compvhip_plan_pipeline(compvhip_plan* p, const uint8_t* d_in, float tLow, fl
 			if (rc) return rc;
 		} while (!done);
 		if (p->copyBack) HIPCHK(p->ctx, hipMemcpyAsync(p->copyBack, p->patchOut, bytes, hipMemcpyDeviceToDevice, st));
-		// replay of the Hough stage on the now final masks (a masks-only byte map is expanded again next to it)
+		// replay of the Hough stage on the now final masks
 	}
 	return COMPVHIP_OK;
 }
@@ -991,11 +908,9 @@ int compvhip_plan_pipeline_async(compvhip_plan* p, const uint8_t* d_in, float tL
 	HIPCHK(ctx, hipSetDevice(ctx->device));
 	if (!stp.done) HIPCHK(ctx, hipEventCreateWithFlags(&stp.done, hipEventDisableTiming));
 	// timing events of asynchronous steps accumulate until compvhip_plan_get_timing reads them (nothing is cleared per step)
-	int rc = planCannyImpl(p, d_in, tLow, tHigh, 3, COMPVHIP_CANNY_THRESHOLD_COMPARE_TO_GRADIENT, d_edges, st, false, false, 0);
+	int rc = planCannyImpl(p, d_in, tLow, tHigh, 3, COMPVHIP_CANNY_THRESHOLD_COMPARE_TO_GRADIENT, d_edges, st, false, false);
 	if (rc) return rc;
-	rc = planShtImpl(p, nullptr, threshold, maxLines, d_lines, lineCap, d_counts, st, false, p->patchOut ? nullptr : d_edges); // masks-only: bytes on the side stream
-	if (rc) return rc;
-	rc = joinSide(p, st);
+	rc = planShtImpl(p, nullptr, threshold, maxLines, d_lines, lineCap, d_counts, st, false);
 	if (rc) return rc;
 	HIPCHK(ctx, hipMemcpyAsync(p->hFlags + 1 + slot, p->flags + (p->roundsUsed - 1), sizeof(int), hipMemcpyDeviceToHost, st));
 	HIPCHK(ctx, hipEventRecord(stp.done, st));

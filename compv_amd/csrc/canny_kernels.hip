@@ -433,37 +433,6 @@ __global__ __launch_bounds__(kResolveThreads) void canny_resolve_kernel(ResolveA
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Edge bytes from the final E mask: out[y][x] = bit x of E row y ? 0xff : 0, for x < So (bits past W are zero).  One thread = 16
-// pixels (one half-word of mask, one 16-byte store); a wave writes 1 KB of a row.  Pure streaming: 1/8 B/px read, 1 B/px written.
-// ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void canny_expand_kernel(const uint32_t* __restrict__ ebits, int wb, size_t bitsFrameStride, int H, int So,
-                                                           uint8_t* __restrict__ out, size_t outFrameStride)
-{
-	const int frame = blockIdx.z;
-	const int y = blockIdx.y;
-	const int g = blockIdx.x * blockDim.x + threadIdx.x; // group of 16 columns
-	const int x = g * 16;
-	if (x >= So) return;
-	const uint16_t* __restrict__ mrow = reinterpret_cast<const uint16_t*>(ebits + (size_t)frame * bitsFrameStride + (size_t)y * wb);
-	const uint32_t m = (g < wb * 2) ? mrow[g] : 0u;
-	uint32_t w[4];
-#pragma unroll
-	for (int q = 0; q < 4; ++q) w[q] = (__umul24((m >> (4 * q)) & 0xfu, 0x00204081u) & 0x01010101u) * 0xffu; // nibble -> 4 bytes
-	uint8_t* __restrict__ o = out + (size_t)frame * outFrameStride + (size_t)y * So + x;
-	if (x + 16 <= So) *reinterpret_cast<uint4*>(o) = make_uint4(w[0], w[1], w[2], w[3]);
-	else *reinterpret_cast<uint2*>(o) = make_uint2(w[0], w[1]); // So % 8 == 0: an 8-column tail
-}
-
-hipError_t launch_canny_expand(const uint32_t* ebits, int wb, size_t bitsFrameStride, int H, int So, uint8_t* out, size_t outFrameStride, int frames,
-                               hipStream_t stream)
-{
-	const int groups = (So + 15) / 16;
-	dim3 grid((groups + 255) / 256, H, frames);
-	hipLaunchKernelGGL(canny_expand_kernel, grid, dim3(256), 0, stream, ebits, wb, bitsFrameStride, H, So, out, outFrameStride);
-	return hipGetLastError();
-}
-
-// ---------------------------------------------------------------------------------------------------------------
 // PERCENT_OF_MEAN thresholds: sum of pixels per frame (CompVMathUtils::sum<u8,u32>, canny_dete.cxx:243), then
 // mean/thresholds exactly as :252-266.
 // ---------------------------------------------------------------------------------------------------------------
@@ -503,20 +472,12 @@ __global__ void mean_thresholds_kernel(const unsigned int* __restrict__ sums, in
 // ---------------------------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------------------------
-// Two tile kernels exist for kernel size 3: this file's register-ring kernel (dense NMS, writes the edge bytes itself) and the SWAR +
-// candidate-list kernel of canny_swar_kernels.hip (masks only; the bytes come from canny_expand_kernel).  Measured end to end on the
-// 32 x 4K benchmark step the ring kernel is still the faster pipeline, so it is the default;
-// COMPVHIP_CANNY_IMPL=swar selects the other one.  Kernel size 5 always runs here.
-static bool use_ring_kernel(int ksize)
-{
-	static const bool swar = [] { const char* e = getenv("COMPVHIP_CANNY_IMPL"); return e && !strcmp(e, "swar"); }();
-	return ksize == 5 || !swar;
-}
-bool canny_tiles_write_bytes(int ksize) { return use_ring_kernel(ksize); }
-
+// Kernel size 3 runs the SWAR + candidate-list kernel of canny_swar_kernels.hip; this file's register-ring kernel serves kernel size 5
+// (and, through CannyArgs::impl = 1, kernel size 3 as the measured alternative: compvhip_plan_create reads COMPVHIP_CANNY_IMPL=ring).
+// Both write E (edges so far), U (weak, unresolved) and the edge bytes of E; canny_resolve_kernel finishes the hysteresis.
 hipError_t launch_canny_tiles(const CannyArgs& a0, int frames, bool gap, hipStream_t stream)
 {
-	if (!use_ring_kernel(a0.ksize)) return launch_canny_tiles_swar(a0, frames, gap, stream);
+	if (a0.ksize == 3 && a0.impl == 0) return launch_canny_tiles_swar(a0, frames, gap, stream);
 	CannyArgs a = a0;
 	a.blockRows = (a.tilesY + kCannyWaves - 1) / kCannyWaves;
 	a.groups = a.blockRows * frames;

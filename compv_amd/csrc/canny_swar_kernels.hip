@@ -1,29 +1,32 @@
-// canny_swar_kernels.hip -- fused Sobel 3x3 -> NMS -> tile hysteresis for gfx950, second generation.
+// canny_swar_kernels.hip -- fused Sobel 3x3 -> NMS -> weak / strong classification for gfx950 (the kernel-size-3 Canny tile kernel).
 //
 // Replaces (behind compvhip_canny_u8 / compvhip_plan_canny / compvhip_plan_pipeline, kernel size 3):
 //   CompVEdgeDeteCanny::process            core/features/edges/compv_core_feature_canny_dete.cxx:123-331
-//   nms_gather / nms_apply / hysteresis    ...canny_dete.cxx:334-528, row leaves :566-680,
+//   nms_gather / nms_apply                 ...canny_dete.cxx:334-462, row leaves :566-616,
 //   CompVCannyNMSGatherRow_16mpw_Intrin_AVX2  core/features/edges/intrin/x86/compv_core_feature_canny_dete_intrin_avx2.cxx:150-235
+// (the hysteresis, :464-528, is canny_resolve_kernel's: this kernel hands it the seeds E = strong and the candidates U = weak & ~strong)
 //
-// What changed against canny_tile_kernel (canny_kernels.hip, still used for the 5x5 gradient): that kernel runs the direction
-// class + four neighbour maxima of the NMS on every pixel and is bound by VALU issue (213 VALU per 512-px row, mostly
-// opcodes that issue at half rate on gfx950: tools/microbench/valu_rate_bench2/3).  Here
-//   * the dense stage only produces the gradient magnitude, two pixels per 32-bit register (SWAR on u16 halves): sums and
-//     differences of 8-bit pixels never carry across the halves once the signed terms are biased (d + 256, gx + 1024,
-//     gy + 1024), so plain v_add_u32 / v_sub_u32 / v_or_b32 -- the full-rate opcodes -- do packed arithmetic; |.| is one
-//     v_pk_max_u16 of (v, 2*bias - v);
-//   * the rows of g (u16, pixel order) go through a 3-row LDS ring; pixels with g > tLow (~10 % on the benchmark frames)
-//     are compacted into a per-row candidate list (wave prefix sum by DPP), and the NMS rule of the reference -- direction
-//     class from |gx|,|gy| with the Q16 constants 27145 / 158217, compare with the two neighbours along the gradient -- is
-//     evaluated one candidate per lane, reading its two neighbours from the ring;
-//   * results are OR-ed into 512-bit row masks (weak / strong) in LDS, collected into the registers of the lane that owns the
-//     row every 8 rows, and the strong -> weak flood inside the tile is the lane == row carry-chain flood of the first kernel.
-// A wave owns 240 output columns x 64 rows, 4 pixels per lane: lanes 0, 1 and 62, 63 compute the gradient of the 8 columns either
+// The kernel is bound by VALU issue, not by HBM (tools/microbench/valu_rate_bench2/3: ~2.3 cycles per wave64
+// instruction for v_add/sub/and/or/xor/lshr with VGPR or literal operands, ~4.3 for everything else), so its structure follows the
+// instruction count:
+//   * dense stage: gradient magnitude of every pixel, two pixels per 32-bit register (SWAR on u16 halves).  Sums and differences of
+//     8-bit pixels never carry across the halves once the signed terms are biased (d + 256, gx + 1024, gy + 1024), so plain
+//     v_add_u32 / v_sub_u32 / v_or_b32 do packed arithmetic; |.| is one v_pk_max_u16 of (v, 2*bias - v).  g' = g + 2048 (u16) and an
+//     aux word (|gx|, sign(gx ^ gy)) of every pixel go to small LDS rings in pixel order;
+//   * sparse stage: only pixels with g > tLow (~10 % on the benchmark frames) can survive the NMS.  They are compacted into a
+//     candidate list (one v_cmp = one ballot per pixel slot, mbcnt ranks) that collects TWO rows before it is processed, so that the
+//     64 lanes of the NMS pass are ~80 % occupied (a one-row list filled 24 of 64 lanes: round 2's measurement); one candidate per lane
+//     evaluates the reference's direction class (Q16 constants 27145 / 158217) and compares with the two neighbours along the
+//     gradient, read from the ring;
+//   * results are OR-ed into 256-bit row masks (weak / strong) in LDS; every 4 rows the masks leave in their final global layout
+//     (E = strong, U = weak & ~strong) together with the edge BYTES of the strong pixels (16-byte stores).  There is no in-tile flood
+//     any more: the 512-bit carry-chain flood of the first two generations cost 20 % of the kernel in lock step on every tile, the
+//     band kernel does the same work on packed words, only where there is something to do (canny_kernels.hip, canny_resolve_kernel).
+// A wave owns 240 output columns x kSwRows rows, 4 pixels per lane: lanes 0, 1 and 62, 63 compute the gradient of the 8 columns either
 // side of the tile (the NMS of columns 0 and 239 needs one of them; two lanes per side keep the tile's bit masks half-word aligned:
-// 240 = 15 half-words) but own no pixels, so no gradient column is computed twice inside a wave.  Every input byte is still fetched
-// once per tile (+ 4/64 row halo, + 16/240 column halo).  Why 4 pixels per lane and not 8: a gfx950 wave issues one instruction
-// every ~8.7 cycles whatever its type (valu_rate_bench2, one wave per SIMD), so throughput = resident waves / 8.7 until a pipe
-// saturates; 4 pixels per lane halve the registers and the LDS of a wave (<= 64 VGPRs, 3.4 KB) and put 8 waves on every SIMD.
+// 240 = 15 half-words) but own no pixels.  Every input byte is fetched once per tile (+ 4/64 row halo, + 16/240 column halo).
+// 4 pixels per lane: <= 64 VGPRs and 4.6 KB of LDS per wave put 8 waves on every SIMD (one wave issues an instruction only every
+// ~8.7 cycles whatever its type, so the issue rate of a SIMD is resident waves / 8.7 until a pipe saturates).
 #include "stencil.hpp"
 #include "kernels.hpp"
 
@@ -36,15 +39,15 @@ namespace {
 
 constexpr int kSwPx = 4;                     // pixels per lane
 constexpr int kSwCols = 240;                 // output columns per wave tile (lanes 2..61)
-constexpr int kSwRowBytes = 512;             // one ring row: 256 u16 in pixel order
-constexpr int kSwG = 0;                      // byte offsets inside a wave's LDS block
-constexpr int kSwAux = kSwG + 3 * kSwRowBytes;
-constexpr int kSwList = kSwAux + 2 * kSwRowBytes;
-constexpr int kSwMask = kSwList + 512;       // mask ring: [4 rows][weak | strong][11 dwords]: [0] = 0, [1..8] = 256 bits, [9] = 0, [10] unused
-constexpr int kMaskPitch = 11;
-constexpr int kSwLdsBytes = kSwMask + 4 * 2 * kMaskPitch * 4;   // 3424 B per wave
-constexpr int kImgPitch = 9;                 // lane == row image of one 256-bit mask (tail of the kernel; reuses the ring space)
-static_assert(64 * kMaskPitch * 4 <= kSwLdsBytes, "padded mask image must fit the wave's LDS block");
+constexpr int kSwRows = 64;                  // output rows per wave tile
+constexpr int kRowB = 512;                   // one ring row: 256 u16 in pixel order
+// LDS of one wave (byte offsets; the g ring is 2048-aligned so that "row above / below" wraps with one AND):
+// [0, 2048): g' ring, 4 rows: row r lives in slot r & 3
+constexpr int kAux = 4 * kRowB;              // aux ring, 2 rows: row r lives in slot r & 1
+constexpr int kList = kAux + 2 * kRowB;      // candidate list of a row pair: <= 480 u16 entries
+constexpr int kMask = kList + 1024;          // mask ring, 4 rows x { weak[16 dwords], strong[16 dwords] }: dword 0 and 9 of a mask are zero pads
+constexpr int kMaskRowB = 128;
+constexpr int kLdsBytes = kMask + 4 * kMaskRowB;   // 4608 B per wave
 
 constexpr uint32_t kBiasD = 0x01000100u;     // +256 per half: horizontal difference R - L
 constexpr uint32_t kBias1k = 0x04000400u;    // +1024 per half: gx, gy
@@ -69,28 +72,38 @@ __device__ __forceinline__ uint32_t twice(uint32_t x)
 	asm("v_add_u32 %0, %1, %1" : "=v"(d) : "v"(x));
 	return d;
 }
+// nibble -> four bytes {0, 0xff}
+__device__ __forceinline__ uint32_t nibble_bytes(uint32_t nib)
+{
+	const uint32_t b = __umul24(nib, 0x00204081u) & 0x01010101u;   // bit j -> byte j
+	uint32_t hi;
+	asm("v_lshlrev_b32 %0, 8, %1" : "=v"(hi) : "v"(b));           // 255 b = (b << 8) - b (spelled out: the compiler otherwise emits a full 32-bit multiply)
+	return hi - b;
+}
 
 } // namespace
 
 // ---------------------------------------------------------------------------------------------------------------
-template <bool GAP>
-__global__ __launch_bounds__(kCannyWaves * 64, 8) void canny_swar_tile_kernel(CannyArgs a)
+template <bool GAP, int WAVES>
+__global__ __launch_bounds__(WAVES * 64, 8) void canny_swar_tile_kernel(CannyArgs a)
 {
-	__shared__ __attribute__((aligned(16))) uint8_t lds_all[kCannyWaves][kSwLdsBytes];
+	// the g rings of all waves first (2048-byte aligned), then the rest of each wave's block
+	__shared__ __attribute__((aligned(2048))) uint8_t lds_all[WAVES * kLdsBytes];
 
 	const int lane = threadIdx.x & 63;
-	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	const int wave = WAVES == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
 	int tileX, group;
 	if (!xcd_tile_map(blockIdx.x, a.tilesX, a.groups, tileX, group)) return;
 	const int frame = group / a.blockRows;
-	const int tileY = (group - frame * a.blockRows) * kCannyWaves + wave;
+	const int tileY = (group - frame * a.blockRows) * WAVES + wave;
 	if (tileY >= a.tilesY) return; // whole wave
 
-	uint8_t* const lds = &lds_all[wave][0];
+	uint8_t* const ring = lds_all + wave * (4 * kRowB);                               // g' ring
+	uint8_t* const rest = lds_all + WAVES * (4 * kRowB) + wave * (kLdsBytes - 4 * kRowB) - kAux; // rest[kAux ..] = aux, list, masks
 	const int W = a.W, H = a.H, S = a.S;
 	const int xbase = tileX * kSwCols - 8;          // column of local bit 0 (lanes 0, 1 = the left halo lanes)
 	const int x0 = xbase + lane * kSwPx;
-	const int y0 = tileY * kTileH;
+	const int y0 = tileY * kSwRows;
 	const uint8_t* __restrict__ in = a.in + (size_t)frame * a.inFrameStride;
 
 	int tLow = a.tLow, tHigh = a.tHigh;
@@ -114,7 +127,7 @@ __global__ __launch_bounds__(kCannyWaves * 64, 8) void canny_swar_tile_kernel(Ca
 	uint32_t ownv = owner ? 0xffffffffu : 0u;
 	asm volatile("" : "+v"(ownv));
 	// tiles whose gradient rows touch the image border rows (g forced to 0 there) or run past the image
-	const bool vEdgeTile = (tileY == 0) || (y0 + kTileH + 1 >= H - 1);
+	const bool vEdgeTile = (tileY == 0) || (y0 + kSwRows + 1 >= H - 1);
 	const bool borderTile = edgeTile || vEdgeTile;
 
 	// mask geometry: local bits 8..247 are global columns [240 t, 240 t + 240): the tile starts at half-word 15 t of a mask row, i.e.
@@ -124,17 +137,7 @@ __global__ __launch_bounds__(kCannyWaves * 64, 8) void canny_swar_tile_kernel(Ca
 	const int d0 = (15 * tileX) >> 1;
 	uint32_t* const ebase = a.ebits + (size_t)frame * a.bitsFrameStride;
 	uint32_t* const ubase = a.ubits + (size_t)frame * a.bitsFrameStride;
-	// one global dword (or its owned half-word) of a mask row from two adjacent LDS dwords [src], [src + 1] of a padded row image
-	auto store_dword = [&](uint32_t* __restrict__ gm, int row, int dl, uint32_t lo, uint32_t hi) {
-		const uint32_t v = odd ? __builtin_amdgcn_alignbit(hi, lo, 24) : __builtin_amdgcn_alignbit(hi, lo, 8);
-		const int gd = d0 + dl;
-		if (row < H && gd < a.wb) {
-			uint32_t* dst = gm + (size_t)row * a.wb + gd;
-			if (!odd && dl == 7) reinterpret_cast<uint16_t*>(dst)[0] = (uint16_t)v;             // low half-word: the next tile owns the high one
-			else if (odd && dl == 0) reinterpret_cast<uint16_t*>(dst)[1] = (uint16_t)(v >> 16);  // high half-word: the previous tile owns the low one
-			else *dst = v;
-		}
-	};
+	uint8_t* const obase = a.out + (size_t)frame * a.outFrameStride;
 
 	// Row loads through a buffer descriptor of the frame: the row offset rides in an SGPR (soffset), the lane's column offset is a
 	// loop-invariant VGPR -- no per-lane address arithmetic in the row loop.  Columns are clamped into the row (clamped lanes only
@@ -154,21 +157,25 @@ __global__ __launch_bounds__(kCannyWaves * 64, 8) void canny_swar_tile_kernel(Ca
 	uint32_t P[2] = { 0, 0 };              // d[y-2] + 2 d[y-1]   (bias 768)
 	uint32_t dprev[2] = { 0, 0 };          // d[y-1]              (bias 256)
 	uint32_t hy[2][2] = { { 0, 0 }, { 0, 0 } }; // horizontal smooth of rows y-1 / y-2 (ring)
-	uint32_t gprev[2] = { 0, 0 };          // g' of the previous gradient row (owner lanes only): its candidates are processed this step
 
-	uint32_t* const maskw = reinterpret_cast<uint32_t*>(lds + kSwMask);
-	auto zero_ring = [&]() { if (lane < 22) *reinterpret_cast<uint4*>(lds + kSwMask + lane * 16) = make_uint4(0, 0, 0, 0); }; // 352 B
-	zero_ring();
+	// per-lane constants of the sparse stage
+	const uint32_t lane8 = (uint32_t)lane * 8u;            // byte offset of the lane's 4 u16 inside a ring row
+	uint32_t* const maskw = reinterpret_cast<uint32_t*>(rest + kMask);
+	auto zero_masks = [&]() { *reinterpret_cast<uint2*>(rest + kMask + lane * 8) = make_uint2(0u, 0u); }; // 4 rows x 128 B = 64 x 8 B
+	zero_masks();
+	uint32_t listCount = 0;                // entries in the candidate list (wave-uniform)
 
 	uint32_t nm, nl, nr;
 	load(y0 - 2, nm, nl, nr);
 
-	// One row step: push input row yin = y0 - 2 + it  ->  gradient row yc = yin - 1  ->  (NMS) non-maximum suppression of row yo = yc - 1.
+	// One row step: push input row yin = y0 - 2 + it  ->  gradient row yc = yin - 1 = y0 + (it - 3)  ->  ring slot (it - 3) & 3.
+	// After the steps with odd it >= 5 the rows 2j, 2j + 1 (j = (it - 5) / 2) of the tile have all three g rows of their neighbourhood
+	// in the ring and their candidates in the list: NMS of the pair.  After every second pair the 4-row mask ring is flushed.
 	auto step = [&](auto phase, auto with_nms, int it) {
-		constexpr int PH = decltype(phase)::value;
+		constexpr int PH = decltype(phase)::value;            // it & 3
 		constexpr bool NMS = decltype(with_nms)::value;
-		constexpr int sD = PH % 3, sC = (PH + 2) % 3, sU = (PH + 1) % 3; // ring slots of rows yo+1 (written now), yo, yo-1
-		constexpr int aNew = PH % 2, aMid = (PH + 1) % 2;
+		constexpr int sNew = (PH + 1) & 3;                    // ring slot of the gradient row produced now
+		constexpr int aNew = (PH + 1) & 1;                    // its aux slot = its row parity
 		const int yin = y0 - 2 + it;
 		const uint32_t m = nm, l = nl, r = nr;
 		load(yin + 1, nm, nl, nr); // prefetch
@@ -204,51 +211,33 @@ __global__ __launch_bounds__(kCannyWaves * 64, 8) void canny_swar_tile_kernel(Ca
 #pragma unroll
 			for (int k = 0; k < 2; ++k) gq[k] = bfi(okm[k] & rowm, gq[k], kBias2k);
 		}
-		*reinterpret_cast<uint2*>(lds + kSwG + sD * kSwRowBytes + lane * 8) = make_uint2(gq[0], gq[1]);
-		*reinterpret_cast<uint2*>(lds + kSwAux + aNew * kSwRowBytes + lane * 8) = make_uint2(aux[0], aux[1]);
+		*reinterpret_cast<uint2*>(ring + sNew * kRowB + lane8) = make_uint2(gq[0], gq[1]);
 
-		// ---- NMS + classification of row yo = yc - 1 on its candidates (pixels with g > tLow) ----
+		// ---- sparse stage: NMS + classification of the row pair (2j, 2j + 1) on its candidates ----
 		if (NMS) {
-			const int rr = yc - 1 - y0; // tile row 0..63
+			static_assert(!NMS || (PH & 1), "pairs complete on odd steps");
+			constexpr int sA = (PH + 3) & 3;                  // ring slot of row 2j: 0 (j even) or 2 (j odd); row 2j + 1 sits in sA + 1
 			__builtin_amdgcn_wave_barrier();
-			// Candidate list of the row, one ballot per pixel slot: entry = byte offset of the candidate inside a ring row (2 * local
-			// column), position = scalar popcount of the earlier slots (rides in as the mbcnt base) + mbcnt of the slot's own mask; the
-			// store is exec-masked (scalar work: the kernel is bound by the VALU pipe, not by scalar issue).
-			uint16_t* const list = reinterpret_cast<uint16_t*>(lds + kSwList);
-			const uint32_t listB = (uint32_t)(wave * kSwLdsBytes + kSwList);                 // LDS byte address of the list
-			uint32_t base2 = listB >> 1;                                                     // uniform: half-word index of the slot's first entry
-#pragma unroll
-			for (int p = 0; p < kSwPx; ++p) {
-				const uint32_t gp = (p & 1) ? (gprev[p >> 1] >> 16) : (gprev[p >> 1] & 0xffffu);
-				const bool c = gp > (uint32_t)tLowQ;
-				const uint64_t mk = __ballot(c);
-				if (c) {
-					const uint32_t rk = __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, base2));
-					*reinterpret_cast<uint16_t*>(&lds_all[0][0] + twice(rk)) = (uint16_t)(lane * 8 + 2 * p);
-				}
-				base2 += (uint32_t)__popcll(mk);
-			}
-			const int total = (int)(__builtin_amdgcn_readfirstlane(base2) - (listB >> 1));
-			__builtin_amdgcn_wave_barrier();
-			const uint8_t* const gU = lds + kSwG + sU * kSwRowBytes;
-			const uint8_t* const gC = lds + kSwG + sC * kSwRowBytes;
-			const uint8_t* const gD = lds + kSwG + sD * kSwRowBytes;
-			const uint8_t* const ax_row = lds + kSwAux + aMid * kSwRowBytes;
-			uint32_t* const mrowW = maskw + ((rr & 3) * 2) * kMaskPitch + 1;
-			uint32_t* const mrowS = mrowW + kMaskPitch;
+			const int total = (int)listCount;
+			const uint8_t* const list = rest + kList;
 #pragma nounroll
 			for (int base = 0; base < total; base += 64) {
-				const int j = base + lane;
-				if (j < total) {
-					const int e = list[j];
-					// the centre, its aux word and all eight neighbours are fetched at once (one LDS round trip), the direction class then
-					// picks one of four neighbour maxima
-					const int gc = *reinterpret_cast<const uint16_t*>(gC + e);
-					const uint32_t au = *reinterpret_cast<const uint16_t*>(ax_row + e);
-					const int nL = *reinterpret_cast<const uint16_t*>(gC + e - 2), nR = *reinterpret_cast<const uint16_t*>(gC + e + 2);
-					const int nU = *reinterpret_cast<const uint16_t*>(gU + e), nD = *reinterpret_cast<const uint16_t*>(gD + e);
-					const int nUL = *reinterpret_cast<const uint16_t*>(gU + e - 2), nUR = *reinterpret_cast<const uint16_t*>(gU + e + 2);
-					const int nDL = *reinterpret_cast<const uint16_t*>(gD + e - 2), nDR = *reinterpret_cast<const uint16_t*>(gD + e + 2);
+				const int jx = base + lane;
+				if (jx < total) {
+					// entry = (row parity << 9) | byte offset of the candidate inside a ring row: centre, aux and all eight neighbours are
+					// fetched at once (one LDS round trip), the direction class then picks one of four neighbour maxima
+					const uint32_t e = *reinterpret_cast<const uint16_t*>(list + 2 * jx);
+					const uint32_t eU = (e + (uint32_t)(sA * kRowB + 3 * kRowB)) & (4u * kRowB - 1u);   // row above (ring wraps)
+					const uint32_t eD = (e + (uint32_t)(sA * kRowB + kRowB)) & (4u * kRowB - 1u);       // row below
+					const uint8_t* const gC = ring + sA * kRowB + e;
+					const uint8_t* const gU = ring + eU;
+					const uint8_t* const gD = ring + eD;
+					const int gc = *reinterpret_cast<const uint16_t*>(gC);
+					const uint32_t au = *reinterpret_cast<const uint16_t*>(rest + kAux + e);
+					const int nL = *reinterpret_cast<const uint16_t*>(gC - 2), nR = *reinterpret_cast<const uint16_t*>(gC + 2);
+					const int nU = *reinterpret_cast<const uint16_t*>(gU), nD = *reinterpret_cast<const uint16_t*>(gD);
+					const int nUL = *reinterpret_cast<const uint16_t*>(gU - 2), nUR = *reinterpret_cast<const uint16_t*>(gU + 2);
+					const int nDL = *reinterpret_cast<const uint16_t*>(gD - 2), nDR = *reinterpret_cast<const uint16_t*>(gD + 2);
 					const uint32_t ax = au & 0x3ffu;
 					const uint32_t ays = (uint32_t)(gc - 2048 - (int)ax) << 16;      // |gy| << 16
 					// direction class (constants canny_dete.h:58-61: tan(pi/8), tan(3pi/8) in Q16; 158217 = 27145 + 2^17)
@@ -262,7 +251,7 @@ __global__ __launch_bounds__(kCannyWaves * 64, 8) void canny_swar_tile_kernel(Ca
 					const int mx2 = k1 ? mh : (k2 ? md : mv);
 					bool weak = gc >= mx2;          // not suppressed: neither neighbour strictly greater (candidates already have g > tLow)
 					bool strong = gc > tHighQ;
-					const int c = e >> 1;           // local column 0..255
+					const int c = (int)((e >> 1) & 255u);   // local column 0..255
 					if (GAP) { // quirk Q3: column coverage of the NMS and of the seed scan, [1,simdEnd) U [cStart,W-1) (canny_dete.cxx:396,514)
 						const int x = xbase + c;
 						const bool in_cov = (x >= 1 && x < a.simdEnd) || (x >= a.cStart && x < W - 1);
@@ -270,175 +259,110 @@ __global__ __launch_bounds__(kCannyWaves * 64, 8) void canny_swar_tile_kernel(Ca
 						strong = strong && in_cov;
 					}
 					const uint32_t bit = 1u << (c & 31);
+					// mask ring row = sA + row parity = (sA * 512 + e) >> 9; word (c >> 5) of the mask lives in dword 1 + (c >> 5)
+					uint32_t* const mw = reinterpret_cast<uint32_t*>(rest + kMask + sA * kMaskRowB + 4) + ((e >> 9) << 5) + (c >> 5);
 					if (weak) {
-						atomicOr(&mrowW[c >> 5], bit);
-						if (strong) atomicOr(&mrowS[c >> 5], bit);
+						atomicOr(mw, bit);
+						if (strong) atomicOr(mw + 16, bit);
 					}
 				}
 			}
-			// every 4 rows the ring goes to the global masks in their final layout (weak -> U buffer, strong -> E buffer), whole row
-			// segments per store instruction (lanes 0..31 the weak rows, 32..63 the strong rows); the tail of the kernel reads them back
-			if ((rr & 3) == 3) {
+			listCount = 0;
+			if constexpr (PH == 3) {
+				// rows 4m .. 4m + 3 of the tile are classified: masks and edge bytes leave in their final global layout
+				const int rr0 = it - 7;                          // tile row of mask ring slot 0
 				__builtin_amdgcn_wave_barrier();
-				const int mi = lane >> 5, q = (lane >> 3) & 3, dl = lane & 7;
-				const uint32_t* rw = maskw + (q * 2 + mi) * kMaskPitch + 1 + dl - odd;
-				store_dword(mi ? ebase : ubase, y0 + rr - 3 + q, dl, rw[0], rw[1]);
+				{
+					// masks: lanes 0..31 the U rows (weak & ~strong), 32..63 the E rows (strong), whole row segments per store instruction
+					const int mi = lane >> 5, q = (lane >> 3) & 3, dl = lane & 7;
+					const uint32_t* rw = maskw + q * 32 + 1 + dl - odd;      // local dwords dl - odd, dl - odd + 1 of the weak mask (dword -1 / 8: zero pads)
+					const uint32_t w0 = rw[0], w1 = rw[1], s0 = rw[16], s1 = rw[17];
+					const uint32_t lo = mi ? s0 : (w0 & ~s0), hi = mi ? s1 : (w1 & ~s1);
+					const uint32_t v = odd ? __builtin_amdgcn_alignbit(hi, lo, 24) : __builtin_amdgcn_alignbit(hi, lo, 8);
+					const int row = y0 + rr0 + q, gd = d0 + dl;
+					if (row < H && gd < a.wb) {
+						uint32_t* dst = (mi ? ebase : ubase) + (size_t)row * a.wb + gd;
+						if (!odd && dl == 7) reinterpret_cast<uint16_t*>(dst)[0] = (uint16_t)v;             // low half-word: the next tile owns the high one
+						else if (odd && dl == 0) reinterpret_cast<uint16_t*>(dst)[1] = (uint16_t)(v >> 16);  // high half-word: the previous tile owns the low one
+						else *dst = v;
+					}
+				}
+				{
+					// edge bytes of the strong pixels (the resolve rounds add the promoted ones): lane = (row q, 16-pixel group gi): one 16-byte store
+					const int q = lane >> 4, gi = lane & 15;
+					const uint32_t* rs = maskw + q * 32 + 16 + 1 + (gi >> 1);   // strong mask: local bits 8 + 16 gi .. 23 + 16 gi
+					const uint32_t bits16 = __builtin_amdgcn_alignbit(rs[1], rs[0], (gi & 1) ? 24 : 8) & 0xffffu;
+					const int row = y0 + rr0 + q;
+					const int x = tileX * kSwCols + gi * 16;
+					if (gi < 15 && row < H && x + 8 <= a.So) {
+						uint8_t* dst = obase + (size_t)row * a.So + x;
+						const uint32_t b0 = nibble_bytes(bits16 & 0xfu), b1 = nibble_bytes((bits16 >> 4) & 0xfu);
+						if (x + 16 <= a.So) {
+							const uint32_t b2 = nibble_bytes((bits16 >> 8) & 0xfu), b3 = nibble_bytes(bits16 >> 12);
+							*reinterpret_cast<uint4*>(dst) = make_uint4(b0, b1, b2, b3);
+						}
+						else *reinterpret_cast<uint2*>(dst) = make_uint2(b0, b1); // So % 8 == 0: an 8-column tail
+					}
+				}
 				__builtin_amdgcn_wave_barrier();
-				zero_ring();
+				zero_masks();
 			}
+			__builtin_amdgcn_wave_barrier();
 		}
+
+		// aux of the new row (its slot held the aux of row 2j until the NMS above was done with it)
+		*reinterpret_cast<uint2*>(rest + kAux + aNew * kRowB + lane8) = make_uint2(aux[0], aux[1]);
+
+		// ---- candidates of the new row join the list: entry = (row parity << 9) | byte offset inside a ring row, position = scalar
+		// popcount of the earlier slots (rides in as the mbcnt base) + mbcnt of the slot's own mask; the store is exec-masked ----
+		if (it >= 3 && it < kSwRows + 3) {   // gradient rows y0 .. y0 + kSwRows - 1 only (uniform)
+			uint8_t* const listw = rest + kList;
+			uint32_t cnt = listCount;
 #pragma unroll
-		for (int k = 0; k < 2; ++k) gprev[k] = gq[k] & ownv;
+			for (int p = 0; p < kSwPx; ++p) {
+				const uint32_t gk = gq[p >> 1] & ownv;
+				const uint32_t gp = (p & 1) ? (gk >> 16) : (gk & 0xffffu);
+				const bool c = gp > (uint32_t)tLowQ;
+				const uint64_t mk = __ballot(c);
+				if (c) {
+					const uint32_t rk = __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, cnt));
+					*reinterpret_cast<uint16_t*>(listw + twice(rk)) = (uint16_t)((aNew << 9) | (lane * 8 + 2 * p));
+				}
+				cnt += (uint32_t)__popcll(mk);
+			}
+			listCount = __builtin_amdgcn_readfirstlane(cnt);
+		}
 	};
 
 	{
 		using T = std::true_type; using F = std::false_type;
+		static_assert(kSwRows % 4 == 0, "the row loop is unrolled by four");
 		step(std::integral_constant<int, 0>{}, F{}, 0);
 		step(std::integral_constant<int, 1>{}, F{}, 1);
 		step(std::integral_constant<int, 2>{}, F{}, 2);
 		step(std::integral_constant<int, 3>{}, F{}, 3);
-		int it = 4;
-		for (; it < kTileH; it += 6) { // it = 4 .. 63: ten trips of six steps
-			step(std::integral_constant<int, 4>{}, T{}, it);
-			step(std::integral_constant<int, 5>{}, T{}, it + 1);
-			step(std::integral_constant<int, 0>{}, T{}, it + 2);
-			step(std::integral_constant<int, 1>{}, T{}, it + 3);
-			step(std::integral_constant<int, 2>{}, T{}, it + 4);
-			step(std::integral_constant<int, 3>{}, T{}, it + 5);
+		for (int it = 4; it < kSwRows + 4; it += 4) { // it = 4 .. kSwRows + 3
+			step(std::integral_constant<int, 0>{}, F{}, it);
+			step(std::integral_constant<int, 1>{}, T{}, it + 1);
+			step(std::integral_constant<int, 2>{}, F{}, it + 2);
+			step(std::integral_constant<int, 3>{}, T{}, it + 3);
 		}
-		static_assert(kTileH % 6 == 4, "main loop ends at it = 64");
-		step(std::integral_constant<int, 4>{}, T{}, it);
-		step(std::integral_constant<int, 5>{}, T{}, it + 1);
-		step(std::integral_constant<int, 0>{}, T{}, it + 2);
-		step(std::integral_constant<int, 1>{}, T{}, it + 3);
 	}
-
-	// ---- lane == row: read the weak / strong masks back (coalesced, through an LDS image), flood strong into weak ----
-	uint32_t* const img = reinterpret_cast<uint32_t*>(lds);
-	const int rowsHere = min(kTileH, H - y0);
-	asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's mask stores have reached the L2
-	auto fetch_mask = [&](const uint32_t* gm, uint64_t (&M)[4]) {
-		__builtin_amdgcn_wave_barrier();
-		const int k = lane & 7;
-		const int a0 = odd ? k : k - 1;     // local dword k = bits of global dwords d0 + a0, d0 + a0 + 1
-#pragma unroll 4
-		for (int itr = 0; itr < 8; ++itr) {
-			const int row = itr * 8 + (lane >> 3);
-			uint32_t g0 = 0, g1 = 0;
-			if (row < rowsHere) {
-				const uint32_t* src = gm + (size_t)(y0 + row) * a.wb + d0;
-				// relaxed agent-scope loads (sc1): served by the L2, never by a stale line of this CU's vector cache
-				if (a0 >= 0 && d0 + a0 < a.wb) g0 = __hip_atomic_load(src + a0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-				if (a0 + 1 <= 7 && d0 + a0 + 1 < a.wb) g1 = __hip_atomic_load(src + a0 + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-			}
-			uint32_t v = odd ? __builtin_amdgcn_alignbit(g1, g0, 8) : __builtin_amdgcn_alignbit(g1, g0, 24);
-			if (k == 0) v &= 0xffffff00u;        // local bits 0..7 and 248..255 are the neighbouring tiles' columns
-			if (k == 7) v &= 0x00ffffffu;
-			img[row * kImgPitch + k] = v;
-		}
-		__builtin_amdgcn_wave_barrier();
-#pragma unroll
-		for (int m = 0; m < 4; ++m) M[m] = (uint64_t)img[lane * kImgPitch + 2 * m] | ((uint64_t)img[lane * kImgPitch + 2 * m + 1] << 32);
-	};
-	uint64_t Wm[4], Em[4];
-	fetch_mask(ubase, Wm);
-	fetch_mask(ebase, Em);
-
-	auto flood_up = [&]() {
-		uint64_t carry = 0;
-#pragma unroll
-		for (int m = 0; m < 4; ++m) {
-			const uint64_t w = Wm[m];
-			const uint64_t b = Em[m] & w;
-			const uint64_t t = w + b;
-			const uint64_t c1 = t < w;
-			const uint64_t t2 = t + carry;
-			const uint64_t c2 = t2 < t;
-			carry = c1 | c2;
-			Em[m] |= w & ~t2;
-		}
-	};
-	auto flood_down = [&]() {
-		uint64_t carry = 0;
-#pragma unroll
-		for (int m = 3; m >= 0; --m) {
-			const uint64_t w = __brevll(Wm[m]);
-			const uint64_t b = __brevll(Em[m]) & w;
-			const uint64_t t = w + b;
-			const uint64_t c1 = t < w;
-			const uint64_t t2 = t + carry;
-			const uint64_t c2 = t2 < t;
-			carry = c1 | c2;
-			Em[m] |= __brevll(w & ~t2);
-		}
-	};
-#pragma unroll
-	for (int m = 0; m < 4; ++m) Em[m] &= Wm[m]; // seeds are weak pixels by construction; keeps E a subset of W whatever happens
-	for (;;) {
-		flood_up();
-		flood_down();
-		bool changed = false;
-		uint64_t nb[4];
-#pragma unroll
-		for (int m = 0; m < 4; ++m) {
-			uint64_t up = __shfl_up(Em[m], 1);
-			uint64_t dn = __shfl_down(Em[m], 1);
-			if (lane == 0) up = 0;
-			if (lane == 63) dn = 0;
-			nb[m] = up | dn;
-		}
-#pragma unroll
-		for (int m = 0; m < 4; ++m) {
-			uint64_t n3 = nb[m] | (nb[m] << 1) | (nb[m] >> 1);
-			if (m > 0) n3 |= nb[m - 1] >> 63;
-			if (m < 3) n3 |= nb[m + 1] << 63;
-			const uint64_t add = Wm[m] & n3 & ~Em[m];
-			Em[m] |= add;
-			changed |= (add != 0);
-		}
-		if (!__any(changed)) break;
-	}
-
-	// ---- outputs: the two 1-bit masks in their final state: E (edges so far) and U (weak pixels this tile could not resolve).
-	// The edge BYTES are expanded from the final E mask by canny_expand_kernel, after the cross-tile resolve, on a side stream next
-	// to the Hough stage: 1 B/px of stores that this kernel no longer waits for.  The masks leave through an LDS image (64 rows x
-	// 11 dwords: [0] = 0, [1..8] = the local dwords, [9] = 0) so that every store instruction writes whole row segments: a
-	// lane == row store of one dword per lane touches 64 cache lines per instruction (measured: 0.14 ms of a 0.34 ms launch).
-	uint32_t* const tr = reinterpret_cast<uint32_t*>(lds);
-	auto put_store = [&](const uint64_t (&M)[4], uint32_t* __restrict__ gm) {
-		__builtin_amdgcn_wave_barrier();
-		tr[lane * kMaskPitch] = 0u; tr[lane * kMaskPitch + 9] = 0u;
-#pragma unroll
-		for (int m = 0; m < 4; ++m) {
-			tr[lane * kMaskPitch + 1 + 2 * m] = (uint32_t)M[m];
-			tr[lane * kMaskPitch + 2 + 2 * m] = (uint32_t)(M[m] >> 32);
-		}
-		__builtin_amdgcn_wave_barrier();
-		const int dl = lane & 7;
-		const int src = 1 + dl - odd;        // LDS dword holding the low part of global dword d0 + dl
-#pragma unroll 4
-		for (int itr = 0; itr < 8; ++itr) {
-			const int row = itr * 8 + (lane >> 3);
-			store_dword(gm, y0 + row, dl, tr[row * kMaskPitch + src], tr[row * kMaskPitch + src + 1]);
-		}
-	};
-	put_store(Em, ebase);
-#pragma unroll
-	for (int m = 0; m < 4; ++m) Wm[m] &= ~Em[m]; // U = weak but not (yet) an edge
-	put_store(Wm, ubase);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 hipError_t launch_canny_tiles_swar(const CannyArgs& a0, int frames, bool gap, hipStream_t stream)
 {
+	constexpr int kWaves = 1;   // one wave per workgroup: every LDS address of the kernel is lane * k + constant
 	CannyArgs a = a0;
 	a.tilesX = (a.W + kSwCols - 1) / kSwCols;
-	a.blockRows = (a.tilesY + kCannyWaves - 1) / kCannyWaves;
+	a.tilesY = (a.H + kSwRows - 1) / kSwRows;
+	a.blockRows = (a.tilesY + kWaves - 1) / kWaves;
 	a.groups = a.blockRows * frames;
 	dim3 grid(8 * ((a.groups + 7) / 8) * a.tilesX);
-	dim3 block(kCannyWaves * 64);
-	if (gap) hipLaunchKernelGGL((canny_swar_tile_kernel<true>), grid, block, 0, stream, a);
-	else hipLaunchKernelGGL((canny_swar_tile_kernel<false>), grid, block, 0, stream, a);
+	dim3 block(kWaves * 64);
+	if (gap) hipLaunchKernelGGL((canny_swar_tile_kernel<true, kWaves>), grid, block, 0, stream, a);
+	else hipLaunchKernelGGL((canny_swar_tile_kernel<false, kWaves>), grid, block, 0, stream, a);
 	return hipGetLastError();
 }
 

@@ -28,12 +28,13 @@ struct CannyArgs {
 	int simdEnd, cStart;      // quirk Q3 coverage: [1,simdEnd) U [cStart,W-1)
 	int blockRows, groups;    // filled by the launcher: workgroup rows per frame, row groups in the launch (XCD-aware map)
 	int ksize;                // Sobel kernel size of the gradient: 3 or 5
+	int impl;                 // kernel size 3: 0 = SWAR + candidate-list kernel (canny_swar_kernels.hip), 1 = register-ring kernel (canny_kernels.hip)
 };
 
 struct ResolveArgs {
 	uint32_t* ebits;
 	uint32_t* ubits;
-	uint8_t* out;             // byte map to patch, or nullptr when canny_expand_kernel rebuilds it from the masks afterwards
+	uint8_t* out;             // byte map to patch with the promoted pixels (nullptr: masks only)
 	int* flags;               // flags[round] = 1 when round changed something
 	uint8_t* dirty;           // [4][frames][bands][chunks]: which workgroups changed their band in round (r & 3)
 	size_t outFrameStride, bitsFrameStride;
@@ -42,13 +43,9 @@ struct ResolveArgs {
 };
 
 hipError_t launch_canny_tiles(const CannyArgs& a, int frames, bool gap, hipStream_t stream);
-bool canny_tiles_write_bytes(int ksize); // true for the first-generation tile kernel (kernel size 5, or COMPVHIP_CANNY_IMPL=ring)
 hipError_t launch_canny_tiles_swar(const CannyArgs& a, int frames, bool gap, hipStream_t stream); // kernel size 3 (canny_swar_kernels.hip)
 hipError_t launch_canny_resolve(const ResolveArgs& a, int frames, hipStream_t stream);
 size_t canny_resolve_dirty_bytes(int H, int wb, int frames);
-// edge bytes {0,0xff} from the final E masks (1 bit/px): out[frames][H][So]
-hipError_t launch_canny_expand(const uint32_t* ebits, int wb, size_t bitsFrameStride, int H, int So, uint8_t* out, size_t outFrameStride, int frames,
-                               hipStream_t stream);
 hipError_t launch_mean_thresholds(const uint8_t* in, int W, int H, int S, size_t frameStride, int frames, float fLow, float fHigh,
                                   unsigned int* sums, int2* thr, hipStream_t stream);
 
@@ -89,11 +86,9 @@ hipError_t launch_convlt_fxp(const uint8_t* in, uint8_t* tmp, uint8_t* out, int 
                              const uint16_t* hzKern, int K, hipStream_t stream);
 
 // ---- Hough SHT ---------------------------------------------------------------------------------------------
-constexpr int kShtVoteThreads = 1024;
-
 struct ShtArgs {
 	const uint32_t* ebits;    // edge bit masks [frames][H][wb]
-	uint32_t* edges;          // compacted edge list per frame: (y << 16) | x, capacity edgeCap
+	uint32_t* edges;          // per-tile edge lists of every frame: (ly << 16) | lx, edgeCap entries per frame
 	int* edgeCounts;          // per frame
 	uint16_t* acc;            // [frames][T][accPitch], u16: a cell never exceeds 65535
 	const int32_t* sinQ;      // [T]
@@ -104,14 +99,11 @@ struct ShtArgs {
 	int W, H, wb;
 	int R, T, accPitch, barrier;
 	int threshold, nmsLastCol;
-	int shards;               // vote workgroups per (frame, theta group)
 	int frames;
 	int cellBits;             // bits of the accumulator cell index in a line key (2^cellBits > R*T)
 	int strengthBits;         // bits of the strength field of a line key (2^strengthBits > 2*max(W,H) >= any cell count)
-	int thetaPerGroup;        // 4 (default) or 2 theta bins per vote workgroup
-	const int32_t* groupOrder; // vote workgroup rank -> theta group, most expensive groups (theta near 90, 0, 180 deg) first
 };
-// second-generation voting (sht_tiles_kernels.hip): image tiles, lane = theta
+// voting (sht_tiles_kernels.hip): image tiles, lane = theta
 struct ShtTileArgs {
 	const int32_t* kt;        // [tiles][T]  window constant K of (tile, theta): window row = (K - lx cosQ - ly sinQ) >> 16
 	const int32_t* rowBase;   // [tiles][T]  accumulator row of window row 0
@@ -128,8 +120,6 @@ hipError_t launch_sht_vote_tiles(const ShtArgs& a, const ShtTileArgs& v, int fra
 hipError_t launch_sht_reduce_tiles(const ShtArgs& a, const ShtTileArgs& v, int frames, hipStream_t stream);
 hipError_t launch_bytes_to_bits(const uint8_t* edges, int W, int H, int S, size_t frameStride, uint32_t* ebits, int wb, size_t bitsFrameStride,
                                 int frames, hipStream_t stream);
-hipError_t launch_sht_compact(const ShtArgs& a, int frames, hipStream_t stream);
-hipError_t launch_sht_vote(const ShtArgs& a, int frames, hipStream_t stream);
 hipError_t launch_sht_nms(const ShtArgs& a, int frames, hipStream_t stream);
 hipError_t launch_sht_decode(const uint64_t* keys, const int* counts, size_t lineCap, int frames, int T, int barrier, float thetaStep,
                              int maxLines, int cellBits, int strengthBits, void* lines /*compvhip_line*/, size_t outCap, hipStream_t stream);
@@ -137,7 +127,6 @@ hipError_t launch_sht_decode(const uint64_t* keys, const int* counts, size_t lin
 hipError_t launch_sht_cartesian(const void* lines /*compvhip_line*/, const int* counts, size_t lineCap, int frames, const float* cosT, const float* invSinT,
                                 float widthF, float r, float* out /*[frames][lineCap][4]*/, hipStream_t stream);
 hipError_t launch_sht_acc_transpose(const uint16_t* accT, int R, int T, int accPitch, int32_t* out, size_t outStride, hipStream_t stream);
-size_t sht_vote_lds_bytes(int R, int thetaPerGroup);
 // one descending radix sort over the (unique) 64-bit line keys of all frames; temp == nullptr queries tempBytes
 hipError_t sht_sort_keys(void* temp, size_t& tempBytes, const uint64_t* keysIn, uint64_t* keysOut, size_t lineCap, int frames, int keyBits,
                          hipStream_t stream);

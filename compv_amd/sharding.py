@@ -46,3 +46,37 @@ def gather_frame_results(local_values, dist=None, device=None):
     for s, o in zip(sizes, out):
         res.extend(int(v) for v in o[:int(s.item())].tolist())
     return res
+
+
+# ---- optional data path of SURVEY.md 8(e): the step's batch is born on one rank ---------------------------------------------------
+def scatter_blocks(dist, block_of_rank, out, src=0):
+    """Rank `src` owns the global batch of a step as per-rank blocks (block_of_rank(r) -> tensor shaped like `out`, only called on `src`);
+    every rank ends up with its block in `out`.  One grouped send/recv (torch.distributed.batch_isend_irecv: a single RCCL group on
+    GPUs, so the P2P copies of all destinations run concurrently over their own xGMI links); no collective involves the payload twice.
+    Without an initialised process group it is a plain copy."""
+    if dist is None or not dist.is_initialized():
+        out.copy_(block_of_rank(0))
+        return
+    rank, world = dist.get_rank(), dist.get_world_size()
+    if rank == src:
+        ops = [dist.P2POp(dist.isend, block_of_rank(r), r) for r in range(world) if r != src]
+        out.copy_(block_of_rank(src))
+    else:
+        ops = [dist.P2POp(dist.irecv, out, src)]
+    if ops:
+        for w in dist.batch_isend_irecv(ops):
+            w.wait()
+
+
+def gather_lines(dist, counts, lines_topk):
+    """All-gather of the per-frame line counts [F] and of the K strongest lines of every frame [F, K, 5] (int32 rows of compvhip_line):
+    every rank ends up with the results of the global batch in rank order.  Returns (counts [world*F], lines [world*F, K, 5])."""
+    if dist is None or not dist.is_initialized():
+        return counts, lines_topk
+    import torch
+    world = dist.get_world_size()
+    all_counts = torch.empty((world * counts.shape[0],), dtype=counts.dtype, device=counts.device)
+    all_lines = torch.empty((world * lines_topk.shape[0],) + tuple(lines_topk.shape[1:]), dtype=lines_topk.dtype, device=lines_topk.device)
+    dist.all_gather_into_tensor(all_counts, counts.contiguous())
+    dist.all_gather_into_tensor(all_lines, lines_topk.contiguous())
+    return all_counts, all_lines

@@ -15,7 +15,7 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
-from oracle_bindings import RefShim, md5_rows, synth_frame  # noqa: E402
+from oracle_bindings import RefShim, libstdcxx_version, md5_rows, synth_frame  # noqa: E402
 
 # name, W, H, seed, tLow, tHigh, theta_deg, threshold, maxLines
 CASES = [("vga_all", 640, 480, 77, 59.0, 119.0, 1.0, 30, 0), ("vga_top100", 640, 480, 77, 59.0, 119.0, 1.0, 30, 100),
@@ -44,6 +44,7 @@ def main():
                       "canny_md5": md5_rows(can), "lines": int(len(a)), "equal_strength_pairs": int((np.diff(s.astype(np.int64)) == 0).sum()),
                       "md5": hashlib.md5(a.tobytes()).hexdigest(), "head": a[:64].tolist(), "tail": a[-64:].tolist()}
         print(name, len(a), meta[name]["equal_strength_pairs"], meta[name]["md5"])
+    meta["_runtime"] = {"libstdcxx": libstdcxx_version(), "note": "tie order = this runtime's std::sort; a different libstdc++ may order equal strengths differently"}
     with open(os.path.join(HERE, "golden_sht_order.json"), "w") as f:
         json.dump(meta, f, sort_keys=True)
 

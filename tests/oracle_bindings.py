@@ -39,6 +39,24 @@ def synth_frame(W, H, seed=12345):
     return v.astype(np.uint8)
 
 
+def libstdcxx_version():
+    """Newest GLIBCXX symbol version of the libstdc++ this process loads, e.g. 'GLIBCXX_3.4.30'.  The order of equal-strength Hough lines
+    is "what this runtime's std::sort (introsort) does" -- in the reference and in the host entry points that reproduce it -- so the
+    fixtures that pin that order record the runtime they were generated with (tests/golden/golden_sht_order.json)."""
+    import re
+    C.CDLL("libstdc++.so.6")
+    path = None
+    with open("/proc/self/maps") as f:
+        for line in f:
+            if "libstdc++.so" in line:
+                path = line.split()[-1]
+                break
+    if not path:
+        return None
+    vers = set(re.findall(rb"GLIBCXX_3\.4\.(\d+)", open(path, "rb").read()))
+    return "GLIBCXX_3.4.%d" % max(int(v) for v in vers) if vers else None
+
+
 def md5_rows(a):
     """MD5 over the valid bytes of each row (the reference's compv_tests_md5 convention,
     tests/tests_common.cxx:98-117)."""

@@ -182,22 +182,65 @@ def test_houghsht_wide_rho_range(hip_ctx, oracle, W, H):
     assert _lines_tuple(lines) == _orc_tuple(exp)
 
 
-def test_houghsht_legacy_vote_kernels(oracle, monkeypatch):
-    """The first-generation vote path (lane = edge, one workgroup per theta pair; COMPVHIP_SHT_VOTE=legacy, with its 4-theta tuning
-    knob) still produces the same histogram -- it is kept for A/B measurements."""
+def test_canny_ring_kernel_alternative(oracle, monkeypatch):
+    """Kernel size 3 has two tile kernels: the SWAR + candidate-list kernel (default) and the register-ring kernel that also serves
+    kernel size 5.  COMPVHIP_CANNY_IMPL=ring is read at every plan creation (a context's host plan included): same edge maps, with the
+    Q3 coverage gap, in place, and on a long weak chain that the band kernel has to flood."""
     from compv_amd import capi
-    monkeypatch.setenv("COMPVHIP_SHT_VOTE", "legacy")
-    monkeypatch.setenv("COMPVHIP_SHT_THETA_PER_GROUP", "4")
+    monkeypatch.setenv("COMPVHIP_CANNY_IMPL", "ring")
     ctx = capi.Context(0)
     try:
-        W, H = 641, 480
-        rc, edges = oracle.canny(synth_frame(W, H), 59., 119.)
-        acc_exp = oracle.sht_acc(edges, 1.0)
-        lines, acc = ctx.houghsht(edges, 1.0, 100, want_acc=True)
-        assert (acc == acc_exp).all()
-        assert _lines_tuple(lines) == _orc_tuple(oracle.sht_lines_from_acc_reference_order(acc_exp, W, H, 1.0, 100))
+        for (W, H) in [(20, 20), (513, 65), (641, 480), (1282, 720)]:
+            img = synth_frame(W, H, 7 + H)
+            for (tl, th) in [(59.0, 119.0), (0.8, 1.6)]:
+                rc, exp = oracle.canny(img, tl, th)
+                got = ctx.canny(img, tl, th)
+                assert (got == exp).all(), (W, H, tl, int((got != exp).sum()))
+        buf = synth_frame(300, 200, 5).copy()
+        rc, exp = oracle.canny(buf, 59.0, 119.0)
+        ctx.canny(buf, 59.0, 119.0, out=buf)
+        assert (buf == exp).all()
     finally:
         ctx.close()
+
+
+def test_canny_documented_deviations(hip_ctx, oracle):
+    """Two DEFINED deviations from the reference, pinned as such:
+    * thresholds above 32767: the reference's SIMD leaves compare them as signed int16 and its scalar remainder as unsigned -- an artefact
+      regime (g <= 24480 can never exceed them) that this implementation rejects with E_INVALID_PARAMETER instead of reproducing;
+    * an Otsu level of 0 (device OTSU threshold mode): the reference's set() rejects the threshold pair and the sample skips the frame
+      (canny_dete.cxx:86-99, samples/hough_lines/main.cxx:103-105); a batch cannot skip a frame: thresholds (1, 3) are used."""
+    import torch
+    from compv_amd import capi
+    img = synth_frame(64, 64)
+    for (tl, th) in [(10.0, 40000.0), (33000.0, 40000.0)]:
+        with pytest.raises(capi.CompvHipError) as e:
+            hip_ctx.canny(img, tl, th)
+        assert e.value.code == capi.E_INVALID_PARAMETER
+    hip_ctx.canny(img, 10.0, 32767.0)      # the largest accepted pair still works (and selects nothing strong: g <= 2040)
+    W, H, F = 320, 96, 2
+    frames = np.zeros((F, H, W), np.uint8)
+    frames[0, 20:60, 50:200] = 200          # two grey levels {0, 200}: every Otsu level 0..199 has the same variance -> level 0
+    frames[1] = synth_frame(W, H, 3)
+    assert oracle.otsu(frames[0]) == 0
+    dev = torch.device("cuda:0")
+    d_in = torch.from_numpy(frames).to(dev)
+    d_e = torch.empty_like(d_in)
+    d_t = torch.zeros(F, dtype=torch.int32, device=dev)
+    plan = capi.Plan(hip_ctx, W, H, W, F, 1.0)
+    try:
+        plan.otsu(d_in.data_ptr(), d_t.data_ptr())
+        plan.canny(d_in.data_ptr(), 0.5, 1.0, d_e.data_ptr(), threshold_type=capi.THRESHOLD_OTSU)
+        torch.cuda.synchronize()
+        assert d_t.cpu().tolist() == [0, int(oracle.otsu(frames[1]))]      # the level is reported, the frame is not skipped
+        rc, exp0 = oracle.canny(frames[0], 1.0, 3.0)
+        assert rc == 0 and exp0.any()
+        assert (d_e[0].cpu().numpy() == exp0).all()
+        lo, hi = oracle.otsu_canny_thresholds(int(oracle.otsu(frames[1])))
+        rc, exp1 = oracle.canny(frames[1], float(lo), float(hi))
+        assert (d_e[1].cpu().numpy() == exp1).all()
+    finally:
+        plan.close()
 
 
 @pytest.mark.parametrize("W,H", [(20480, 16), (32767, 64), (64, 32767), (8192, 8192)])
@@ -872,6 +915,56 @@ def test_two_plans_in_flight_on_two_streams(hip_ctx, oracle):
                 exp = oracle.sht(e, 1.0, 45)
                 assert counts[f] == len(exp) and len(exp) <= cap
                 assert _lines_tuple(np.frombuffer(raw[f].tobytes(), dtype=capi.LINE_DTYPE)[:len(exp)]) == _orc_tuple(exp), (k, f)
+    finally:
+        for q in lanes:
+            q["plan"].close()
+
+
+def test_bench_batches_match_the_reference_fixture(hip_ctx):
+    """The benchmark's own workload and step mode: two resident batches of 32 4K frames (seeds 12345 .. 12345+63 of BASELINE config 4),
+    two plans on two streams, asynchronous steps in flight at the same time -- every frame's edge map (MD5), edge count, line count,
+    strength sum and line-set hash against tests/golden/golden_batch.json, which the real CompV library produced
+    (tests/golden/make_golden_batch.py).  bench.py runs the same check over all 256 frames after its timed region."""
+    import hashlib
+    import json
+    import torch
+    import bench
+    from compv_amd import capi
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "golden_batch.json")))
+    W, H, F, cap = gold["W"], gold["H"], 32, 1 << 16
+    by_seed = {g["seed"]: g for g in gold["frames"]}
+    dev = torch.device("cuda:0")
+    synth = bench.FrameSynth(torch, dev, W, H)
+    assert np.array_equal(synth.frame(12345 + 40).cpu().numpy(), synth_frame(W, H, 12345 + 40))
+    lanes = []
+    for k in range(2):
+        seeds = [gold["first_seed"] + k * F + f for f in range(F)]
+        lanes.append({"seeds": seeds, "in": synth.batch(seeds), "plan": capi.Plan(hip_ctx, W, H, W, F, gold["theta_deg"]), "st": torch.cuda.Stream(device=dev),
+                      "e": torch.empty((F, H, W), dtype=torch.uint8, device=dev), "l": torch.zeros((F, cap, 5), dtype=torch.int32, device=dev),
+                      "c": torch.zeros(F, dtype=torch.int32, device=dev)})
+    del synth
+    torch.cuda.synchronize()
+    try:
+        for rep in range(2):      # the second round re-uses every buffer of both plans
+            tickets = [(q, q["plan"].pipeline_async(q["in"].data_ptr(), gold["tLow"], gold["tHigh"], gold["threshold"], 0, q["e"].data_ptr(), q["l"].data_ptr(),
+                                                    cap, q["c"].data_ptr(), q["st"].cuda_stream)) for q in lanes]
+            for q, t in tickets:
+                q["plan"].wait(t)
+        torch.cuda.synchronize()
+        for q in lanes:
+            counts = q["c"].cpu().numpy()
+            assert int(counts.max()) <= cap
+            ln = q["l"].to(torch.int64)
+            valid = torch.arange(cap, device=dev)[None, :] < q["c"].to(torch.int64)[:, None]
+            hv = (W + H - ln[:, :, 3] + 32768) * 1000003 + ln[:, :, 4] * 7919 + ln[:, :, 2] * 31337
+            hv = torch.where(valid, hv, torch.zeros_like(hv)).sum(dim=1).cpu().numpy()
+            sums = torch.where(valid, ln[:, :, 2], torch.zeros_like(ln[:, :, 2])).sum(dim=1).cpu().numpy()
+            edges = q["e"].cpu().numpy()
+            for f in range(F):
+                g = by_seed[q["seeds"][f]]
+                got = {"canny_md5": hashlib.md5(edges[f].tobytes()).hexdigest(), "edges": int((edges[f] != 0).sum()), "lines": int(counts[f]),
+                       "sum_strength": int(sums[f]), "line_hash": "%016x" % (int(hv[f]) & bench.M64)}
+                assert got == {k: g[k] for k in got}, (q["seeds"][f], got, g)
     finally:
         for q in lanes:
             q["plan"].close()

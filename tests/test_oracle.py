@@ -128,6 +128,16 @@ def _pack_lines(rho, theta, strength):
     return a
 
 
+def test_sht_tie_order_runtime_is_the_fixtures_runtime():
+    """The order of equal-strength lines is "what this C++ runtime's std::sort does", in the reference and in compvhip_houghsht_u8 /
+    compvhip_houghkht_u8 that reproduce it (api.cpp referenceLineOrder, kht_host.cpp khtPeaks).  The fixtures record the libstdc++ they
+    were generated with; on another runtime they would have to be regenerated (with the reference rebuilt against it): fail loudly."""
+    from oracle_bindings import libstdcxx_version
+    want = _sht_order_golden()["_runtime"]["libstdcxx"]
+    assert libstdcxx_version() == want, ("tie-order fixtures were generated with %s, this process runs %s: regenerate "
+                                         "tests/golden/golden_sht_order.json with the reference built against this runtime" % (want, libstdcxx_version()))
+
+
 @pytest.mark.parametrize("name", ["vga_all", "vga_top100", "hd_halfdeg", "ragged_top40", "calib_like"])
 def test_sht_reference_line_order_fixture(oracle, name):
     """The compiled reference's line list, element by element (tests/golden/make_golden_sht_order.py): thousands of equal-strength
