@@ -335,7 +335,6 @@ __global__ __launch_bounds__(kResolveThreads) void canny_resolve_kernel(ResolveA
 	const int rows = min(kBandH, a.H - y0);
 	const int ew = cw + 2;                            // E row pitch in LDS (halo word each side)
 	uint32_t* sE = smem;                              // (rows+2) x ew
-	uint32_t* sU = smem + (kBandH + 2) * (kBandWords + 2); // rows x cw
 
 	uint32_t* __restrict__ gE = a.ebits + (size_t)frame * a.bitsFrameStride;
 	uint32_t* __restrict__ gU = a.ubits + (size_t)frame * a.bitsFrameStride;
@@ -358,66 +357,86 @@ __global__ __launch_bounds__(kResolveThreads) void canny_resolve_kernel(ResolveA
 		if (!any) { if (tid == 0) *mine = 0; return; } // uniform
 	}
 
-	// load U; bail out early when the band has nothing unresolved
+	// A thread owns up to kResolveRows CONSECUTIVE rows of one word column: k = tid % cw, row group tid / cw.  Its U words and its own
+	// E words live in registers; the LDS copy of E serves the neighbours (the rows above / below the group, bits 31 / 0 of the word
+	// columns left / right).  A sweep down then up the group's rows carries a vertical or diagonal chain through all of them in ONE
+	// iteration, words without candidates cost one test, and a word whose candidates do not touch the word border needs no LDS access.
+	const int k = tid % cw, grp = tid / cw;
+	const int nGroups = kResolveThreads / cw;                         // >= 8: cw <= kBandWords = 64
+	const int rpg = (rows + nGroups - 1) / nGroups;                   // <= kResolveRows
+	const int r0 = grp * rpg;
+	const int n = (grp < nGroups) ? max(min(rpg, rows - r0), 0) : 0;  // rows of this thread
+	uint32_t u[kResolveRows], e[kResolveRows + 2];
 	int haveU = 0;
-	for (int i = tid; i < rows * cw; i += kResolveThreads) {
-		const int r = i / cw, k = i - r * cw;
-		const uint32_t u = gU[(size_t)(y0 + r) * wb + w0 + k];
-		sU[r * cw + k] = u;
-		haveU |= (u != 0);
+#pragma unroll
+	for (int j = 0; j < kResolveRows; ++j) {
+		u[j] = (j < n) ? gU[(size_t)(y0 + r0 + j) * wb + w0 + k] : 0u;
+		haveU |= (u[j] != 0);
 	}
-	if (!__syncthreads_or(haveU)) { if (tid == 0) *mine = 0; return; }
+	if (!__syncthreads_or(haveU)) { if (tid == 0) *mine = 0; return; }  // nothing unresolved in this band
 	for (int i = tid; i < (rows + 2) * ew; i += kResolveThreads) {
-		const int r = i / ew, k = i - r * ew;
-		const int y = y0 - 1 + r, w = w0 - 1 + k;
-		uint32_t e = 0;
-		if (y >= 0 && y < a.H && w >= 0 && w < wb) e = gE[(size_t)y * wb + w];
-		sE[i] = e;
+		const int r = i / ew, c = i - r * ew;
+		const int y = y0 - 1 + r, w = w0 - 1 + c;
+		uint32_t v = 0;
+		if (y >= 0 && y < a.H && w >= 0 && w < wb) v = gE[(size_t)y * wb + w];
+		sE[i] = v;
 	}
 	__syncthreads();
+	uint32_t* const col = sE + (size_t)(n > 0 ? r0 : 0) * ew + k + 1;   // LDS word of (row r0 - 1, column k); row j of the group is col[(j + 1) * ew]
+#pragma unroll
+	for (int j = 0; j < kResolveRows + 2; ++j) e[j] = (j <= n + 1) ? col[j * ew] : 0u;
 
+	// one word: candidates next to an edge pixel are promoted, then the promotion runs along the horizontal candidate runs of the word
+	auto visit = [&](uint32_t uw, uint32_t up, uint32_t& ce, uint32_t dn, uint32_t* lds, int& changed) {
+		const uint32_t cand = uw & ~ce;
+		if (!cand) return;
+		const uint32_t c = up | ce | dn;
+		uint32_t nbits = c | (c << 1) | (c >> 1);
+		if (cand & 0x80000001u) {   // bit 0 / 31 of the neighbouring word columns, rows above .. below
+			const uint32_t L = lds[-ew - 1] | lds[-1] | lds[ew - 1], R = lds[-ew + 1] | lds[1] | lds[ew + 1];
+			nbits |= (L >> 31) | (R << 31);
+		}
+		uint32_t add = cand & nbits;
+		if (!add) return;
+		const uint32_t upr = cand & ~(cand + add);
+		const uint32_t rc = __brev(cand), ra = __brev(add);
+		const uint32_t dnr = __brev(rc & ~(rc + ra));
+		add |= upr | dnr;
+		ce |= add;
+		*lds = ce;      // single owner per word; neighbours may read old or new (monotone)
+		changed = 1;
+	};
 	for (;;) {
 		int changed = 0;
-		for (int i = tid; i < rows * cw; i += kResolveThreads) {
-			const int r = i / cw, k = i - r * cw;
-			const uint32_t cand = sU[i] & ~sE[(r + 1) * ew + k + 1];
-			if (!cand) continue;
-			uint32_t nb = 0;
+		e[0] = col[0];                       // the rows of the groups above / below may have moved
+		if (n > 0) {
 #pragma unroll
-			for (int dr = 0; dr < 3; ++dr) {
-				const uint32_t* row = sE + (r + dr) * ew + k;
-				const uint32_t c = row[1];
-				nb |= c | (c << 1) | (c >> 1) | (row[0] >> 31) | (row[2] << 31);
-			}
-			uint32_t add = cand & nb;
-			if (add) {
-				// extend along horizontal runs of candidates inside the word (both directions)
-				const uint32_t up = cand & ~(cand + add);
-				const uint32_t rc = __brev(cand), ra = __brev(add);
-				const uint32_t dn = __brev(rc & ~(rc + ra));
-				add |= up | dn;
-				sE[(r + 1) * ew + k + 1] |= add; // single owner per word; neighbours may read old or new (monotone)
-				changed = 1;
-			}
+			for (int j = 0; j < kResolveRows; ++j)
+				if (j == n - 1) e[j + 2] = col[(j + 2) * ew];
 		}
+#pragma unroll
+		for (int j = 0; j < kResolveRows; ++j)
+			if (j < n) visit(u[j], e[j], e[j + 1], e[j + 2], col + (j + 1) * ew, changed);
+#pragma unroll
+		for (int j = kResolveRows - 2; j >= 0; --j)
+			if (j < n) visit(u[j], e[j], e[j + 1], e[j + 2], col + (j + 1) * ew, changed);
 		if (!__syncthreads_or(changed)) break;
 	}
 
 	// write back: promoted = E_new & U_old
 	int wrote = 0;
 	uint8_t* __restrict__ out = a.out ? a.out + (size_t)frame * a.outFrameStride : nullptr;
-	for (int i = tid; i < rows * cw; i += kResolveThreads) {
-		const int r = i / cw, k = i - r * cw;
-		const uint32_t u = sU[i];
-		if (!u) continue;
-		uint32_t p = u & sE[(r + 1) * ew + k + 1];
+#pragma unroll
+	for (int j = 0; j < kResolveRows; ++j) {
+		if (j >= n || !u[j]) continue;
+		uint32_t p = u[j] & e[j + 1];
 		if (!p) continue;
-		const size_t gi = (size_t)(y0 + r) * wb + w0 + k;
-		gE[gi] = sE[(r + 1) * ew + k + 1];
-		gU[gi] = u & ~p;
+		const size_t gi = (size_t)(y0 + r0 + j) * wb + w0 + k;
+		gE[gi] = e[j + 1];
+		gU[gi] = u[j] & ~p;
 		wrote = 1;
-		if (a.out) { // byte map patched in place (only when no canny_expand_kernel pass follows)
-			uint8_t* orow = out + (size_t)(y0 + r) * a.So + (size_t)(w0 + k) * 32;
+		if (a.out) { // byte map patched in place
+			uint8_t* orow = out + (size_t)(y0 + r0 + j) * a.So + (size_t)(w0 + k) * 32;
 			while (p) {
 				const int b = __ffs(p) - 1;
 				p &= p - 1;
@@ -502,7 +521,7 @@ size_t canny_resolve_dirty_bytes(int H, int wb, int frames)
 
 size_t resolve_lds_bytes()
 {
-	return ((size_t)(kBandH + 2) * (kBandWords + 2) + (size_t)kBandH * kBandWords) * sizeof(uint32_t);
+	return (size_t)(kBandH + 2) * (kBandWords + 2) * sizeof(uint32_t);
 }
 
 hipError_t launch_canny_resolve(const ResolveArgs& a, int frames, hipStream_t stream)

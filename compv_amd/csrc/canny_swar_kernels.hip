@@ -39,7 +39,6 @@ namespace {
 
 constexpr int kSwPx = 4;                     // pixels per lane
 constexpr int kSwCols = 240;                 // output columns per wave tile (lanes 2..61)
-constexpr int kSwRows = 64;                  // output rows per wave tile
 constexpr int kRowB = 512;                   // one ring row: 256 u16 in pixel order
 // LDS of one wave (byte offsets; the g ring is 2048-aligned so that "row above / below" wraps with one AND):
 // [0, 2048): g' ring, 4 rows: row r lives in slot r & 3
@@ -84,7 +83,7 @@ __device__ __forceinline__ uint32_t nibble_bytes(uint32_t nib)
 } // namespace
 
 // ---------------------------------------------------------------------------------------------------------------
-template <bool GAP, int WAVES>
+template <bool GAP, int WAVES, int kSwRows>
 __global__ __launch_bounds__(WAVES * 64, 8) void canny_swar_tile_kernel(CannyArgs a)
 {
 	// the g rings of all waves first (2048-byte aligned), then the rest of each wave's block
@@ -351,19 +350,28 @@ __global__ __launch_bounds__(WAVES * 64, 8) void canny_swar_tile_kernel(CannyArg
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-hipError_t launch_canny_tiles_swar(const CannyArgs& a0, int frames, bool gap, hipStream_t stream)
+template <int kWaves, int kRows>
+static hipError_t launch_swar(const CannyArgs& a0, int frames, bool gap, hipStream_t stream)
 {
-	constexpr int kWaves = 1;   // one wave per workgroup: every LDS address of the kernel is lane * k + constant
 	CannyArgs a = a0;
 	a.tilesX = (a.W + kSwCols - 1) / kSwCols;
-	a.tilesY = (a.H + kSwRows - 1) / kSwRows;
+	a.tilesY = (a.H + kRows - 1) / kRows;
 	a.blockRows = (a.tilesY + kWaves - 1) / kWaves;
 	a.groups = a.blockRows * frames;
 	dim3 grid(8 * ((a.groups + 7) / 8) * a.tilesX);
 	dim3 block(kWaves * 64);
-	if (gap) hipLaunchKernelGGL((canny_swar_tile_kernel<true, kWaves>), grid, block, 0, stream, a);
-	else hipLaunchKernelGGL((canny_swar_tile_kernel<false, kWaves>), grid, block, 0, stream, a);
+	if (gap) hipLaunchKernelGGL((canny_swar_tile_kernel<true, kWaves, kRows>), grid, block, 0, stream, a);
+	else hipLaunchKernelGGL((canny_swar_tile_kernel<false, kWaves, kRows>), grid, block, 0, stream, a);
 	return hipGetLastError();
+}
+
+hipError_t launch_canny_tiles_swar(const CannyArgs& a0, int frames, bool gap, hipStream_t stream)
+{
+	// tuning knobs of the A/B runs (tools/gpu_round.sh): waves per workgroup and rows per wave tile
+	const char* ew = getenv("COMPVHIP_CANNY_WAVES"); const char* er = getenv("COMPVHIP_CANNY_ROWS");
+	const int w = ew ? atoi(ew) : 1, r = er ? atoi(er) : 64;
+	if (w == 4) return r == 32 ? launch_swar<4, 32>(a0, frames, gap, stream) : r == 128 ? launch_swar<4, 128>(a0, frames, gap, stream) : launch_swar<4, 64>(a0, frames, gap, stream);
+	return r == 32 ? launch_swar<1, 32>(a0, frames, gap, stream) : r == 128 ? launch_swar<1, 128>(a0, frames, gap, stream) : launch_swar<1, 64>(a0, frames, gap, stream);
 }
 
 } // namespace compvhip

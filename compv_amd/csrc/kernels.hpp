@@ -13,6 +13,7 @@ constexpr int kCannyWaves = 4;        // waves (= 512x64 tiles, stacked vertical
 constexpr int kBandH = 64;            // rows per resolve band
 constexpr int kBandWords = 64;        // 32-px words per resolve chunk (2048 columns): 0.056 ms per step at 4K, 0.075 ms with 128
 constexpr int kResolveThreads = 512;
+constexpr int kResolveRows = kBandH * kBandWords / kResolveThreads; // rows of one word column a resolve thread owns (8)
 
 struct CannyArgs {
 	const uint8_t* in;

@@ -39,4 +39,4 @@ def test_bench_under_torchrun_nccl_single_rank(tmp_path):
     line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
     res = json.loads(line)
     assert res["dist_backend"] == "nccl" and res["n_gpus"] == 1 and res["value"] > 0
-    assert res["lines_all_frames"] is not None and res["lines_frame0"] > 0
+    assert res["lines_last_step_all_ranks"] is not None and res["lines_frame0"] > 0
