@@ -355,6 +355,37 @@ __global__ __launch_bounds__(kResolveThreads) void canny_resolve_kernel(ResolveA
 				if (b2 >= 0 && b2 < nb && c2 >= 0 && c2 < nc) any |= prev[b2 * nc + c2];
 			}
 		if (!any) { if (tid == 0) *mine = 0; return; } // uniform
+		// This band reached its fixed point the last time it ran: only NEW edge pixels in its halo can promote anything, and only through a
+		// candidate (U) pixel of its border that touches one of them.  Look at the border first -- 6 rows and 6 word columns instead of the whole
+		// band: in round 1 nearly every neighbour has changed something, but few of those changes touch a candidate across the border.
+		int hit = 0;
+		for (int i = tid; i < 2 * cw; i += kResolveThreads) {          // top and bottom rows
+			const int bottom = i >= cw, c = bottom ? i - cw : i;
+			const int r = bottom ? rows - 1 : 0, yh = bottom ? y0 + rows : y0 - 1;   // border row of the band, halo row outside it
+			if (yh < 0 || yh >= a.H) continue;
+			const size_t gi = (size_t)(y0 + r) * wb + w0 + c;
+			const uint32_t cand = gU[gi] & ~gE[gi];
+			if (!cand) continue;
+			const uint32_t* hrow = gE + (size_t)yh * wb + w0 + c;
+			const uint32_t hc = hrow[0];
+			uint32_t nbits = hc | (hc << 1) | (hc >> 1);
+			if (w0 + c > 0) nbits |= hrow[-1] >> 31;
+			if (w0 + c + 1 < wb) nbits |= hrow[1] << 31;
+			hit |= (cand & nbits) != 0;
+		}
+		for (int i = tid; i < 2 * rows; i += kResolveThreads) {        // leftmost and rightmost word columns (chunked rows only)
+			const int right = i >= rows, r = right ? i - rows : i;
+			const int wc = right ? w0 + cw - 1 : w0, wh = right ? w0 + cw : w0 - 1;    // border word column, halo word column
+			if (wh < 0 || wh >= wb) continue;
+			const size_t gi = (size_t)(y0 + r) * wb + wc;
+			const uint32_t cand = (gU[gi] & ~gE[gi]) & (right ? 0x80000000u : 1u);
+			if (!cand) continue;
+			uint32_t h = gE[(size_t)(y0 + r) * wb + wh];
+			if (y0 + r > 0) h |= gE[(size_t)(y0 + r - 1) * wb + wh];
+			if (y0 + r + 1 < a.H) h |= gE[(size_t)(y0 + r + 1) * wb + wh];
+			hit |= right ? (h & 1u) != 0 : (h >> 31) != 0;
+		}
+		if (!__syncthreads_or(hit)) { if (tid == 0) *mine = 0; return; }
 	}
 
 	// A thread owns up to kResolveRows CONSECUTIVE rows of one word column: k = tid % cw, row group tid / cw.  Its U words and its own

@@ -6,5 +6,5 @@ R=${GRAFT_REPO_ROOT:-$PWD}
 NAME=$1; shift
 cd /tmp && export TMPDIR=/tmp
 timeout 300 rocprofv3 --kernel-trace --pmc "$@" --output-format csv -d "$R/gpurun_out/pmc_$NAME" -- \
-  python "$R/bench.py" --steps 3 --warmup 1 --no-cpu-baseline > "$R/gpurun_out/pmc_$NAME.log" 2>&1
+  python "$R/bench.py" --steps 3 --warmup 1 --reps 1 --inflight 1 --no-cpu-baseline --no-extras --no-verify > "$R/gpurun_out/pmc_$NAME.log" 2>&1
 echo "pmc $NAME exit $?" >> "$R/gpurun_out/pmc_$NAME.log"
