@@ -44,9 +44,9 @@ constexpr int kRowB = 512;                   // one ring row: 256 u16 in pixel o
 // [0, 2048): g' ring, 4 rows: row r lives in slot r & 3
 constexpr int kAux = 4 * kRowB;              // aux ring, 2 rows: row r lives in slot r & 1
 constexpr int kList = kAux + 2 * kRowB;      // candidate list of a row pair: <= 480 u16 entries
-constexpr int kMask = kList + 1024;          // mask ring, 4 rows x { weak[16 dwords], strong[16 dwords] }: dword 0 and 9 of a mask are zero pads
-constexpr int kMaskRowB = 128;
-constexpr int kLdsBytes = kMask + 4 * kMaskRowB;   // 4608 B per wave
+constexpr int kNib = kList + 1024;           // result nibbles, 4 rows x 64 bytes: byte l of a row = lane l's four pixels, weak flags in bits 0..3, strong in 4..7
+constexpr int kNibRowB = 64;
+constexpr int kLdsBytes = kNib + 4 * kNibRowB + 64;   // 4416 B per wave (the flush reads up to 8 bytes past the last row)
 
 constexpr uint32_t kBiasD = 0x01000100u;     // +256 per half: horizontal difference R - L
 constexpr uint32_t kBias1k = 0x04000400u;    // +1024 per half: gx, gy
@@ -159,9 +159,8 @@ __global__ __launch_bounds__(WAVES * 64, 8) void canny_swar_tile_kernel(CannyArg
 
 	// per-lane constants of the sparse stage
 	const uint32_t lane8 = (uint32_t)lane * 8u;            // byte offset of the lane's 4 u16 inside a ring row
-	uint32_t* const maskw = reinterpret_cast<uint32_t*>(rest + kMask);
-	auto zero_masks = [&]() { *reinterpret_cast<uint2*>(rest + kMask + lane * 8) = make_uint2(0u, 0u); }; // 4 rows x 128 B = 64 x 8 B
-	zero_masks();
+	auto zero_nibbles = [&]() { *reinterpret_cast<uint32_t*>(rest + kNib + lane * 4) = 0u; };   // 4 rows x 64 B
+	zero_nibbles();
 	uint32_t listCount = 0;                // entries in the candidate list (wave-uniform)
 
 	uint32_t nm, nl, nr;
@@ -169,7 +168,7 @@ __global__ __launch_bounds__(WAVES * 64, 8) void canny_swar_tile_kernel(CannyArg
 
 	// One row step: push input row yin = y0 - 2 + it  ->  gradient row yc = yin - 1 = y0 + (it - 3)  ->  ring slot (it - 3) & 3.
 	// After the steps with odd it >= 5 the rows 2j, 2j + 1 (j = (it - 5) / 2) of the tile have all three g rows of their neighbourhood
-	// in the ring and their candidates in the list: NMS of the pair.  After every second pair the 4-row mask ring is flushed.
+	// in the ring and their candidates in the list: NMS of the pair.  After every second pair the four result rows are flushed.
 	auto step = [&](auto phase, auto with_nms, int it) {
 		constexpr int PH = decltype(phase)::value;            // it & 3
 		constexpr bool NMS = decltype(with_nms)::value;
@@ -223,61 +222,69 @@ __global__ __launch_bounds__(WAVES * 64, 8) void canny_swar_tile_kernel(CannyArg
 			for (int base = 0; base < total; base += 64) {
 				const int jx = base + lane;
 				if (jx < total) {
-					// entry = (row parity << 9) | byte offset of the candidate inside a ring row: centre, aux and all eight neighbours are
-					// fetched at once (one LDS round trip), the direction class then picks one of four neighbour maxima
+					// entry = (row parity << 9) | byte offset of the candidate inside a ring row.  The LDS pipe, not the VALU, bounded the kernel
+					// while every candidate fetched its eight neighbours (round 3 PMC: 60 % of the LDS cycles were bank conflicts of these
+					// scattered 2-byte reads): the direction class is evaluated first, from the centre and its aux word, and only the TWO
+					// neighbours along the gradient are fetched.
 					const uint32_t e = *reinterpret_cast<const uint16_t*>(list + 2 * jx);
-					const uint32_t eU = (e + (uint32_t)(sA * kRowB + 3 * kRowB)) & (4u * kRowB - 1u);   // row above (ring wraps)
+					const uint32_t cAbs = e + (uint32_t)(sA * kRowB);                                    // ring offset of the centre
+					const uint32_t eU = (e + (uint32_t)(sA * kRowB + 3 * kRowB)) & (4u * kRowB - 1u);   // same column, row above (ring wraps)
 					const uint32_t eD = (e + (uint32_t)(sA * kRowB + kRowB)) & (4u * kRowB - 1u);       // row below
-					const uint8_t* const gC = ring + sA * kRowB + e;
-					const uint8_t* const gU = ring + eU;
-					const uint8_t* const gD = ring + eD;
-					const int gc = *reinterpret_cast<const uint16_t*>(gC);
+					const int gc = *reinterpret_cast<const uint16_t*>(ring + sA * kRowB + e);
 					const uint32_t au = *reinterpret_cast<const uint16_t*>(rest + kAux + e);
-					const int nL = *reinterpret_cast<const uint16_t*>(gC - 2), nR = *reinterpret_cast<const uint16_t*>(gC + 2);
-					const int nU = *reinterpret_cast<const uint16_t*>(gU), nD = *reinterpret_cast<const uint16_t*>(gD);
-					const int nUL = *reinterpret_cast<const uint16_t*>(gU - 2), nUR = *reinterpret_cast<const uint16_t*>(gU + 2);
-					const int nDL = *reinterpret_cast<const uint16_t*>(gD - 2), nDR = *reinterpret_cast<const uint16_t*>(gD + 2);
 					const uint32_t ax = au & 0x3ffu;
 					const uint32_t ays = (uint32_t)(gc - 2048 - (int)ax) << 16;      // |gy| << 16
 					// direction class (constants canny_dete.h:58-61: tan(pi/8), tan(3pi/8) in Q16; 158217 = 27145 + 2^17)
 					const uint32_t t1 = __umul24(ax, 27145u);
 					const bool k1 = ays < t1;
 					const bool k2 = ays < t1 + (ax << 17);
-					const bool ngd = (au & 0x400u) != 0;
-					// neighbours along the gradient: k1 left/right; k2 diagonal ((gx^gy) < 0: (y+1,x-1),(y-1,x+1), else (y-1,x-1),(y+1,x+1)); else up/down
-					const int mh = max(nL, nR), mv = max(nU, nD), md1 = max(nUL, nDR), md2 = max(nDL, nUR);
-					const int md = ngd ? md2 : md1;
-					const int mx2 = k1 ? mh : (k2 ? md : mv);
-					bool weak = gc >= mx2;          // not suppressed: neither neighbour strictly greater (candidates already have g > tLow)
+					const bool dg = k2 && ((au & 0x400u) != 0);
+					// neighbours along the gradient: k1 left / right; k2 diagonal ((gx^gy) < 0: (y+1,x-1),(y-1,x+1), else (y-1,x-1),(y+1,x+1)); else up / down,
+					// i.e. (X - d, Y + d) with (X, Y, d) = (C, C, 2) | (D, U, 2) | (U, D, 2) | (U, D, 0)
+					uint32_t X = dg ? eD : eU, Y = dg ? eU : eD;
+					X = k1 ? cAbs : X; Y = k1 ? cAbs : Y;
+					const uint32_t dl = k2 ? 2u : 0u;
+					const int n1 = *reinterpret_cast<const uint16_t*>(ring + (X - dl)), n2 = *reinterpret_cast<const uint16_t*>(ring + (Y + dl));
+					bool weak = gc >= max(n1, n2);  // not suppressed: neither neighbour strictly greater (candidates already have g > tLow)
 					bool strong = gc > tHighQ;
-					const int c = (int)((e >> 1) & 255u);   // local column 0..255
+					const uint32_t c = (e >> 1) & 255u;   // local column 0..255
 					if (GAP) { // quirk Q3: column coverage of the NMS and of the seed scan, [1,simdEnd) U [cStart,W-1) (canny_dete.cxx:396,514)
-						const int x = xbase + c;
+						const int x = xbase + (int)c;
 						const bool in_cov = (x >= 1 && x < a.simdEnd) || (x >= a.cStart && x < W - 1);
 						weak = weak || !in_cov;       // outside the NMS coverage: thresholded only, never a seed
 						strong = strong && in_cov;
 					}
-					const uint32_t bit = 1u << (c & 31);
-					// mask ring row = sA + row parity = (sA * 512 + e) >> 9; word (c >> 5) of the mask lives in dword 1 + (c >> 5)
-					uint32_t* const mw = reinterpret_cast<uint32_t*>(rest + kMask + sA * kMaskRowB + 4) + ((e >> 9) << 5) + (c >> 5);
+					// result: bit (c & 3) (weak) and 4 + (c & 3) (strong) of byte (c >> 2) of nibble row sA + parity = cAbs >> 9.  One dword holds four
+					// lanes: candidates of one instruction rarely share it (the mask-word atomics of the previous version put 8 lanes on one address)
 					if (weak) {
-						atomicOr(mw, bit);
-						if (strong) atomicOr(mw + 16, bit);
+						uint32_t* const nw = reinterpret_cast<uint32_t*>(rest + kNib) + ((cAbs >> 9) << 4) + (c >> 4);
+						atomicOr(nw, (strong ? 0x11u : 0x01u) << ((c & 3u) | ((c & 12u) << 1)));
 					}
 				}
 			}
 			listCount = 0;
 			if constexpr (PH == 3) {
 				// rows 4m .. 4m + 3 of the tile are classified: masks and edge bytes leave in their final global layout
-				const int rr0 = it - 7;                          // tile row of mask ring slot 0
+				const int rr0 = it - 7;                          // tile row of nibble row 0
 				__builtin_amdgcn_wave_barrier();
+				const uint32_t* const nibw = reinterpret_cast<const uint32_t*>(rest + kNib);
 				{
-					// masks: lanes 0..31 the U rows (weak & ~strong), 32..63 the E rows (strong), whole row segments per store instruction
+					// masks: lanes 0..31 the U rows (weak & ~strong), 32..63 the E rows (strong), whole row segments per store instruction.  Global
+					// dword d0 + dl = the pixels of lanes [8 dl + 2, 8 dl + 10) (even tiles) or [8 dl - 2, 8 dl + 6) (odd): 8 result bytes that start
+					// in the middle of a dword (the bytes of a neighbouring tile's columns, or of the next row, end in a half-word that is not stored)
 					const int mi = lane >> 5, q = (lane >> 3) & 3, dl = lane & 7;
-					const uint32_t* rw = maskw + q * 32 + 1 + dl - odd;      // local dwords dl - odd, dl - odd + 1 of the weak mask (dword -1 / 8: zero pads)
-					const uint32_t w0 = rw[0], w1 = rw[1], s0 = rw[16], s1 = rw[17];
-					const uint32_t lo = mi ? s0 : (w0 & ~s0), hi = mi ? s1 : (w1 & ~s1);
-					const uint32_t v = odd ? __builtin_amdgcn_alignbit(hi, lo, 24) : __builtin_amdgcn_alignbit(hi, lo, 8);
+					const uint32_t* rn = nibw + q * 16 + 2 * dl - odd;
+					const uint32_t d0w = rn[0], d1w = rn[1], d2w = rn[2];
+					uint32_t v = 0;
+#pragma unroll
+					for (int hh = 0; hh < 2; ++hh) {
+						const uint32_t by = hh ? __builtin_amdgcn_alignbit(d2w, d1w, 16) : __builtin_amdgcn_alignbit(d1w, d0w, 16);  // 4 lanes = 16 pixels
+						const uint32_t wk = by & 0x0f0f0f0fu, st = (by >> 4) & 0x0f0f0f0fu;
+						uint32_t t = mi ? st : (wk & ~st);                       // E = strong, U = weak & ~strong
+						t = (t | (t >> 4)) & 0x00ff00ffu;
+						t = (t | (t >> 8)) & 0x0000ffffu;
+						v |= t << (16 * hh);
+					}
 					const int row = y0 + rr0 + q, gd = d0 + dl;
 					if (row < H && gd < a.wb) {
 						uint32_t* dst = (mi ? ebase : ubase) + (size_t)row * a.wb + gd;
@@ -287,24 +294,25 @@ __global__ __launch_bounds__(WAVES * 64, 8) void canny_swar_tile_kernel(CannyArg
 					}
 				}
 				{
-					// edge bytes of the strong pixels (the resolve rounds add the promoted ones): lane = (row q, 16-pixel group gi): one 16-byte store
+					// edge bytes of the strong pixels (the resolve rounds add the promoted ones): lane = (row q, 16-pixel group gi = lanes 2 + 4 gi .. 5 + 4 gi):
+					// one 16-byte store
 					const int q = lane >> 4, gi = lane & 15;
-					const uint32_t* rs = maskw + q * 32 + 16 + 1 + (gi >> 1);   // strong mask: local bits 8 + 16 gi .. 23 + 16 gi
-					const uint32_t bits16 = __builtin_amdgcn_alignbit(rs[1], rs[0], (gi & 1) ? 24 : 8) & 0xffffu;
+					const uint32_t* rn = nibw + q * 16 + gi;
+					const uint32_t by = __builtin_amdgcn_alignbit(rn[1], rn[0], 16);
 					const int row = y0 + rr0 + q;
 					const int x = tileX * kSwCols + gi * 16;
 					if (gi < 15 && row < H && x + 8 <= a.So) {
 						uint8_t* dst = obase + (size_t)row * a.So + x;
-						const uint32_t b0 = nibble_bytes(bits16 & 0xfu), b1 = nibble_bytes((bits16 >> 4) & 0xfu);
+						const uint32_t b0 = nibble_bytes((by >> 4) & 0xfu), b1 = nibble_bytes((by >> 12) & 0xfu);
 						if (x + 16 <= a.So) {
-							const uint32_t b2 = nibble_bytes((bits16 >> 8) & 0xfu), b3 = nibble_bytes(bits16 >> 12);
+							const uint32_t b2 = nibble_bytes((by >> 20) & 0xfu), b3 = nibble_bytes(by >> 28);
 							*reinterpret_cast<uint4*>(dst) = make_uint4(b0, b1, b2, b3);
 						}
 						else *reinterpret_cast<uint2*>(dst) = make_uint2(b0, b1); // So % 8 == 0: an 8-column tail
 					}
 				}
 				__builtin_amdgcn_wave_barrier();
-				zero_masks();
+				zero_nibbles();
 			}
 			__builtin_amdgcn_wave_barrier();
 		}
