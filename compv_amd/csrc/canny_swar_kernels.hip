@@ -44,7 +44,7 @@ constexpr int kRowB = 512;                   // one ring row: 256 u16 in pixel o
 // [0, 2048): g' ring, 4 rows: row r lives in slot r & 3
 constexpr int kAux = 4 * kRowB;              // aux ring, 2 rows: row r lives in slot r & 1
 constexpr int kList = kAux + 2 * kRowB;      // candidate list of a row pair: <= 480 u16 entries
-constexpr int kNib = kList + 1024;           // result nibbles, 4 rows x 64 bytes: byte l of a row = lane l's four pixels, weak flags in bits 0..3, strong in 4..7
+constexpr int kNib = kList + 1024;           // result nibbles, 4 rows x 64 bytes: byte l of a row = lane l's four pixels, U flags (weak, not strong) in bits 0..3, E flags (strong) in 4..7
 constexpr int kNibRowB = 64;
 constexpr int kLdsBytes = kNib + 4 * kNibRowB + 64;   // 4416 B per wave (the flush reads up to 8 bytes past the last row)
 
@@ -121,10 +121,10 @@ __global__ __launch_bounds__(WAVES * 64, 8) void canny_swar_tile_kernel(CannyArg
 			okm[k] = ((xa >= 1 && xa <= W - 2) ? 0x0000ffffu : 0u) | ((xb >= 1 && xb <= W - 2) ? 0xffff0000u : 0u);
 		}
 	}
-	// lanes 0, 1, 62, 63 own no pixels (column halo): their copy of g' for the candidate test is zeroed
+	// lanes 0, 1, 62, 63 own no pixels (column halo): their candidate threshold is out of reach
 	const bool owner = (lane >= 2 && lane <= 61);
-	uint32_t ownv = owner ? 0xffffffffu : 0u;
-	asm volatile("" : "+v"(ownv));
+	uint32_t thrV = owner ? (uint32_t)tLowQ : 0xffffu;
+	asm volatile("" : "+v"(thrV));
 	// tiles whose gradient rows touch the image border rows (g forced to 0 there) or run past the image
 	const bool vEdgeTile = (tileY == 0) || (y0 + kSwRows + 1 >= H - 1);
 	const bool borderTile = edgeTile || vEdgeTile;
@@ -204,7 +204,8 @@ __global__ __launch_bounds__(WAVES * 64, 8) void canny_swar_tile_kernel(CannyArg
 			aux[k] = bfi(kBias1k, gxb ^ gyb, mx);                      // bits 0..9 |gx|, bit 10 = ((gx ^ gy) < 0)
 		}
 		const int yc = yin - 1;
-		if (borderTile) { // one wave-uniform test per row; interior tiles skip all of it
+		if (borderTile) { // one wave-uniform test per row; interior tiles skip all of it (the empty asm keeps the compiler from turning the branch into selects)
+			asm volatile("" : "+v"(gq[0]), "+v"(gq[1]));
 			const uint32_t rowm = (yc >= 1 && yc <= H - 2) ? 0xffffffffu : 0u; // image border rows (and rows past the image): g = 0
 #pragma unroll
 			for (int k = 0; k < 2; ++k) gq[k] = bfi(okm[k] & rowm, gq[k], kBias2k);
@@ -254,11 +255,11 @@ __global__ __launch_bounds__(WAVES * 64, 8) void canny_swar_tile_kernel(CannyArg
 						weak = weak || !in_cov;       // outside the NMS coverage: thresholded only, never a seed
 						strong = strong && in_cov;
 					}
-					// result: bit (c & 3) (weak) and 4 + (c & 3) (strong) of byte (c >> 2) of nibble row sA + parity = cAbs >> 9.  One dword holds four
-					// lanes: candidates of one instruction rarely share it (the mask-word atomics of the previous version put 8 lanes on one address)
+					// result: bit (c & 3) (U: weak, not strong) or 4 + (c & 3) (E: strong) of byte (c >> 2) of nibble row sA + parity = cAbs >> 9.  One dword
+					// holds four lanes: candidates of one instruction rarely share it (the mask-word atomics of the previous version put 8 lanes on one address)
 					if (weak) {
 						uint32_t* const nw = reinterpret_cast<uint32_t*>(rest + kNib) + ((cAbs >> 9) << 4) + (c >> 4);
-						atomicOr(nw, (strong ? 0x11u : 0x01u) << ((c & 3u) | ((c & 12u) << 1)));
+						atomicOr(nw, (strong ? 0x10u : 0x01u) << ((c & 3u) | ((c & 12u) << 1)));
 					}
 				}
 			}
@@ -275,16 +276,16 @@ __global__ __launch_bounds__(WAVES * 64, 8) void canny_swar_tile_kernel(CannyArg
 					const int mi = lane >> 5, q = (lane >> 3) & 3, dl = lane & 7;
 					const uint32_t* rn = nibw + q * 16 + 2 * dl - odd;
 					const uint32_t d0w = rn[0], d1w = rn[1], d2w = rn[2];
-					uint32_t v = 0;
+					const uint32_t nsh = (uint32_t)mi * 4u;                          // U: low nibbles, E: high nibbles
+					uint32_t th[2];
 #pragma unroll
 					for (int hh = 0; hh < 2; ++hh) {
 						const uint32_t by = hh ? __builtin_amdgcn_alignbit(d2w, d1w, 16) : __builtin_amdgcn_alignbit(d1w, d0w, 16);  // 4 lanes = 16 pixels
-						const uint32_t wk = by & 0x0f0f0f0fu, st = (by >> 4) & 0x0f0f0f0fu;
-						uint32_t t = mi ? st : (wk & ~st);                       // E = strong, U = weak & ~strong
+						uint32_t t = (by >> nsh) & 0x0f0f0f0fu;
 						t = (t | (t >> 4)) & 0x00ff00ffu;
-						t = (t | (t >> 8)) & 0x0000ffffu;
-						v |= t << (16 * hh);
+						th[hh] = (t | (t >> 8)) & 0x0000ffffu;
 					}
+					const uint32_t v = th[0] | (th[1] << 16);
 					const int row = y0 + rr0 + q, gd = d0 + dl;
 					if (row < H && gd < a.wb) {
 						uint32_t* dst = (mi ? ebase : ubase) + (size_t)row * a.wb + gd;
@@ -327,9 +328,9 @@ __global__ __launch_bounds__(WAVES * 64, 8) void canny_swar_tile_kernel(CannyArg
 			uint32_t cnt = listCount;
 #pragma unroll
 			for (int p = 0; p < kSwPx; ++p) {
-				const uint32_t gk = gq[p >> 1] & ownv;
+				const uint32_t gk = gq[p >> 1];
 				const uint32_t gp = (p & 1) ? (gk >> 16) : (gk & 0xffffu);
-				const bool c = gp > (uint32_t)tLowQ;
+				const bool c = gp > thrV;
 				const uint64_t mk = __ballot(c);
 				if (c) {
 					const uint32_t rk = __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, cnt));

@@ -9,6 +9,10 @@ tail -4 $O/pytest.log
 B="python bench.py --no-cpu-baseline --no-extras"
 $B > $O/bench_default.json 2> $O/bench_default.err
 $B --inflight 1 > $O/bench_inflight1.json 2> $O/bench_inflight1.err
+for r in 32 128; do
+  COMPVHIP_CANNY_ROWS=$r $B --reps 3 --no-verify > $O/bench_r${r}.json 2> $O/bench_r${r}.err
+  COMPVHIP_CANNY_ROWS=$r $B --inflight 1 --reps 3 --no-verify > $O/bench_r${r}_inflight1.json 2> $O/bench_r${r}_inflight1.err
+done
 for f in $O/bench_*.json; do python - "$f" <<'PY'
 import json,sys
 try:
@@ -18,7 +22,3 @@ except Exception as e:
     print(sys.argv[1], "FAILED", e)
 PY
 done
-bash tools/pmc_pass.sh ${TAG}_sq1 SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY
-bash tools/pmc_pass.sh ${TAG}_sq2 SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_ANY SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_INSTS_VMEM_RD SQ_INSTS_SMEM
-python tools/pmc_summary.py gpurun_out/pmc_${TAG}_sq1 gpurun_out/pmc_${TAG}_sq2 > $O/pmc_summary.txt 2>&1
-grep -A18 "canny_swar\|canny_resolve" $O/pmc_summary.txt | head -60
