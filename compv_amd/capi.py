@@ -38,7 +38,7 @@ EXPORTS = [
     "compvhip_houghkht_u8", "compvhip_grayscale_u8", "compvhip_otsu_u8", "compvhip_plan_grayscale", "compvhip_plan_otsu",
     "compvhip_gauss_kernel_fixedpoint", "compvhip_convlt1_fixedpoint_u8", "compvhip_plan_convlt1_fixedpoint", "compvhip_plan_to_cartesian",
     "compvhip_plan_pipeline_async", "compvhip_plan_wait", "compvhip_houghsht_to_cartesian", "compvhip_houghkht_to_cartesian",
-    "compvhip_houghkht_kernels_u8", "compvhip_houghkht_stage_ms",
+    "compvhip_houghkht_kernels_u8", "compvhip_houghkht_stage_ms", "compvhip_convlt1_8u16s16s", "compvhip_convlt1_16s16s16s",
 ]
 
 
@@ -113,6 +113,8 @@ def load():
     L.compvhip_gauss_kernel_fixedpoint.argtypes = [sz, C.c_float, vp]
     L.compvhip_convlt1_fixedpoint_u8.argtypes = [vp, vp, sz, sz, sz, vp, vp, sz, vp, sz]
     L.compvhip_plan_convlt1_fixedpoint.argtypes = [vp, vp, vp, vp, sz, vp, vp]
+    L.compvhip_convlt1_8u16s16s.argtypes = [vp, vp, sz, sz, sz, vp, vp, sz, vp, sz]
+    L.compvhip_convlt1_16s16s16s.argtypes = [vp, vp, sz, sz, sz, vp, vp, sz, vp, sz]
     L.compvhip_plan_pipeline.argtypes = [vp, vp, C.c_float, C.c_float, i32, i32, vp, vp, sz, vp, vp]
     L.compvhip_plan_pipeline_async.argtypes = [vp, vp, C.c_float, C.c_float, i32, i32, vp, vp, sz, vp, vp, C.POINTER(i32)]
     L.compvhip_plan_wait.argtypes = [vp, i32]
@@ -183,6 +185,17 @@ class Context:
         vt = np.ascontiguousarray(vt, np.uint16); hz = np.ascontiguousarray(hz, np.uint16)
         out = np.empty((H, W), np.uint8)
         self._chk(self.lib.compvhip_convlt1_fixedpoint_u8(self.h, _ptr(img), W, H, img.strides[0], _ptr(vt), _ptr(hz), len(vt), _ptr(out), W))
+        return out
+
+    def convlt1_i16(self, img, vt, hz):
+        """CompVMathConvlt::convlt1<u8|s16, s16, s16>: separable integer correlation, int16 out (img: uint8 or int16, C-contiguous rows)."""
+        H, W = img.shape
+        vt = np.ascontiguousarray(vt, np.int16); hz = np.ascontiguousarray(hz, np.int16)
+        assert len(vt) == len(hz)
+        out = np.zeros((H, W), np.int16)
+        fn = self.lib.compvhip_convlt1_8u16s16s if img.dtype == np.uint8 else self.lib.compvhip_convlt1_16s16s16s
+        assert img.dtype in (np.uint8, np.int16)
+        self._chk(fn(self.h, _ptr(img), W, H, img.strides[0] // img.itemsize, _ptr(vt), _ptr(hz), len(vt), _ptr(out), W))
         return out
 
     def otsu(self, img):

@@ -1085,6 +1085,47 @@ int compvhip_convlt1_fixedpoint_u8(compvhip_ctx* ctx, const uint8_t* in, size_t 
 	return COMPVHIP_OK;
 }
 
+// CompVMathConvlt::convlt1<uint8_t | int16_t, int16_t, int16_t> (compv_math_convlt.h:26-28,37-39,98-292): the separable integer correlation the
+// gradient is made of, stand-alone.  The device buffers are private to the call (the operator is not on the per-frame hot path: there it is
+// fused into the tile kernels); S, So in elements.
+static int convlt1I16(compvhip_ctx* ctx, const void* in, bool inIsU8, size_t W, size_t H, size_t S, const int16_t* vtKern, const int16_t* hzKern, size_t kernSize,
+                      int16_t* out, size_t So)
+{
+	if (!ctx) return COMPVHIP_E_INVALID_PARAMETER;
+	if (!in || !out || !vtKern || !hzKern || S < W || So < W || !(kernSize & 1) || W < kernSize || H < kernSize)
+		return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "convolution: null pointer, stride < width, even kernel size or image smaller than the kernel"); // compv_math_convlt.h:100
+	if (kernSize > static_cast<size_t>(kFxpMaxTaps)) return fail(ctx, COMPVHIP_E_NOT_IMPLEMENTED, "integer convolution supports kernel sizes 1..15");
+	if (W > 32767 || H > 32767) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "image size out of range");
+	HIPCHK(ctx, hipSetDevice(ctx->device));
+	const size_t es = inIsU8 ? 1 : 2;
+	const size_t Sd = alignUp(W, 64);
+	uint8_t* dIn = nullptr; int16_t* dTmp = nullptr; int16_t* dOut = nullptr;
+	int rc = COMPVHIP_OK;
+	do {
+		if (dmalloc(ctx, &dIn, Sd * H * es) != hipSuccess || dmalloc(ctx, &dTmp, Sd * H) != hipSuccess || dmalloc(ctx, &dOut, Sd * H) != hipSuccess) { rc = fail(ctx, COMPVHIP_E_OUT_OF_MEMORY, "convolution buffers"); break; }
+		hipError_t e = hipMemcpy2DAsync(dIn, Sd * es, in, S * es, W * es, H, hipMemcpyHostToDevice, ctx->stream);
+		if (e == hipSuccess) e = launch_convlt_i16(dIn, inIsU8, dTmp, dOut, static_cast<int>(W), static_cast<int>(H), static_cast<int>(Sd), static_cast<int>(Sd), vtKern, hzKern,
+		                                           static_cast<int>(kernSize), ctx->stream);
+		if (e == hipSuccess) e = hipMemcpy2DAsync(out, So * 2, dOut, Sd * 2, W * 2, H, hipMemcpyDeviceToHost, ctx->stream);
+		if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+		if (e != hipSuccess) rc = fail(ctx, COMPVHIP_E_HIP, "integer convolution", e);
+	} while (0);
+	dfree(ctx, dIn); dfree(ctx, dTmp); dfree(ctx, dOut);
+	return rc;
+}
+
+int compvhip_convlt1_8u16s16s(compvhip_ctx* ctx, const uint8_t* in, size_t W, size_t H, size_t S, const int16_t* vtKern, const int16_t* hzKern, size_t kernSize,
+                              int16_t* out, size_t So)
+{
+	return convlt1I16(ctx, in, true, W, H, S, vtKern, hzKern, kernSize, out, So);
+}
+
+int compvhip_convlt1_16s16s16s(compvhip_ctx* ctx, const int16_t* in, size_t W, size_t H, size_t S, const int16_t* vtKern, const int16_t* hzKern, size_t kernSize,
+                               int16_t* out, size_t So)
+{
+	return convlt1I16(ctx, in, false, W, H, S, vtKern, hzKern, kernSize, out, So);
+}
+
 int compvhip_grayscale_u8(compvhip_ctx* ctx, const uint8_t* in, int pixfmt, size_t W, size_t H, size_t S, uint8_t* out, size_t So)
 {
 	if (!ctx) return COMPVHIP_E_INVALID_PARAMETER;

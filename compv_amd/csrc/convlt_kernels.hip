@@ -208,4 +208,79 @@ hipError_t launch_convlt_fxp(const uint8_t* in, uint8_t* tmp, uint8_t* out, int 
 	}
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+// Integer separable correlation, int16 out: CompVMathConvlt::convlt1<uint8_t, int16_t, int16_t> and <int16_t, int16_t, int16_t>
+// (base/include/compv/base/math/compv_math_convlt.h:26-28,37-39; driver :98-173, hz :176-229, vt :232-292; AVX2 leaf
+// base/math/intrin/x86/compv_math_convlt_intrin_avx2.cxx:314-430: int32 sums, packs = signed saturation).  This is the operator the
+// gradient of the path is made of (canny_dete.cxx:237-241) -- there it is fused into the tile kernels and never materialised; these two
+// kernels are its stand-alone form (compvhip_convlt1_8u16s16s / _16s16s16s), generic in the (odd) kernel size.  Horizontal pass into an
+// int16 temporary (zero columns [0, r) and [W - r, W)), vertical pass over it (zero rows [0, r) and [H - r, H)), both saturating.
+// One thread = 4 adjacent outputs of one row; the taps are wave-uniform kernel arguments.
+// ---------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ int sat16i(int v) { return min(max(v, -32768), 32767); }
+
+template <typename TIn>
+__global__ __launch_bounds__(256) void convlt_i16_hz_kernel(I16Args a)
+{
+	const int y = blockIdx.y;
+	const int x0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+	if (x0 >= a.W) return;
+	const int r = a.K >> 1;
+	const TIn* __restrict__ row = reinterpret_cast<const TIn*>(a.in) + (size_t)y * a.S;
+	int16_t* __restrict__ dst = a.out + (size_t)y * a.So;
+	int v[4 + kFxpMaxTaps - 1];
+#pragma unroll
+	for (int j = 0; j < 4 + kFxpMaxTaps - 1; ++j) {
+		const int x = x0 - r + j;
+		v[j] = (j < 4 + a.K - 1 && x >= 0 && x < a.W) ? (int)row[x] : 0;
+	}
+#pragma unroll
+	for (int j = 0; j < 4; ++j) {
+		const int x = x0 + j;
+		if (x >= a.W) break;
+		int sum = 0;
+#pragma unroll
+		for (int t = 0; t < kFxpMaxTaps; ++t) if (t < a.K) sum += v[j + t] * a.kern[t];
+		dst[x] = (x < r || x >= a.W - r) ? (int16_t)0 : (int16_t)sat16i(sum);
+	}
+}
+
+__global__ __launch_bounds__(256) void convlt_i16_vt_kernel(I16Args a)
+{
+	const int y = blockIdx.y;
+	const int x0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+	if (x0 >= a.W) return;
+	const int r = a.K >> 1;
+	const int16_t* __restrict__ src = reinterpret_cast<const int16_t*>(a.in);
+	int16_t* __restrict__ dst = a.out + (size_t)y * a.So;
+	const bool border = (y < r || y >= a.H - r);
+	int sum[4] = { 0, 0, 0, 0 };
+	if (!border) {
+		for (int t = 0; t < a.K; ++t) {
+			const int16_t* __restrict__ row = src + (size_t)(y - r + t) * a.S;
+			const int k = a.kern[t];
+#pragma unroll
+			for (int j = 0; j < 4; ++j) if (x0 + j < a.W) sum[j] += (int)row[x0 + j] * k;
+		}
+	}
+#pragma unroll
+	for (int j = 0; j < 4; ++j) if (x0 + j < a.W) dst[x0 + j] = border ? (int16_t)0 : (int16_t)sat16i(sum[j]);
+}
+
+// in (u8 when inIsU8, else s16; stride S elements) -> tmp (s16, stride W rounded up) -> out (s16, stride So)
+hipError_t launch_convlt_i16(const void* in, bool inIsU8, int16_t* tmp, int16_t* out, int W, int H, int S, int So, const int16_t* vtKern, const int16_t* hzKern,
+                             int K, hipStream_t stream)
+{
+	if (K < 1 || K > kFxpMaxTaps || !(K & 1)) return hipErrorInvalidValue;
+	I16Args hz, vt;
+	hz.in = in; hz.out = tmp; hz.W = W; hz.H = H; hz.S = S; hz.So = So; hz.K = K;
+	vt.in = tmp; vt.out = out; vt.W = W; vt.H = H; vt.S = So; vt.So = So; vt.K = K;
+	for (int t = 0; t < kFxpMaxTaps; ++t) { hz.kern[t] = t < K ? hzKern[t] : 0; vt.kern[t] = t < K ? vtKern[t] : 0; }
+	const dim3 grid((unsigned)((W + 1023) / 1024), (unsigned)H);
+	if (inIsU8) hipLaunchKernelGGL((convlt_i16_hz_kernel<uint8_t>), grid, dim3(256), 0, stream, hz);
+	else hipLaunchKernelGGL((convlt_i16_hz_kernel<int16_t>), grid, dim3(256), 0, stream, hz);
+	hipLaunchKernelGGL(convlt_i16_vt_kernel, grid, dim3(256), 0, stream, vt);
+	return hipGetLastError();
+}
+
 } // namespace compvhip

@@ -86,6 +86,16 @@ struct FxpArgs {
 hipError_t launch_convlt_fxp(const uint8_t* in, uint8_t* tmp, uint8_t* out, int W, int H, int S, size_t frameStride, int frames, const uint16_t* vtKern,
                              const uint16_t* hzKern, int K, hipStream_t stream);
 
+// integer separable correlation, int16 out (CompVMathConvlt::convlt1<u8|s16, s16, s16>)
+struct I16Args {
+	const void* in;           // u8 or s16 rows of S elements
+	int16_t* out;             // s16 rows of So elements
+	int W, H, S, So, K;
+	int kern[kFxpMaxTaps];    // taps of this pass
+};
+hipError_t launch_convlt_i16(const void* in, bool inIsU8, int16_t* tmp, int16_t* out, int W, int H, int S, int So, const int16_t* vtKern, const int16_t* hzKern,
+                             int K, hipStream_t stream);
+
 // ---- Hough SHT ---------------------------------------------------------------------------------------------
 struct ShtArgs {
 	const uint32_t* ebits;    // edge bit masks [frames][H][wb]

@@ -127,6 +127,17 @@ COMPVHIP_API int compvhip_gauss_kernel_fixedpoint(size_t size, float sigma, uint
 COMPVHIP_API int compvhip_convlt1_fixedpoint_u8(compvhip_ctx* ctx, const uint8_t* in, size_t W, size_t H, size_t S,
                                                 const uint16_t* vtKern, const uint16_t* hzKern, size_t kernSize, uint8_t* out, size_t So);
 
+/* CompVMathConvlt::convlt1<uint8_t, int16_t, int16_t> and <int16_t, int16_t, int16_t> (base/include/compv/base/math/compv_math_convlt.h:26-28,
+ * 37-39; driver :98-173, passes :176-292): separable integer CORRELATION (no kernel flip), horizontal pass with hzKern then vertical pass
+ * with vtKern through an int16 temporary, int32 sums saturated to int16 after each pass, zero OUTPUT border of kernSize/2 columns and
+ * rows.  The operator the Sobel / Scharr / Prewitt gradients are made of (gx: vt = smoothing, hz = derivative; canny_dete.cxx:237-241);
+ * on the hot path it is fused into the tile kernels, this is its stand-alone form (reference known-answer vectors:
+ * unittests/math_convlt.cxx:24-25).  kernSize odd, 1..15 (larger: COMPVHIP_E_NOT_IMPLEMENTED), W,H >= kernSize; S, So in ELEMENTS. */
+COMPVHIP_API int compvhip_convlt1_8u16s16s(compvhip_ctx* ctx, const uint8_t* in, size_t W, size_t H, size_t S,
+                                           const int16_t* vtKern, const int16_t* hzKern, size_t kernSize, int16_t* out, size_t So);
+COMPVHIP_API int compvhip_convlt1_16s16s16s(compvhip_ctx* ctx, const int16_t* in, size_t W, size_t H, size_t S,
+                                            const int16_t* vtKern, const int16_t* hzKern, size_t kernSize, int16_t* out, size_t So);
+
 /* CompVHoughSht::process (core/features/hough/compv_core_feature_houghsht.cxx:96-262).  rho must be 1 (:306-316),
  * thetaDeg in degrees, threshold > 0 is the NMS/line threshold, maxLines <= 0 keeps every line.
  * lines: caller-allocated, capacity cap; *n receives the number of lines found (after the maxLines cut); if *n > cap

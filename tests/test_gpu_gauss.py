@@ -78,3 +78,43 @@ def test_plan_blur_then_canny_batch(hip_ctx, oracle):
             assert (e[f][:, :W] == exp[f][1]).all(), f
     finally:
         plan.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# integer separable correlation: the reference's own known-answer vectors on the GPU
+# ---------------------------------------------------------------------------------------------------------------
+def test_convlt1_int16_reference_known_answers_on_the_gpu(hip_ctx):
+    """unittests/math_convlt.cxx:24-25, cases 5 and 6 (1285x720, stride 1344, k = 7, data (i*j)+53 with alternating signs for the int16
+    case): MD5 of the int16 result -- the only reference-held golden vectors on the hot path's operators -- from the HIP kernels."""
+    from test_oracle import _convlt_inputs
+    from oracle_bindings import md5_rows
+    d8, d16, k = _convlt_inputs()
+    assert md5_rows(hip_ctx.convlt1_i16(d8, k, k)) == "7f1116ade2a1cdb37842084c781ee05e"
+    assert md5_rows(hip_ctx.convlt1_i16(d16, k, k)) == "cad2f4d2fd66e171997f39804e667699"
+
+
+@pytest.mark.parametrize("W,H,K", [(9, 9, 3), (64, 33, 5), (257, 65, 1), (301, 200, 15), (1282, 70, 9)])
+def test_convlt1_int16_matches_oracle(hip_ctx, oracle, W, H, K):
+    """Generic odd kernel sizes, both input types, saturation included (weights up to +-32767 overflow int16 on purpose), and the gradient
+    of the path as two calls: gx = (vt smoothing, hz derivative), gy swapped (canny_dete.cxx:237-241)."""
+    from compv_amd import capi
+    rng = np.random.default_rng(W * 7 + K)
+    img8 = rng.integers(0, 256, (H, W), dtype=np.uint8)
+    img16 = rng.integers(-32768, 32768, (H, W), dtype=np.int16)
+    for scale in (3, 32767):
+        vt = rng.integers(-scale, scale + 1, K).astype(np.int16)
+        hz = rng.integers(-scale, scale + 1, K).astype(np.int16)
+        rc, exp = oracle.convlt_8u(img8, vt, hz)
+        assert rc == 0 and (hip_ctx.convlt1_i16(img8, vt, hz) == exp).all()
+        rc, exp = oracle.convlt_16s(img16, vt, hz)
+        assert rc == 0 and (hip_ctx.convlt1_i16(img16, vt, hz) == exp).all()
+    if K == 3:
+        gx_exp, gy_exp, _ = oracle.gradient(img8, 0)
+        assert (hip_ctx.convlt1_i16(img8, [1, 2, 1], [-1, 0, 1]) == gx_exp).all()
+        assert (hip_ctx.convlt1_i16(img8, [-1, 0, 1], [1, 2, 1]) == gy_exp).all()
+    with pytest.raises(capi.CompvHipError) as e:
+        hip_ctx.convlt1_i16(img8[:2], [1, 2, 1], [1, 2, 1])          # H < k (compv_math_convlt.h:100)
+    assert e.value.code == capi.E_INVALID_PARAMETER
+    with pytest.raises(capi.CompvHipError) as e:
+        hip_ctx.convlt1_i16(img8, [1, 2], [1, 2])                    # even kernel size
+    assert e.value.code == capi.E_INVALID_PARAMETER
