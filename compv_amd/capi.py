@@ -39,6 +39,7 @@ EXPORTS = [
     "compvhip_gauss_kernel_fixedpoint", "compvhip_convlt1_fixedpoint_u8", "compvhip_plan_convlt1_fixedpoint", "compvhip_plan_to_cartesian",
     "compvhip_plan_pipeline_async", "compvhip_plan_wait", "compvhip_houghsht_to_cartesian", "compvhip_houghkht_to_cartesian",
     "compvhip_houghkht_kernels_u8", "compvhip_houghkht_stage_ms", "compvhip_convlt1_8u16s16s", "compvhip_convlt1_16s16s16s",
+    "compvhip_plan_pipeline_ex",
 ]
 
 
@@ -47,6 +48,12 @@ class Line(C.Structure):
 
 
 LINE_DTYPE = np.dtype([("rho", "<f4"), ("theta", "<f4"), ("strength", "<i4"), ("row", "<i4"), ("col", "<i4")])
+
+
+class PipelineOpts(C.Structure):
+    """compvhip_pipeline_opts (include/compv_hip.h)"""
+    _fields_ = [("tLow", C.c_float), ("tHigh", C.c_float), ("threshold", C.c_int), ("maxLines", C.c_int), ("ksize", C.c_int),
+                ("thresholdType", C.c_int), ("pixfmt", C.c_int), ("d_gray", C.c_void_p), ("d_otsu", C.c_void_p), ("d_cart", C.c_void_p)]
 
 
 class CompvHipError(RuntimeError):
@@ -118,6 +125,7 @@ def load():
     L.compvhip_plan_pipeline.argtypes = [vp, vp, C.c_float, C.c_float, i32, i32, vp, vp, sz, vp, vp]
     L.compvhip_plan_pipeline_async.argtypes = [vp, vp, C.c_float, C.c_float, i32, i32, vp, vp, sz, vp, vp, C.POINTER(i32)]
     L.compvhip_plan_wait.argtypes = [vp, i32]
+    L.compvhip_plan_pipeline_ex.argtypes = [vp, vp, C.POINTER(PipelineOpts), vp, vp, sz, vp, vp, C.POINTER(i32)]
     L.compvhip_plan_acc.argtypes = [vp, sz, C.POINTER(vp), C.POINTER(sz), C.POINTER(sz), C.POINTER(sz)]
     L.compvhip_plan_acc_export.argtypes = [vp, sz, vp, sz, vp]
     L.compvhip_plan_edge_counts.argtypes = [vp, C.POINTER(vp)]
@@ -325,6 +333,15 @@ class Plan:
         self.ctx._chk(self.lib.compvhip_plan_pipeline_async(self.h, d_in, tLow, tHigh, threshold, max_lines, d_edges, d_lines, line_cap,
                                                             d_counts, stream, C.byref(t)))
         return t.value
+
+    def pipeline_ex(self, d_in, tLow, tHigh, threshold, max_lines, d_edges, d_lines, line_cap, d_counts, ksize=3,
+                    threshold_type=THRESHOLD_COMPARE_TO_GRADIENT, pixfmt=FMT_Y, d_gray=0, d_otsu=0, d_cart=0, stream=0, asynchronous=False):
+        """[grayscale ->] Canny (any kernel size / threshold mode) -> SHT [-> toCartesian] as one enqueue; returns the ticket when asynchronous."""
+        o = PipelineOpts(tLow, tHigh, threshold, max_lines, ksize, threshold_type, pixfmt, d_gray or None, d_otsu or None, d_cart or None)
+        t = C.c_int(-1)
+        self.ctx._chk(self.lib.compvhip_plan_pipeline_ex(self.h, d_in, C.byref(o), d_edges, d_lines, line_cap, d_counts, stream,
+                                                         C.byref(t) if asynchronous else None))
+        return t.value if asynchronous else None
 
     def wait(self, ticket):
         self.ctx._chk(self.lib.compvhip_plan_wait(self.h, ticket))

@@ -28,6 +28,7 @@ constexpr int kMaxRounds = 4096;       // hysteresis round flag slots (a multipl
 constexpr int kSpecRounds = 3;         // rounds enqueued speculatively between two convergence checks
 constexpr size_t kMinLineCap = 1u << 16;  // per-frame line-key slots: max(caller's lineCap, 65536), clamped to R*T (include/compv_hip.h, compvhip_plan_houghsht)
 constexpr int kAsyncDepth = 4;            // outstanding compvhip_plan_pipeline_async steps per plan
+constexpr size_t kMaxTimeline = 4096;     // timing entries kept while nobody reads them (asynchronous steps)
 } // namespace
 
 struct compvhip_ctx {
@@ -61,6 +62,14 @@ struct compvhip_ctx {
 
 struct TimingEntry { const char* name; hipEvent_t a, b; };
 
+// one step of the device-resident pipeline: [grayscale ->] Canny -> SHT [-> toCartesian] (compvhip_plan_pipeline{,_async,_ex})
+struct StepParams {
+	const uint8_t* d_in = nullptr; float tLow = 0.f, tHigh = 0.f; int threshold = 0, maxLines = 0;
+	int ksize = 3, thresholdType = COMPVHIP_CANNY_THRESHOLD_COMPARE_TO_GRADIENT, pixfmt = COMPVHIP_FMT_Y;
+	uint8_t* d_gray = nullptr; int32_t* d_otsu = nullptr; float* d_cart = nullptr;
+	uint8_t* d_edges = nullptr; compvhip_line* d_lines = nullptr; size_t lineCap = 0; int32_t* d_counts = nullptr;
+};
+
 struct compvhip_plan {
 	compvhip_ctx* ctx = nullptr;
 	size_t W = 0, H = 0, S = 0, frames = 0;
@@ -78,6 +87,7 @@ struct compvhip_plan {
 	int2* thrDev = nullptr; unsigned int* sums = nullptr;
 	uint8_t* dirty = nullptr;  // per-workgroup change flags of the resolve rounds
 	uint8_t* patchOut = nullptr; uint8_t* copyBack = nullptr; // byte map the tile kernel writes and the resolve rounds patch / in-place target of the last Canny call
+	uint8_t* grayTmp = nullptr; // luma plane of a packed-input step when the caller does not want it (compvhip_plan_pipeline_ex)
 	uint8_t* tmpOut = nullptr; // aliasing (in == out) scratch: a tile may still read the row halo a neighbour has overwritten
 	int cannyImpl = 0;         // kernel size 3: 0 = SWAR + candidate-list tile kernel, 1 = register-ring kernel (COMPVHIP_CANNY_IMPL=ring at plan creation)
 	bool bitsValid = false;
@@ -99,11 +109,7 @@ struct compvhip_plan {
 	std::vector<int32_t> vtKt, vtRowBase;        // host copies of the [tiles][T] tables
 	int32_t* dKt = nullptr; int32_t* dRowBase = nullptr; uint16_t* partial = nullptr; int* tileCounts = nullptr;
 	// asynchronous steps (compvhip_plan_pipeline_async / compvhip_plan_wait)
-	struct AsyncStep {
-		bool used = false; hipEvent_t done = nullptr; hipStream_t stream = nullptr;
-		const uint8_t* d_in = nullptr; float tLow = 0.f, tHigh = 0.f; int threshold = 0, maxLines = 0; uint8_t* d_edges = nullptr;
-		compvhip_line* d_lines = nullptr; size_t lineCap = 0; int32_t* d_counts = nullptr;
-	} steps[kAsyncDepth];
+	struct AsyncStep { bool used = false; hipEvent_t done = nullptr; hipStream_t stream = nullptr; StepParams sp; } steps[kAsyncDepth];
 	// timing
 	int timing = 0; // 0 off, 1 every kernel, 2 canny_tile + sht_vote, 3 sht_vote only, 4 canny_tile only
 	std::vector<hipEvent_t> eventPool;
@@ -646,7 +652,7 @@ void compvhip_plan_destroy(compvhip_plan* p)
 	dfree(ctx, p->dirty);
 	dfree(ctx, p->ebits); dfree(ctx, p->ubits); dfree(ctx, p->counters); dfree(ctx, p->thrDev); dfree(ctx, p->sums); dfree(ctx, p->tmpOut);
 	if (p->hFlags) (void)hipHostFree(p->hFlags);
-	dfree(ctx, p->hist); dfree(ctx, p->otsu); dfree(ctx, p->blurTmp);
+	dfree(ctx, p->hist); dfree(ctx, p->otsu); dfree(ctx, p->blurTmp); dfree(ctx, p->grayTmp);
 	dfree(ctx, p->cosT); dfree(ctx, p->invSinT);
 	dfree(ctx, p->dKt); dfree(ctx, p->dRowBase); dfree(ctx, p->partial);
 	dfree(ctx, p->sinQ); dfree(ctx, p->cosQ); dfree(ctx, p->edges); dfree(ctx, p->acc);
@@ -860,18 +866,68 @@ int compvhip_plan_houghsht(compvhip_plan* p, const uint8_t* d_edges, int thresho
 	return planShtImpl(p, d_edges, threshold, maxLines, d_lines, lineCap, d_counts, static_cast<hipStream_t>(stream), true);
 }
 
-int compvhip_plan_pipeline(compvhip_plan* p, const uint8_t* d_in, float tLow, float tHigh, int threshold, int maxLines, uint8_t* d_edges,
-                           compvhip_line* d_lines, size_t lineCap, int32_t* d_counts, void* stream)
+// ---- the step: [grayscale ->] Canny (any kernel size / threshold mode) -> SHT [-> toCartesian], one enqueue ----------------------
+static int checkStep(compvhip_plan* p, const StepParams& sp)
 {
-	if (!p) return COMPVHIP_E_INVALID_PARAMETER;
-	hipStream_t st = static_cast<hipStream_t>(stream);
+	compvhip_ctx* ctx = p->ctx;
+	if (!sp.d_in || !sp.d_edges) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "null frame pointer");
+	if (sp.pixfmt != COMPVHIP_FMT_Y) {
+		if (!pixfmtBytes(sp.pixfmt)) return fail(ctx, COMPVHIP_E_NOT_IMPLEMENTED, "pixel format without a grayscale conversion"); // conv_to_grayscale.cxx:86-88
+		if ((sp.pixfmt == COMPVHIP_FMT_YUYV422 || sp.pixfmt == COMPVHIP_FMT_UYVY422) && (p->W & 1))
+			return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "packed 4:2:2 needs an even width");
+	}
+	if (sp.d_cart && (!sp.d_lines || !sp.d_counts)) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "toCartesian needs the line and count buffers");
+	return COMPVHIP_OK;
+}
+
+// everything up to (not including) the convergence check, on `st`
+static int enqueueStep(compvhip_plan* p, const StepParams& sp, hipStream_t st, bool clearTimeline)
+{
+	compvhip_ctx* ctx = p->ctx;
+	const uint8_t* luma = sp.d_in;
+	if (sp.pixfmt != COMPVHIP_FMT_Y) {
+		// samples/hough_lines/main.cxx:102: CompVImage::convertGrayscale in front of everything else
+		uint8_t* gray = sp.d_gray;
+		if (!gray) {
+			if (!p->grayTmp) HIPCHK(ctx, dmalloc(ctx, &p->grayTmp, p->S * p->H * p->frames));
+			gray = p->grayTmp;
+		}
+		HIPCHK(ctx, hipSetDevice(ctx->device));
+		if (p->timing && clearTimeline) timelineClear(p);
+		clearTimeline = false;
+		GrayArgs a;
+		a.in = sp.d_in; a.out = gray; a.W = static_cast<int>(p->W); a.H = static_cast<int>(p->H); a.S = static_cast<int>(p->S); a.So = static_cast<int>(p->S);
+		Stamp s(p, st, "gray_kernel");
+		HIPCHK(ctx, launch_gray(a, sp.pixfmt, static_cast<int>(p->frames), st));
+		luma = gray;
+	}
+	int rc = planCannyImpl(p, luma, sp.tLow, sp.tHigh, sp.ksize, sp.thresholdType, sp.d_edges, st, false, clearTimeline);
+	if (rc) return rc;
+	if (sp.d_otsu && sp.thresholdType == COMPVHIP_CANNY_THRESHOLD_OTSU)
+		HIPCHK(ctx, hipMemcpyAsync(sp.d_otsu, p->otsu, sizeof(int32_t) * p->frames, hipMemcpyDeviceToDevice, st));
+	return COMPVHIP_OK;
+}
+
+static int enqueueStepTail(compvhip_plan* p, const StepParams& sp, hipStream_t st)
+{
+	int rc = planShtImpl(p, nullptr, sp.threshold, sp.maxLines, sp.d_lines, sp.lineCap, sp.d_counts, st, false);
+	if (rc) return rc;
+	if (sp.d_cart) {
+		rc = compvhip_plan_to_cartesian(p, sp.d_lines, sp.d_counts, sp.lineCap, sp.d_cart, st);
+		if (rc) return rc;
+	}
+	return COMPVHIP_OK;
+}
+
+static int runStepSync(compvhip_plan* p, const StepParams& sp, hipStream_t st)
+{
 	// Everything is enqueued back to back (speculative resolve rounds included); the convergence flag is checked once at the end and,
 	// in the rare case the hysteresis needed more rounds, the tail is replayed.
-	int rc = planCannyImpl(p, d_in, tLow, tHigh, 3, COMPVHIP_CANNY_THRESHOLD_COMPARE_TO_GRADIENT, d_edges, st, false, true);
+	int rc = enqueueStep(p, sp, st, true);
 	if (rc) return rc;
 	const size_t bytes = p->S * p->H * p->frames;
 	for (;;) {
-		rc = planShtImpl(p, nullptr, threshold, maxLines, d_lines, lineCap, d_counts, st, false);
+		rc = enqueueStepTail(p, sp, st);
 		if (rc) return rc;
 		bool done = false;
 		rc = resolveConverged(p, st, &done);
@@ -891,34 +947,75 @@ int compvhip_plan_pipeline(compvhip_plan* p, const uint8_t* d_in, float tLow, fl
 
 // The step without its host round trip: the hysteresis flag of the last speculative round travels to a pinned host slot behind
 // the step's kernels and is looked at by compvhip_plan_wait(), normally while the NEXT step is already running.
-int compvhip_plan_pipeline_async(compvhip_plan* p, const uint8_t* d_in, float tLow, float tHigh, int threshold, int maxLines, uint8_t* d_edges,
-                                 compvhip_line* d_lines, size_t lineCap, int32_t* d_counts, void* stream, int* ticket)
+static int runStepAsync(compvhip_plan* p, const StepParams& sp, hipStream_t st, int* ticket)
 {
-	if (!p || !ticket) return COMPVHIP_E_INVALID_PARAMETER;
 	compvhip_ctx* ctx = p->ctx;
 	*ticket = -1;
 	int slot = -1;
 	for (int i = 0; i < kAsyncDepth; ++i) if (!p->steps[i].used) { slot = i; break; }
 	if (slot < 0) return fail(ctx, COMPVHIP_E_INVALID_STATE, "too many steps in flight: call compvhip_plan_wait first");
 	const size_t bytes = p->S * p->H * p->frames;
-	if (d_in && d_edges && (d_in < d_edges + bytes) && (d_edges < d_in + bytes))
+	const size_t inBytes = bytes * static_cast<size_t>(sp.pixfmt == COMPVHIP_FMT_Y ? 1 : pixfmtBytes(sp.pixfmt));
+	if ((sp.d_in < sp.d_edges + bytes) && (sp.d_edges < sp.d_in + inBytes))
 		return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "the asynchronous step needs distinct input and edge buffers"); // a replay re-reads d_in
-	hipStream_t st = static_cast<hipStream_t>(stream);
 	compvhip_plan::AsyncStep& stp = p->steps[slot];
 	HIPCHK(ctx, hipSetDevice(ctx->device));
 	if (!stp.done) HIPCHK(ctx, hipEventCreateWithFlags(&stp.done, hipEventDisableTiming));
-	// timing events of asynchronous steps accumulate until compvhip_plan_get_timing reads them (nothing is cleared per step)
-	int rc = planCannyImpl(p, d_in, tLow, tHigh, 3, COMPVHIP_CANNY_THRESHOLD_COMPARE_TO_GRADIENT, d_edges, st, false, false);
+	// timing events of asynchronous steps accumulate until compvhip_plan_get_timing reads them; beyond kMaxTimeline entries the oldest go
+	if (p->timeline.size() > kMaxTimeline) timelineClear(p);
+	int rc = enqueueStep(p, sp, st, false);
 	if (rc) return rc;
-	rc = planShtImpl(p, nullptr, threshold, maxLines, d_lines, lineCap, d_counts, st, false);
+	rc = enqueueStepTail(p, sp, st);
 	if (rc) return rc;
 	HIPCHK(ctx, hipMemcpyAsync(p->hFlags + 1 + slot, p->flags + (p->roundsUsed - 1), sizeof(int), hipMemcpyDeviceToHost, st));
 	HIPCHK(ctx, hipEventRecord(stp.done, st));
-	stp.used = true; stp.stream = st;
-	stp.d_in = d_in; stp.tLow = tLow; stp.tHigh = tHigh; stp.threshold = threshold; stp.maxLines = maxLines; stp.d_edges = d_edges;
-	stp.d_lines = d_lines; stp.lineCap = lineCap; stp.d_counts = d_counts;
+	stp.used = true; stp.stream = st; stp.sp = sp;
 	*ticket = slot;
 	return COMPVHIP_OK;
+}
+
+static StepParams classicStep(const uint8_t* d_in, float tLow, float tHigh, int threshold, int maxLines, uint8_t* d_edges, compvhip_line* d_lines, size_t lineCap,
+                              int32_t* d_counts)
+{
+	StepParams sp;
+	sp.d_in = d_in; sp.tLow = tLow; sp.tHigh = tHigh; sp.threshold = threshold; sp.maxLines = maxLines; sp.d_edges = d_edges; sp.d_lines = d_lines;
+	sp.lineCap = lineCap; sp.d_counts = d_counts;
+	return sp;
+}
+
+int compvhip_plan_pipeline(compvhip_plan* p, const uint8_t* d_in, float tLow, float tHigh, int threshold, int maxLines, uint8_t* d_edges,
+                           compvhip_line* d_lines, size_t lineCap, int32_t* d_counts, void* stream)
+{
+	if (!p) return COMPVHIP_E_INVALID_PARAMETER;
+	const StepParams sp = classicStep(d_in, tLow, tHigh, threshold, maxLines, d_edges, d_lines, lineCap, d_counts);
+	int rc = checkStep(p, sp);
+	if (rc) return rc;
+	return runStepSync(p, sp, static_cast<hipStream_t>(stream));
+}
+
+int compvhip_plan_pipeline_async(compvhip_plan* p, const uint8_t* d_in, float tLow, float tHigh, int threshold, int maxLines, uint8_t* d_edges,
+                                 compvhip_line* d_lines, size_t lineCap, int32_t* d_counts, void* stream, int* ticket)
+{
+	if (!p || !ticket) return COMPVHIP_E_INVALID_PARAMETER;
+	const StepParams sp = classicStep(d_in, tLow, tHigh, threshold, maxLines, d_edges, d_lines, lineCap, d_counts);
+	*ticket = -1;
+	int rc = checkStep(p, sp);
+	if (rc) return rc;
+	return runStepAsync(p, sp, static_cast<hipStream_t>(stream), ticket);
+}
+
+int compvhip_plan_pipeline_ex(compvhip_plan* p, const uint8_t* d_in, const compvhip_pipeline_opts* o, uint8_t* d_edges, compvhip_line* d_lines, size_t lineCap,
+                              int32_t* d_counts, void* stream, int* ticket)
+{
+	if (!p) return COMPVHIP_E_INVALID_PARAMETER;
+	if (ticket) *ticket = -1;
+	if (!o) return fail(p->ctx, COMPVHIP_E_INVALID_PARAMETER, "null options");
+	StepParams sp = classicStep(d_in, o->tLow, o->tHigh, o->threshold, o->maxLines, d_edges, d_lines, lineCap, d_counts);
+	sp.ksize = o->ksize ? o->ksize : 3; sp.thresholdType = o->thresholdType; sp.pixfmt = o->pixfmt;
+	sp.d_gray = o->d_gray; sp.d_otsu = o->d_otsu; sp.d_cart = o->d_cart;
+	int rc = checkStep(p, sp);
+	if (rc) return rc;
+	return ticket ? runStepAsync(p, sp, static_cast<hipStream_t>(stream), ticket) : runStepSync(p, sp, static_cast<hipStream_t>(stream));
 }
 
 int compvhip_plan_wait(compvhip_plan* p, int ticket)
@@ -933,7 +1030,7 @@ int compvhip_plan_wait(compvhip_plan* p, int ticket)
 	// Rare: the hysteresis of this step needed more rounds than were enqueued, and a later step may already have reused the
 	// plan's masks.  Let the stream drain and run the step again, synchronously, from its (unmodified) input.
 	HIPCHK(ctx, hipStreamSynchronize(stp.stream));
-	return compvhip_plan_pipeline(p, stp.d_in, stp.tLow, stp.tHigh, stp.threshold, stp.maxLines, stp.d_edges, stp.d_lines, stp.lineCap, stp.d_counts, stp.stream);
+	return runStepSync(p, stp.sp, stp.stream);
 }
 
 int compvhip_plan_to_cartesian(compvhip_plan* p, const compvhip_line* d_lines, const int32_t* d_counts, size_t lineCap, float* d_cart, void* stream)

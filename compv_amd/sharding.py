@@ -58,14 +58,19 @@ def scatter_blocks(dist, block_of_rank, out, src=0):
         out.copy_(block_of_rank(0))
         return
     rank, world = dist.get_rank(), dist.get_world_size()
+    staged = out.is_cuda and dist.get_backend() == "gloo"   # gloo has no device-to-device send/recv: host staging (test configurations only)
     if rank == src:
-        ops = [dist.P2POp(dist.isend, block_of_rank(r), r) for r in range(world) if r != src]
+        ops = [dist.P2POp(dist.isend, block_of_rank(r).cpu() if staged else block_of_rank(r), r) for r in range(world) if r != src]
         out.copy_(block_of_rank(src))
+        tmp = None
     else:
-        ops = [dist.P2POp(dist.irecv, out, src)]
+        tmp = out.cpu() if staged else out
+        ops = [dist.P2POp(dist.irecv, tmp, src)]
     if ops:
         for w in dist.batch_isend_irecv(ops):
             w.wait()
+    if staged and tmp is not None:
+        out.copy_(tmp)
 
 
 def gather_lines(dist, counts, lines_topk):
@@ -75,6 +80,9 @@ def gather_lines(dist, counts, lines_topk):
         return counts, lines_topk
     import torch
     world = dist.get_world_size()
+    if counts.is_cuda and dist.get_backend() == "gloo":     # host staging (test configurations only)
+        c, l = gather_lines(dist, counts.cpu(), lines_topk.cpu())
+        return c.to(counts.device), l.to(counts.device)
     all_counts = torch.empty((world * counts.shape[0],), dtype=counts.dtype, device=counts.device)
     all_lines = torch.empty((world * lines_topk.shape[0],) + tuple(lines_topk.shape[1:]), dtype=lines_topk.dtype, device=lines_topk.device)
     dist.all_gather_into_tensor(all_counts, counts.contiguous())

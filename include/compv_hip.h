@@ -228,7 +228,8 @@ COMPVHIP_API int compvhip_plan_edge_dete(compvhip_plan* plan, const uint8_t* d_i
 
 /* SHT on the edge maps produced by the last compvhip_plan_canny() of this plan (uses its 1-bit edge masks, no byte
  * re-read) or, when d_edges != NULL, on arbitrary device edge maps.  Results stay on the device:
- * d_lines: frames * lineCap compvhip_line (sorted as compvhip_houghsht_u8), d_counts: frames int32 (lines found,
+ * d_lines: frames * lineCap compvhip_line (strength descending, ties by accumulator (row, col) ascending -- the canonical order, not the
+ * reference's unstable-sort tie order the host entry point reproduces), d_counts: frames int32 (lines found,
  * before clipping to lineCap).  The call is asynchronous and cannot grow its buffers after the fact: the device key buffer holds
  * min(R*T, max(lineCap, 65536)) candidates per frame, so whatever lineCap is, the lineCap STRONGEST lines are returned as long as
  * d_counts[f] <= max(lineCap, 65536); beyond that the key buffer overflowed and frame f's lines are an arbitrary subset -- call
@@ -252,6 +253,24 @@ COMPVHIP_API int compvhip_plan_pipeline_async(compvhip_plan* plan, const uint8_t
                                               int threshold, int maxLines, uint8_t* d_edges,
                                               compvhip_line* d_lines, size_t lineCap, int32_t* d_counts, void* stream, int* ticket);
 COMPVHIP_API int compvhip_plan_wait(compvhip_plan* plan, int ticket);
+
+/* The general step: what samples/hough_lines/main.cxx:102-109 does per camera frame -- convertGrayscale -> thresholdOtsu ->
+ * Canny(Otsu * tLow, Otsu * tHigh) -> HoughSHT -> toCartesian -- as ONE enqueue over the plan's frames.  Zero-initialise the struct and set what
+ * is needed; compvhip_plan_pipeline(_async) is this call with ksize 3, COMPARE_TO_GRADIENT, FMT_Y and no optional outputs. */
+typedef struct compvhip_pipeline_opts {
+	float tLow, tHigh;      /* Canny thresholds (threshold factors in the PERCENT_OF_MEAN / OTSU modes) */
+	int threshold, maxLines;/* SHT threshold (> 0) / line cut (<= 0: every line) */
+	int ksize;              /* Sobel kernel size of the gradient: 3 or 5 (0 = 3) */
+	int thresholdType;      /* COMPVHIP_CANNY_THRESHOLD_* */
+	int pixfmt;             /* compvhip_pixfmt of d_in; COMPVHIP_FMT_Y (luma plane, stride S) or a packed format ([frames][H][S samples]): converted first */
+	uint8_t* d_gray;        /* packed input: receives the luma planes [frames][H][S] (NULL: plan-owned scratch) */
+	int32_t* d_otsu;        /* OTSU mode: receives the per-frame Otsu levels (NULL: not wanted) */
+	float* d_cart;          /* receives toCartesian's endpoints [frames][lineCap][4] (NULL: not wanted) */
+} compvhip_pipeline_opts;
+/* ticket == NULL: synchronous like compvhip_plan_pipeline; otherwise asynchronous like compvhip_plan_pipeline_async (same rules: wait with
+ * compvhip_plan_wait, d_in unmodified and distinct from d_edges until then). */
+COMPVHIP_API int compvhip_plan_pipeline_ex(compvhip_plan* plan, const uint8_t* d_in, const compvhip_pipeline_opts* opts, uint8_t* d_edges,
+                                           compvhip_line* d_lines, size_t lineCap, int32_t* d_counts, void* stream, int* ticket);
 
 /* Device accumulator of frame f after compvhip_plan_houghsht: uint16 (a cell never exceeds the pixels of a 1-px band),
  * theta-major [T][accPitch] (pitch >= R).  compvhip_plan_acc_export gives the reference's int32 rho-major layout. */

@@ -35,9 +35,29 @@ def main():
     elapsed = time.perf_counter() - t0
     tmax = sharding.max_over_ranks(elapsed, dist)
     allc = sharding.gather_frame_results(counts, dist)
+
+    # ---- the data path of bench.py --scatter: the step's global batch is born on rank 0, every rank receives its block with
+    # one grouped send/recv, the per-frame line counts and strongest lines are all-gathered.  Same functions, CPU tensors, gloo.
+    import numpy as np
+    import torch
+    F, H, W, K = 3, 24, 40, 4
+    blocks = None
+    if rank == 0:
+        blocks = [torch.from_numpy(np.stack([synth_frame(W, H, 100 * r + f) for f in range(F)])) for r in range(world)]
+    mine_in = torch.zeros((F, H, W), dtype=torch.uint8)
+    sharding.scatter_blocks(dist, (lambda r: blocks[r]), mine_in, src=0)
+    exp_in = np.stack([synth_frame(W, H, 100 * rank + f) for f in range(F)])
+    scatter_ok = bool((mine_in.numpy() == exp_in).all())
+    my_counts = torch.tensor([1000 * rank + f for f in range(F)], dtype=torch.int32)
+    my_lines = (torch.arange(F * K * 5, dtype=torch.int32).reshape(F, K, 5) + 100000 * rank)
+    g_counts, g_lines = sharding.gather_lines(dist, my_counts, my_lines)
+    ok = torch.tensor([1 if scatter_ok else 0], dtype=torch.int32)
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
     if rank == 0:
         with open(out_path, "w") as f:
-            json.dump({"world": world, "counts": allc, "tmax": tmax, "elapsed_rank0": elapsed}, f)
+            json.dump({"world": world, "counts": allc, "tmax": tmax, "elapsed_rank0": elapsed, "scatter_ok_all_ranks": int(ok.item()),
+                       "gathered_counts": g_counts.tolist(), "gathered_lines_shape": list(g_lines.shape),
+                       "gathered_lines_first": [int(g_lines[r * F, 0, 0]) for r in range(world)]}, f)
     dist.destroy_process_group()
 
 

@@ -41,3 +41,7 @@ def test_two_ranks_gloo(tmp_path, oracle):
         exp.append(int((e != 0).sum()))
     assert res["counts"] == exp
     assert res["tmax"] >= res["elapsed_rank0"] - 1e-6 and res["tmax"] >= 0.1   # rank 1 sleeps longer: MAX picks it
+    # --scatter data path: every rank received exactly its block; counts / top-K lines of all ranks arrive in rank order
+    assert res["scatter_ok_all_ranks"] == 1
+    assert res["gathered_counts"] == [0, 1, 2, 1000, 1001, 1002]
+    assert res["gathered_lines_shape"] == [6, 4, 5] and res["gathered_lines_first"] == [0, 100000]

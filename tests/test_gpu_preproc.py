@@ -112,3 +112,68 @@ def test_grayscale_matches_reference_golden(hip_ctx, case):
 @pytest.mark.parametrize("case", GOLDEN_PREPROC["otsu"], ids=lambda c: "%s_%dx%d" % (c["kind"], c["W"], c["H"]))
 def test_otsu_matches_reference_golden(hip_ctx, case):
     assert hip_ctx.otsu(otsu_input(case["kind"], case["W"], case["H"], case["seed"])) == float(case["threshold"])
+
+
+def test_sample_loop_as_one_enqueue(hip_ctx, oracle):
+    """compvhip_plan_pipeline_ex: the per-frame sequence of samples/hough_lines/main.cxx:102-109 -- convertGrayscale -> thresholdOtsu ->
+    Canny(Otsu * 0.5, Otsu) -> HoughSHT -> toCartesian -- as ONE call on a batch of packed RGB24 frames, synchronous and as an asynchronous
+    ticket; then the other configurations of the step (5x5 Sobel with PERCENT_OF_MEAN thresholds on a luma plane)."""
+    import torch
+    from compv_amd import capi
+    W, H, S, F, cap = 640, 480, 640, 3, 4096
+    dev = torch.device("cuda", 0)
+    rgb = np.zeros((F, H, S * 3), np.uint8)
+    grays, otsus, edges_exp, lines_exp = [], [], [], []
+    for f in range(F):
+        base = synth_frame(W, H, 901 + f).astype(np.int32)
+        frame = np.stack([np.clip(base + 15 * f, 0, 255), np.clip(base * 3 // 4, 0, 255), np.clip(255 - base, 0, 255)], axis=-1).astype(np.uint8)
+        rgb[f] = frame.reshape(H, W * 3)
+        g = oracle.grayscale(rgb[f], capi.FMT_RGB24, W)
+        t = oracle.otsu(g)
+        lo, hi = oracle.otsu_canny_thresholds(t)
+        rc, e = oracle.canny(g, float(lo), float(hi))
+        assert rc == 0
+        grays.append(g); otsus.append(t); edges_exp.append(e); lines_exp.append(oracle.sht(e, 1.0, 60))
+    d_rgb = torch.from_numpy(rgb).to(dev)
+    plan = capi.Plan(hip_ctx, W, H, S, F, 1.0)
+    try:
+        for asynchronous in (False, True):
+            d_gray = torch.zeros((F, H, S), dtype=torch.uint8, device=dev)
+            d_edges = torch.zeros_like(d_gray)
+            d_otsu = torch.zeros(F, dtype=torch.int32, device=dev)
+            d_lines = torch.zeros((F, cap, 5), dtype=torch.int32, device=dev)
+            d_counts = torch.zeros(F, dtype=torch.int32, device=dev)
+            d_cart = torch.zeros((F, cap, 4), dtype=torch.float32, device=dev)
+            t = plan.pipeline_ex(d_rgb.data_ptr(), 0.5, 1.0, 60, 0, d_edges.data_ptr(), d_lines.data_ptr(), cap, d_counts.data_ptr(),
+                                 threshold_type=capi.THRESHOLD_OTSU, pixfmt=capi.FMT_RGB24, d_gray=d_gray.data_ptr(), d_otsu=d_otsu.data_ptr(),
+                                 d_cart=d_cart.data_ptr(), asynchronous=asynchronous)
+            if asynchronous:
+                plan.wait(t)
+            torch.cuda.synchronize()
+            assert d_otsu.cpu().tolist() == otsus
+            g = d_gray.cpu().numpy(); e = d_edges.cpu().numpy(); counts = d_counts.cpu().numpy()
+            raw = d_lines.cpu().numpy().view(np.uint8).reshape(F, cap, 20); cart = d_cart.cpu().numpy()
+            for f in range(F):
+                assert (g[f][:, :W] == grays[f]).all() and (e[f][:, :W] == edges_exp[f]).all(), (asynchronous, f)
+                exp = lines_exp[f]
+                assert counts[f] == len(exp) and 0 < len(exp) <= cap
+                got = np.frombuffer(raw[f].tobytes(), dtype=capi.LINE_DTYPE)[:len(exp)]
+                assert [(int(l["row"]), int(l["col"]), int(l["strength"])) for l in got] == [(l[3], l[4], l[2]) for l in exp]
+                ce = oracle.sht_to_cartesian(W, H, [(float(np.float32(l[0])), float(np.float32(l[1]))) for l in exp])
+                assert (cart[f][:len(exp)].view(np.uint32) == ce.view(np.uint32)).all(), (asynchronous, f)
+        # kernel size 5 + PERCENT_OF_MEAN thresholds on the luma planes, no optional outputs (the plan keeps its own scratch)
+        d_y = torch.from_numpy(np.stack(grays)).to(dev)
+        d_edges = torch.zeros_like(d_y); d_lines.zero_(); d_counts.zero_()
+        plan.pipeline_ex(d_y.data_ptr(), 0.68, 1.36, 40, 0, d_edges.data_ptr(), d_lines.data_ptr(), cap, d_counts.data_ptr(), ksize=5,
+                         threshold_type=capi.THRESHOLD_PERCENT_OF_MEAN)
+        torch.cuda.synchronize()
+        e = d_edges.cpu().numpy(); counts = d_counts.cpu().numpy()
+        for f in range(F):
+            rc, exp_e = oracle.canny(grays[f], 0.68, 1.36, 5, 1)
+            assert rc == 0 and (e[f] == exp_e).all(), f
+            assert counts[f] == len(oracle.sht(exp_e, 1.0, 40))
+        with pytest.raises(capi.CompvHipError) as err:
+            plan.pipeline_ex(d_y.data_ptr(), 10.0, 20.0, 40, 0, d_edges.data_ptr(), d_lines.data_ptr(), cap, d_counts.data_ptr(), pixfmt=99)
+        assert err.value.code == capi.E_NOT_IMPLEMENTED
+    finally:
+        plan.close()

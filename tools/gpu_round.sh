@@ -9,7 +9,7 @@ tail -4 $O/pytest.log
 B="python bench.py --no-cpu-baseline --no-extras"
 $B > $O/bench_default.json 2> $O/bench_default.err
 $B --inflight 1 > $O/bench_inflight1.json 2> $O/bench_inflight1.err
-for r in 32 128; do
+for r in 16 64; do
   COMPVHIP_CANNY_ROWS=$r $B --reps 3 --no-verify > $O/bench_r${r}.json 2> $O/bench_r${r}.err
   COMPVHIP_CANNY_ROWS=$r $B --inflight 1 --reps 3 --no-verify > $O/bench_r${r}_inflight1.json 2> $O/bench_r${r}_inflight1.err
 done
