@@ -89,7 +89,6 @@ struct compvhip_plan {
 	uint8_t* patchOut = nullptr; uint8_t* copyBack = nullptr; // byte map the tile kernel writes and the resolve rounds patch / in-place target of the last Canny call
 	uint8_t* grayTmp = nullptr; // luma plane of a packed-input step when the caller does not want it (compvhip_plan_pipeline_ex)
 	uint8_t* tmpOut = nullptr; // aliasing (in == out) scratch: a tile may still read the row halo a neighbour has overwritten
-	int cannyImpl = 0;         // kernel size 3: 0 = SWAR + candidate-list tile kernel, 1 = register-ring kernel (COMPVHIP_CANNY_IMPL=ring at plan creation)
 	bool bitsValid = false;
 	// sht
 	bool shtReady = false;
@@ -426,7 +425,7 @@ int enqueueCanny(compvhip_plan* p, const uint8_t* d_in, uint8_t* d_out, int tLow
 	a.in = d_in; a.out = d_out; a.ebits = p->ebits; a.ubits = p->ubits; a.thrDev = (thrMode != COMPVHIP_CANNY_THRESHOLD_COMPARE_TO_GRADIENT) ? p->thrDev : nullptr;
 	a.inFrameStride = p->S * p->H; a.outFrameStride = p->S * p->H; a.bitsFrameStride = p->bitsFrameStride;
 	a.W = static_cast<int>(p->W); a.H = static_cast<int>(p->H); a.S = static_cast<int>(p->S); a.So = static_cast<int>(p->S);
-	a.wb = p->wb; a.tilesX = p->tilesX; a.tilesY = p->tilesY; a.tLow = tLow; a.tHigh = tHigh; a.ksize = ksize; a.impl = p->cannyImpl;
+	a.wb = p->wb; a.tilesX = p->tilesX; a.tilesY = p->tilesY; a.tLow = tLow; a.tHigh = tHigh; a.ksize = ksize;
 	cannyCoverage(p->W, &a.simdEnd, &a.cStart);
 	// coverage [1,simdEnd) U [cStart,W-1) equals the whole interior unless the two pieces leave a hole (W = 1 mod 16 ...)
 	const bool gap = !((a.simdEnd >= a.W - 1) || (a.cStart <= a.simdEnd));
@@ -615,9 +614,7 @@ int compvhip_plan_create(compvhip_ctx* ctx, size_t W, size_t H, size_t S, size_t
 		// the fills run on the null stream; the plan's kernels may be enqueued on non-blocking streams that do not wait for it
 		if (hipDeviceSynchronize() != hipSuccess) { rc = COMPVHIP_E_HIP; break; }
 		{
-			// tuning / A-B knobs are read at EVERY plan creation (a process-wide static would freeze the first plan's choice)
 			p->voteTiles = true;
-			{ const char* e = getenv("COMPVHIP_CANNY_IMPL"); p->cannyImpl = (e && !strcmp(e, "ring")) ? 1 : 0; }
 			size_t R = 0, T = 0; float step = 0.f;
 			if (p->voteTiles && shtDims(W, H, thetaDeg, &R, &T, &step) == COMPVHIP_OK && T >= 5) {
 				std::vector<int32_t> sq, cq;

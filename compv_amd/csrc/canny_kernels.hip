@@ -9,14 +9,13 @@
 //                        out u8 [H][So]  {0,0xff}      (written once, 1 B/px)
 //                        E,U bitmasks u32 [H][wb]      (1 bit/px each: E = edge so far, U = weak but unresolved)
 //
-// Kernel 1 (canny_tile_kernel): one wave per 512x64 tile.  Streams rows through registers (stencil.hpp), applies the
-//   NMS rule to the *unsuppressed* g (gather/apply split of the reference), classifies weak (g_nms > tLow) / strong
-//   (g_nms > tHigh) per pixel, collects per-lane mask bytes (v_alignbit on difference signs) into LDS rows (lane == row), and then
-//   floods strong -> weak inside the tile to a fixed point with 512-bit carry-propagate adds (horizontal runs in one
-//   step) + cross-lane row exchange (vertical/diagonal steps).  Pixels resolved inside the tile are final; weak
-//   pixels the tile cannot resolve go to the U mask.
-// Kernel 2 (canny_resolve_kernel): works on the 1-bit masks only (0.25 B/px): one workgroup per 64-row band floods
-//   E into U across tile borders; repeated (device flag, no data-dependent host work) until no band changes.  The
+// Kernel 1: the tile kernel -- gradient, NMS, weak / strong classification; writes E (edges so far), U (weak, unresolved) and the bytes of E.
+//   Kernel size 3: canny_swar_tile_kernel (canny_swar_kernels.hip).  Kernel size 5: canny5_tile_kernel below -- one wave per 512x64 tile
+//   streams rows through registers (stencil.hpp, Grad5State), applies the NMS rule to the *unsuppressed* g (gather/apply split of the
+//   reference), collects per-lane mask bytes into LDS rows (lane == row) and floods strong -> weak inside the tile with 512-bit
+//   carry-propagate adds + cross-lane row exchange; weak pixels the tile cannot resolve go to the U mask.
+// Kernel 2 (canny_resolve_kernel): the hysteresis, on the 1-bit masks only (0.25 B/px): one workgroup per 64-row band floods E into U
+//   (register-resident column sweeps); repeated (device flags, no data-dependent host work) until no band changes.  The
 //   fixed point "all pixels with g_nms > tLow 8-connected to a pixel with g_nms > tHigh" is unique, hence
 //   bit-exact whatever the propagation order (the reference's own multithreaded bands race the same way).
 #include "stencil.hpp"
@@ -83,9 +82,10 @@ __device__ __forceinline__ int max3i(int a, int b, int sc)
 // ---------------------------------------------------------------------------------------------------------------
 // Kernel 1
 // ---------------------------------------------------------------------------------------------------------------
-template <int KS, bool GAP>
-__global__ __launch_bounds__(kCannyWaves * 64) void canny_tile_kernel(CannyArgs a)
+template <bool GAP>
+__global__ __launch_bounds__(kCannyWaves * 64) void canny5_tile_kernel(CannyArgs a)
 {
+	constexpr int KS = 5;
 	constexpr int R = KS / 2; // kernel radius = width of the zero OUTPUT border of the gradient
 	constexpr int kMaskPitch = 33; // 32 mask dwords per row + 1: lane==row reads are bank-conflict free
 	__shared__ uint32_t lds_masks[kCannyWaves][kTileH][kMaskPitch];
@@ -134,9 +134,8 @@ __global__ __launch_bounds__(kCannyWaves * 64) void canny_tile_kernel(CannyArgs 
 	// tiles whose first/last gradient rows fall on the image border rows (g forced to 0 there)
 	const bool vEdgeTile = (tileY == 0) || (y0 + kTileH + 1 >= H - R);
 
-	Grad3Ring<1, 2> st;
 	Grad5State st5;
-	if (KS == 3) st.reset(); else st5.reset();
+	st5.reset();
 	int gr[3][10];           // ring of the last three gradient-magnitude rows
 	int axr[2][8];           // ring of |gx| of the last two gradient rows (direction class is evaluated at NMS time)
 	bool ngr[2][8];          // ring of sign(gx^gy)
@@ -163,8 +162,7 @@ __global__ __launch_bounds__(kCannyWaves * 64) void canny_tile_kernel(CannyArgs 
 		int (&gD)[10] = gr[gNew];
 		const int (&gC)[10] = gr[gMid];
 		const int (&gU)[10] = gr[gOld];
-		if constexpr (KS == 3) st.template push<PH & 1>(rb, gD, axr[aNew], ngr[aNew]);
-		else st5.push(rb, gD, axr[aNew], ngr[aNew]);
+		st5.push(rb, gD, axr[aNew], ngr[aNew]);
 
 		const int yc = yin - R;
 		if (vEdgeTile) {
@@ -213,21 +211,7 @@ __global__ __launch_bounds__(kCannyWaves * 64) void canny_tile_kernel(CannyArgs 
 		}
 	};
 
-	if constexpr (KS == 3) {
-		static_assert((kTileH + 4) % 6 == 2, "row loop is unrolled by 6 with a 2-step tail");
-		int it = 0;
-		for (; it < kTileH + 4 - 2; it += 6) {
-			step(std::integral_constant<int, 0>{}, it);
-			step(std::integral_constant<int, 1>{}, it + 1);
-			step(std::integral_constant<int, 2>{}, it + 2);
-			step(std::integral_constant<int, 3>{}, it + 3);
-			step(std::integral_constant<int, 4>{}, it + 4);
-			step(std::integral_constant<int, 5>{}, it + 5);
-		}
-		step(std::integral_constant<int, 0>{}, it);
-		step(std::integral_constant<int, 1>{}, it + 1);
-	}
-	else {
+	{
 		// 5x5: plain rolled loop; phase 0 every step (new -> slot 0, centre = slot 2, old = slot 1), then shift the windows
 		for (int it = 0; it < kTileH + 2 + 2 * R; ++it) {
 			step(std::integral_constant<int, 0>{}, it);
@@ -522,25 +506,18 @@ __global__ void mean_thresholds_kernel(const unsigned int* __restrict__ sums, in
 // ---------------------------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------------------------
-// Kernel size 3 runs the SWAR + candidate-list kernel of canny_swar_kernels.hip; this file's register-ring kernel serves kernel size 5
-// (and, through CannyArgs::impl = 1, kernel size 3 as the measured alternative: compvhip_plan_create reads COMPVHIP_CANNY_IMPL=ring).
+// Kernel size 3 runs the SWAR + candidate-list kernel of canny_swar_kernels.hip; this file's register-ring kernel serves kernel size 5.
 // Both write E (edges so far), U (weak, unresolved) and the edge bytes of E; canny_resolve_kernel finishes the hysteresis.
 hipError_t launch_canny_tiles(const CannyArgs& a0, int frames, bool gap, hipStream_t stream)
 {
-	if (a0.ksize == 3 && a0.impl == 0) return launch_canny_tiles_swar(a0, frames, gap, stream);
+	if (a0.ksize == 3) return launch_canny_tiles_swar(a0, frames, gap, stream);
 	CannyArgs a = a0;
 	a.blockRows = (a.tilesY + kCannyWaves - 1) / kCannyWaves;
 	a.groups = a.blockRows * frames;
 	dim3 grid(8 * ((a.groups + 7) / 8) * a.tilesX);
 	dim3 block(kCannyWaves * 64);
-	if (a.ksize == 5) {
-		if (gap) hipLaunchKernelGGL((canny_tile_kernel<5, true>), grid, block, 0, stream, a);
-		else hipLaunchKernelGGL((canny_tile_kernel<5, false>), grid, block, 0, stream, a);
-	}
-	else {
-		if (gap) hipLaunchKernelGGL((canny_tile_kernel<3, true>), grid, block, 0, stream, a);
-		else hipLaunchKernelGGL((canny_tile_kernel<3, false>), grid, block, 0, stream, a);
-	}
+	if (gap) hipLaunchKernelGGL((canny5_tile_kernel<true>), grid, block, 0, stream, a);
+	else hipLaunchKernelGGL((canny5_tile_kernel<false>), grid, block, 0, stream, a);
 	return hipGetLastError();
 }
 

@@ -29,7 +29,6 @@ struct CannyArgs {
 	int simdEnd, cStart;      // quirk Q3 coverage: [1,simdEnd) U [cStart,W-1)
 	int blockRows, groups;    // filled by the launcher: workgroup rows per frame, row groups in the launch (XCD-aware map)
 	int ksize;                // Sobel kernel size of the gradient: 3 or 5
-	int impl;                 // kernel size 3: 0 = SWAR + candidate-list kernel (canny_swar_kernels.hip), 1 = register-ring kernel (canny_kernels.hip)
 };
 
 struct ResolveArgs {

@@ -182,28 +182,6 @@ def test_houghsht_wide_rho_range(hip_ctx, oracle, W, H):
     assert _lines_tuple(lines) == _orc_tuple(exp)
 
 
-def test_canny_ring_kernel_alternative(oracle, monkeypatch):
-    """Kernel size 3 has two tile kernels: the SWAR + candidate-list kernel (default) and the register-ring kernel that also serves
-    kernel size 5.  COMPVHIP_CANNY_IMPL=ring is read at every plan creation (a context's host plan included): same edge maps, with the
-    Q3 coverage gap, in place, and on a long weak chain that the band kernel has to flood."""
-    from compv_amd import capi
-    monkeypatch.setenv("COMPVHIP_CANNY_IMPL", "ring")
-    ctx = capi.Context(0)
-    try:
-        for (W, H) in [(20, 20), (513, 65), (641, 480), (1282, 720)]:
-            img = synth_frame(W, H, 7 + H)
-            for (tl, th) in [(59.0, 119.0), (0.8, 1.6)]:
-                rc, exp = oracle.canny(img, tl, th)
-                got = ctx.canny(img, tl, th)
-                assert (got == exp).all(), (W, H, tl, int((got != exp).sum()))
-        buf = synth_frame(300, 200, 5).copy()
-        rc, exp = oracle.canny(buf, 59.0, 119.0)
-        ctx.canny(buf, 59.0, 119.0, out=buf)
-        assert (buf == exp).all()
-    finally:
-        ctx.close()
-
-
 def test_canny_documented_deviations(hip_ctx, oracle):
     """Two DEFINED deviations from the reference, pinned as such:
     * thresholds above 32767: the reference's SIMD leaves compare them as signed int16 and its scalar remainder as unsigned -- an artefact
