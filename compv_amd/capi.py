@@ -39,7 +39,7 @@ EXPORTS = [
     "compvhip_gauss_kernel_fixedpoint", "compvhip_convlt1_fixedpoint_u8", "compvhip_plan_convlt1_fixedpoint", "compvhip_plan_to_cartesian",
     "compvhip_plan_pipeline_async", "compvhip_plan_wait", "compvhip_houghsht_to_cartesian", "compvhip_houghkht_to_cartesian",
     "compvhip_houghkht_kernels_u8", "compvhip_houghkht_stage_ms", "compvhip_convlt1_8u16s16s", "compvhip_convlt1_16s16s16s",
-    "compvhip_plan_pipeline_ex",
+    "compvhip_plan_pipeline_ex", "compvhip_plan_houghkht", "compvhip_plan_houghkht_stage_ms",
 ]
 
 
@@ -125,6 +125,8 @@ def load():
     L.compvhip_plan_pipeline.argtypes = [vp, vp, C.c_float, C.c_float, i32, i32, vp, vp, sz, vp, vp]
     L.compvhip_plan_pipeline_async.argtypes = [vp, vp, C.c_float, C.c_float, i32, i32, vp, vp, sz, vp, vp, C.POINTER(i32)]
     L.compvhip_plan_wait.argtypes = [vp, i32]
+    L.compvhip_plan_houghkht.argtypes = [vp, vp, C.c_float, C.c_float, i32, i32, C.c_double, sz, C.c_double, vp, sz, vp, vp, i32]
+    L.compvhip_plan_houghkht_stage_ms.argtypes = [vp, vp, C.POINTER(C.c_double), C.POINTER(i32)]
     L.compvhip_plan_pipeline_ex.argtypes = [vp, vp, C.POINTER(PipelineOpts), vp, vp, sz, vp, vp, C.POINTER(i32)]
     L.compvhip_plan_acc.argtypes = [vp, sz, C.POINTER(vp), C.POINTER(sz), C.POINTER(sz), C.POINTER(sz)]
     L.compvhip_plan_acc_export.argtypes = [vp, sz, vp, sz, vp]
@@ -342,6 +344,25 @@ class Plan:
         self.ctx._chk(self.lib.compvhip_plan_pipeline_ex(self.h, d_in, C.byref(o), d_edges, d_lines, line_cap, d_counts, stream,
                                                          C.byref(t) if asynchronous else None))
         return t.value if asynchronous else None
+
+    def houghkht(self, d_edges, rho=1.0, theta_deg=1.0, threshold=1, max_lines=0, min_dev=2.0, min_size=10, min_height=0.002, cap=1 << 14, threads=0):
+        """CompVHoughKht::process on the plan's device edge maps; returns ([lines of frame f as a LINE_DTYPE array], [GS of frame f or None])."""
+        F = self.frames
+        lines = np.zeros((F, cap), LINE_DTYPE)
+        counts = np.zeros(F, np.uint64)
+        gs = np.full(F, np.nan, np.float64)
+        self.ctx._chk(self.lib.compvhip_plan_houghkht(self.h, d_edges, rho, theta_deg, threshold, max_lines, min_dev, min_size, min_height,
+                                                      _ptr(lines), cap, _ptr(counts), _ptr(gs), threads))
+        return [lines[f][:int(counts[f])] for f in range(F)], [None if np.isnan(g) else float(g) for g in gs]
+
+    def houghkht_stage_ms(self):
+        ms = (C.c_double * 6)(); wall = C.c_double(0); th = C.c_int(0)
+        self.ctx._chk(self.lib.compvhip_plan_houghkht_stage_ms(self.h, ms, C.byref(wall), C.byref(th)))
+        names = ["link", "subdivide", "statistics", "prune_gmin", "vote_peaks", "sort_sweep"]
+        F = max(1, self.frames)
+        host = ms[0] + ms[3] + ms[5]
+        return {"stages": {n: round(ms[i] / F, 4) for i, n in enumerate(names)}, "wall_ms": wall.value, "threads": th.value,
+                "host_share": round(host / max(sum(ms), 1e-9), 3)}
 
     def wait(self, ticket):
         self.ctx._chk(self.lib.compvhip_plan_wait(self.h, ticket))

@@ -9,7 +9,9 @@
 #include "kernels.hpp"
 #include "kht.hpp"
 
+#include <atomic>
 #include <chrono>
+#include <thread>
 
 #include <hip/hip_runtime.h>
 
@@ -31,10 +33,30 @@ constexpr int kAsyncDepth = 4;            // outstanding compvhip_plan_pipeline_
 constexpr size_t kMaxTimeline = 4096;     // timing entries kept while nobody reads them (asynchronous steps)
 } // namespace
 
+// Device + host scratch of ONE KHT frame in flight: the context owns one for its host entry point, a plan one per worker thread of
+// compvhip_plan_houghkht (every worker has its own HIP stream; nothing in here is shared between threads).
+struct KhtScratch {
+	hipStream_t stream = nullptr; bool ownStream = false;
+	int32_t* counts = nullptr; size_t countsElems = 0;
+	KhtVoteParams* params = nullptr; size_t paramsCap = 0;
+	KhtCell* cells = nullptr; size_t cellsCap = 0;
+	int* cellCount = nullptr;
+	KhtPoint* pts = nullptr; size_t ptsCap = 0;
+	KhtSpan* spans = nullptr; size_t spansCap = 0;
+	KhtKernel* kernelsDev = nullptr;
+	KhtStringDesc* strings = nullptr; size_t stringsCap = 0;
+	uint32_t* counts32 = nullptr;
+	KhtSpan* scratch = nullptr;
+	KhtSubdivFrame* stack = nullptr;
+	uint8_t* hostEdges = nullptr; size_t hostEdgesBytes = 0;   // pinned: one frame's edge map downloaded from the device (plan workers)
+	double stageMs[6] = {};   // link, subdivide (GPU), statistics (GPU), prune + Gmin, vote + peaks (GPU), sort + sweep: last frame (ctx) / sums (plan worker)
+	std::string err;
+};
+
 struct compvhip_ctx {
 	int device = 0;
 	std::string err;
-	long live = 0;
+	std::atomic<long> live{0};   // hipMalloc / hipFree balance; KHT workers of a plan allocate from their own threads
 	hipStream_t stream = nullptr;      // stream of the host entry points
 	compvhip_plan* hostPlan = nullptr; // single-frame plan cached for the host entry points
 	uint8_t* dIn = nullptr;            // device staging of the host entry points
@@ -45,19 +67,7 @@ struct compvhip_ctx {
 	compvhip_line* dLines = nullptr; size_t dLinesCap = 0;
 	int32_t* dCounts = nullptr;
 	int32_t* dAccOut = nullptr; size_t dAccOutElems = 0;
-	// KHT scratch (device)
-	int32_t* khtCounts = nullptr; size_t khtCountsElems = 0;
-	KhtVoteParams* khtParams = nullptr; size_t khtParamsCap = 0;
-	KhtCell* khtCells = nullptr; size_t khtCellsCap = 0;
-	int* khtCellCount = nullptr;
-	KhtPoint* khtPts = nullptr; size_t khtPtsCap = 0;
-	KhtSpan* khtSpans = nullptr; size_t khtSpansCap = 0;
-	KhtKernel* khtKernelsDev = nullptr;
-	KhtStringDesc* khtStrings = nullptr; size_t khtStringsCap = 0;
-	uint32_t* khtCounts32 = nullptr;
-	KhtSpan* khtScratch = nullptr;
-	KhtSubdivFrame* khtStack = nullptr;
-	double khtStageMs[6] = {};   // link, subdivide (GPU), statistics (GPU), prune + Gmin, vote + peaks (GPU), sort + sweep of the last KHT call
+	KhtScratch kht;                    // KHT scratch of the host entry point (compvhip_houghkht_u8)
 };
 
 struct TimingEntry { const char* name; hipEvent_t a, b; };
@@ -107,6 +117,9 @@ struct compvhip_plan {
 	ShtTileArgs vt = {};                         // geometry + device tables
 	std::vector<int32_t> vtKt, vtRowBase;        // host copies of the [tiles][T] tables
 	int32_t* dKt = nullptr; int32_t* dRowBase = nullptr; uint16_t* partial = nullptr; int* tileCounts = nullptr;
+	// batched KHT (compvhip_plan_houghkht): one scratch set + stream per worker thread, stage clocks of the last call
+	std::vector<KhtScratch*> khtWorkers;
+	double khtStageMs[6] = {}; double khtWallMs = 0.0; int khtThreads = 0;
 	// asynchronous steps (compvhip_plan_pipeline_async / compvhip_plan_wait)
 	struct AsyncStep { bool used = false; hipEvent_t done = nullptr; hipStream_t stream = nullptr; StepParams sp; } steps[kAsyncDepth];
 	// timing
@@ -145,6 +158,15 @@ void dfree(compvhip_ctx* ctx, T*& p)
 }
 
 size_t alignUp(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+void khtScratchFree(compvhip_ctx* ctx, KhtScratch& k)
+{
+	dfree(ctx, k.counts); dfree(ctx, k.params); dfree(ctx, k.cells); dfree(ctx, k.cellCount);
+	dfree(ctx, k.pts); dfree(ctx, k.spans); dfree(ctx, k.kernelsDev);
+	dfree(ctx, k.strings); dfree(ctx, k.counts32); dfree(ctx, k.scratch); dfree(ctx, k.stack);
+	if (k.hostEdges) { (void)hipHostFree(k.hostEdges); k.hostEdges = nullptr; k.hostEdgesBytes = 0; }
+	if (k.ownStream && k.stream) { (void)hipStreamDestroy(k.stream); k.stream = nullptr; }
+}
 
 // ---- thresholds: core/features/edges/compv_core_feature_canny_dete.cxx:251-266 (COMPARE_TO_GRADIENT branch) ----
 // cosf / sinf exactly as the reference's scalar calls resolve them (never merged into sincosf)
@@ -540,15 +562,13 @@ void compvhip_ctx_destroy(compvhip_ctx* ctx)
 	if (ctx->hostPlan) compvhip_plan_destroy(ctx->hostPlan);
 	dfree(ctx, ctx->dPacked); dfree(ctx, ctx->dHist);
 	dfree(ctx, ctx->dIn); dfree(ctx, ctx->dOut); dfree(ctx, ctx->dLines); dfree(ctx, ctx->dCounts); dfree(ctx, ctx->dAccOut);
-	dfree(ctx, ctx->khtCounts); dfree(ctx, ctx->khtParams); dfree(ctx, ctx->khtCells); dfree(ctx, ctx->khtCellCount);
-	dfree(ctx, ctx->khtPts); dfree(ctx, ctx->khtSpans); dfree(ctx, ctx->khtKernelsDev);
-	dfree(ctx, ctx->khtStrings); dfree(ctx, ctx->khtCounts32); dfree(ctx, ctx->khtScratch); dfree(ctx, ctx->khtStack);
+	khtScratchFree(ctx, ctx->kht);
 	if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
 	delete ctx;
 }
 
 const char* compvhip_last_error(const compvhip_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
-long compvhip_live_allocations(const compvhip_ctx* ctx) { return ctx ? ctx->live : 0; }
+long compvhip_live_allocations(const compvhip_ctx* ctx) { return ctx ? ctx->live.load() : 0; }
 
 int compvhip_houghsht_to_cartesian(size_t W, size_t H, const compvhip_line* lines, size_t n, float* out)
 {
@@ -650,6 +670,8 @@ void compvhip_plan_destroy(compvhip_plan* p)
 	dfree(ctx, p->ebits); dfree(ctx, p->ubits); dfree(ctx, p->counters); dfree(ctx, p->thrDev); dfree(ctx, p->sums); dfree(ctx, p->tmpOut);
 	if (p->hFlags) (void)hipHostFree(p->hFlags);
 	dfree(ctx, p->hist); dfree(ctx, p->otsu); dfree(ctx, p->blurTmp); dfree(ctx, p->grayTmp);
+	for (KhtScratch* k : p->khtWorkers) { khtScratchFree(ctx, *k); delete k; }
+	p->khtWorkers.clear();
 	dfree(ctx, p->cosT); dfree(ctx, p->invSinT);
 	dfree(ctx, p->dKt); dfree(ctx, p->dRowBase); dfree(ctx, p->partial);
 	dfree(ctx, p->sinQ); dfree(ctx, p->cosQ); dfree(ctx, p->edges); dfree(ctx, p->acc);
@@ -1350,8 +1372,13 @@ int compvhip_houghsht_u8(compvhip_ctx* ctx, const uint8_t* edges, size_t W, size
 	return COMPVHIP_OK;
 }
 
+// ---- KHT -----------------------------------------------------------------------------------------------------------------------
+// All of it works on ONE KhtScratch (its stream, its device buffers) and reports failures through K.err: the batched entry point runs
+// several of these at the same time on worker threads, so nothing below touches ctx->err or any other shared state (ctx->live is atomic).
+#define KCHK(K, call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { (K).err = std::string(#call) + ": " + hipGetErrorString(e__); return COMPVHIP_E_HIP; } } while (0)
+
 // host linking, then cluster subdivision (kht_subdivide_kernel) and per-cluster statistics (kht_stats_kernel) on the GPU; kernels in cluster order
-static int khtBuildKernels(compvhip_ctx* ctx, const uint8_t* edges, size_t W, size_t H, size_t S, double clusterMinDeviation, size_t clusterMinSize,
+static int khtBuildKernels(compvhip_ctx* ctx, KhtScratch& K, const uint8_t* edges, size_t W, size_t H, size_t S, double clusterMinDeviation, size_t clusterMinSize,
                            std::vector<KhtKernel>& kernels, double& hmax)
 {
 	using clk = std::chrono::steady_clock;
@@ -1364,11 +1391,11 @@ static int khtBuildKernels(compvhip_ctx* ctx, const uint8_t* edges, size_t W, si
 	std::vector<KhtPos> poss; std::vector<KhtRange> strings;
 	khtLink(work.data(), W, H, W, clusterMinSize, poss, strings);
 	const auto t1 = clk::now();
-	ctx->khtStageMs[0] = ms(t0, t1);
+	K.stageMs[0] += ms(t0, t1);
 	if (strings.empty()) return COMPVHIP_OK;
-	if (poss.size() > 0x7fffffffull) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "too many edge pixels");
+	if (poss.size() > 0x7fffffffull) { K.err = "too many edge pixels"; return COMPVHIP_E_INVALID_PARAMETER; }
 
-	// device: cluster subdivision (one thread per string), per-cluster statistics (one thread per cluster)
+	// device: cluster subdivision (one wave per string), per-cluster statistics (one thread per cluster)
 	std::vector<KhtPoint> pts(poss.size());
 	for (size_t i = 0; i < poss.size(); ++i) { pts[i].x = poss[i].x; pts[i].y = poss[i].y; }
 	std::vector<KhtStringDesc> descs(strings.size());
@@ -1378,45 +1405,122 @@ static int khtBuildKernels(compvhip_ctx* ctx, const uint8_t* edges, size_t W, si
 		descs[i].slot = static_cast<uint32_t>(slots);
 		slots += khtSubdivSlots(strings[i].end - strings[i].begin, clusterMinSize);
 	}
-	HIPCHK(ctx, hipSetDevice(ctx->device));
-	if (ctx->khtPtsCap < pts.size()) { dfree(ctx, ctx->khtPts); ctx->khtPtsCap = 0; HIPCHK(ctx, dmalloc(ctx, &ctx->khtPts, pts.size())); ctx->khtPtsCap = pts.size(); }
-	if (ctx->khtStringsCap < descs.size()) {
-		dfree(ctx, ctx->khtStrings); dfree(ctx, ctx->khtCounts32); ctx->khtStringsCap = 0;
-		HIPCHK(ctx, dmalloc(ctx, &ctx->khtStrings, descs.size())); HIPCHK(ctx, dmalloc(ctx, &ctx->khtCounts32, descs.size() + 1)); ctx->khtStringsCap = descs.size();
+	KCHK(K, hipSetDevice(ctx->device));
+	if (K.ptsCap < pts.size()) { dfree(ctx, K.pts); K.ptsCap = 0; KCHK(K, dmalloc(ctx, &K.pts, pts.size())); K.ptsCap = pts.size(); }
+	if (K.stringsCap < descs.size()) {
+		dfree(ctx, K.strings); dfree(ctx, K.counts32); K.stringsCap = 0;
+		KCHK(K, dmalloc(ctx, &K.strings, descs.size())); KCHK(K, dmalloc(ctx, &K.counts32, descs.size() + 2)); K.stringsCap = descs.size();
 	}
-	if (ctx->khtSpansCap < slots) {
-		dfree(ctx, ctx->khtSpans); dfree(ctx, ctx->khtScratch); dfree(ctx, ctx->khtStack); dfree(ctx, ctx->khtKernelsDev); ctx->khtSpansCap = 0;
-		HIPCHK(ctx, dmalloc(ctx, &ctx->khtSpans, slots)); HIPCHK(ctx, dmalloc(ctx, &ctx->khtScratch, slots)); HIPCHK(ctx, dmalloc(ctx, &ctx->khtStack, slots));
-		HIPCHK(ctx, dmalloc(ctx, &ctx->khtKernelsDev, slots)); ctx->khtSpansCap = slots;
+	if (K.spansCap < slots) {
+		dfree(ctx, K.spans); dfree(ctx, K.scratch); dfree(ctx, K.stack); dfree(ctx, K.kernelsDev); K.spansCap = 0;
+		KCHK(K, dmalloc(ctx, &K.spans, slots)); KCHK(K, dmalloc(ctx, &K.scratch, slots)); KCHK(K, dmalloc(ctx, &K.stack, slots));
+		KCHK(K, dmalloc(ctx, &K.kernelsDev, slots)); K.spansCap = slots;
 	}
-	hipStream_t st = ctx->stream;
-	HIPCHK(ctx, hipMemcpyAsync(ctx->khtPts, pts.data(), pts.size() * sizeof(KhtPoint), hipMemcpyHostToDevice, st));
-	HIPCHK(ctx, hipMemcpyAsync(ctx->khtStrings, descs.data(), descs.size() * sizeof(KhtStringDesc), hipMemcpyHostToDevice, st));
+	hipStream_t st = K.stream;
+	KCHK(K, hipMemcpyAsync(K.pts, pts.data(), pts.size() * sizeof(KhtPoint), hipMemcpyHostToDevice, st));
+	KCHK(K, hipMemcpyAsync(K.strings, descs.data(), descs.size() * sizeof(KhtStringDesc), hipMemcpyHostToDevice, st));
 	KhtSubdivArgs sv;
-	sv.pts = ctx->khtPts; sv.strings = ctx->khtStrings; sv.nStrings = static_cast<int>(descs.size());
+	sv.pts = K.pts; sv.strings = K.strings; sv.nStrings = static_cast<int>(descs.size());
 	sv.minSize = static_cast<int>(std::min<size_t>(clusterMinSize, 0x7fffffff)); sv.minDev = clusterMinDeviation;
-	sv.scratch = ctx->khtScratch; sv.stack = ctx->khtStack; sv.counts = ctx->khtCounts32; sv.clusters = ctx->khtSpans; sv.total = ctx->khtCounts32 + descs.size();
-	HIPCHK(ctx, launch_kht_subdivide(sv, st));
-	uint32_t nClusters = 0;
-	HIPCHK(ctx, hipMemcpyAsync(&nClusters, sv.total, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-	HIPCHK(ctx, hipStreamSynchronize(st));
+	sv.scratch = K.scratch; sv.stack = K.stack; sv.counts = K.counts32; sv.clusters = K.spans; sv.total = K.counts32 + descs.size();
+	KCHK(K, hipMemsetAsync(sv.total, 0, 2 * sizeof(uint32_t), st));   // [0] cluster total, [1] "recursion truncated" flag
+	KCHK(K, launch_kht_subdivide(sv, st));
+	uint32_t tot[2] = { 0, 0 };
+	KCHK(K, hipMemcpyAsync(tot, sv.total, sizeof(tot), hipMemcpyDeviceToHost, st));
+	KCHK(K, hipStreamSynchronize(st));
+	if (tot[1]) { K.err = "cluster subdivision ran out of recursion slots"; return COMPVHIP_E_INVALID_STATE; } // never for clusterMinSize >= 2 (khtSubdivSlots bounds the depth)
+	const uint32_t nClusters = tot[0];
 	const auto t2 = clk::now();
-	ctx->khtStageMs[1] = ms(t1, t2);
+	K.stageMs[1] += ms(t1, t2);
 	if (!nClusters) return COMPVHIP_OK;
 	const size_t n = nClusters;
 	KhtStatsArgs sa;
-	sa.pts = ctx->khtPts; sa.clusters = ctx->khtSpans; sa.n = static_cast<int>(n);
+	sa.pts = K.pts; sa.clusters = K.spans; sa.n = static_cast<int>(n);
 	const size_t pack = n >= 4 ? 4 : (n >= 2 ? 2 : 1); // the reference's AVX (4) / SSE2 (2) kernel-height loops take n & ~(pack - 1) clusters
 	sa.simdEnd = static_cast<int>(pack > 1 ? (n & ~(pack - 1)) : 0);
 	sa.hw = static_cast<double>(W) * 0.5; sa.hh = static_cast<double>(H) * 0.5;
-	sa.out = ctx->khtKernelsDev;
-	HIPCHK(ctx, launch_kht_stats(sa, st));
+	sa.out = K.kernelsDev;
+	KCHK(K, launch_kht_stats(sa, st));
 	kernels.resize(n);
-	HIPCHK(ctx, hipMemcpyAsync(kernels.data(), ctx->khtKernelsDev, n * sizeof(KhtKernel), hipMemcpyDeviceToHost, st));
-	HIPCHK(ctx, hipStreamSynchronize(st));
+	KCHK(K, hipMemcpyAsync(kernels.data(), K.kernelsDev, n * sizeof(KhtKernel), hipMemcpyDeviceToHost, st));
+	KCHK(K, hipStreamSynchronize(st));
 	khtFinishKernels(kernels, hmax);
-	ctx->khtStageMs[2] = ms(t2, clk::now());
+	K.stageMs[2] += ms(t2, clk::now());
 	return COMPVHIP_OK;
+}
+
+// one frame, host edge map -> lines in the reference's order (the body of CompVHoughKht::process, houghkht.cxx:208-447)
+static int khtFrame(compvhip_ctx* ctx, KhtScratch& K, const uint8_t* edges, size_t W, size_t H, size_t S, const KhtAxes& ax, int threshold, int maxLines,
+                    double clusterMinDeviation, size_t clusterMinSize, double kernelMinHeight, std::vector<KhtLine>& out, double* gs)
+{
+	using clk = std::chrono::steady_clock;
+	auto msSince = [](clk::time_point a) { return std::chrono::duration<double, std::milli>(clk::now() - a).count(); };
+	out.clear();
+	std::vector<KhtKernel> kernels;
+	double hmax = 0.0;
+	const int rck = khtBuildKernels(ctx, K, edges, W, H, S, clusterMinDeviation, clusterMinSize, kernels, hmax);
+	if (rck) return rck;
+	if (kernels.empty()) return COMPVHIP_OK;
+	auto t3 = clk::now();
+	const double GS = khtPruneAndScale(kernels, hmax, kernelMinHeight);
+	if (kernels.empty()) return COMPVHIP_OK;
+	if (gs) *gs = GS;
+	std::vector<KhtVoteParams> params;
+	khtVoteParams(ax, kernels, params);
+
+	// device: Gaussian voting + smoothing/threshold
+	KCHK(K, hipSetDevice(ctx->device));
+	const int stride = static_cast<int>(alignUp(ax.rhoN + 2, 16));
+	const size_t countsElems = (ax.T + 2) * static_cast<size_t>(stride);
+	if (K.countsElems < countsElems) { dfree(ctx, K.counts); K.countsElems = 0; KCHK(K, dmalloc(ctx, &K.counts, countsElems)); K.countsElems = countsElems; }
+	if (K.paramsCap < params.size()) { dfree(ctx, K.params); K.paramsCap = 0; KCHK(K, dmalloc(ctx, &K.params, params.size())); K.paramsCap = params.size(); }
+	const size_t cellCap = ax.T * ax.rhoN;
+	if (K.cellsCap < cellCap) { dfree(ctx, K.cells); K.cellsCap = 0; KCHK(K, dmalloc(ctx, &K.cells, cellCap)); K.cellsCap = cellCap; }
+	if (!K.cellCount) KCHK(K, dmalloc(ctx, &K.cellCount, 1));
+	hipStream_t st = K.stream;
+	K.stageMs[3] += msSince(t3);
+	t3 = clk::now();
+	KCHK(K, hipMemsetAsync(K.counts, 0, countsElems * sizeof(int32_t), st));
+	KCHK(K, hipMemsetAsync(K.cellCount, 0, sizeof(int), st));
+	KCHK(K, hipMemcpyAsync(K.params, params.data(), params.size() * sizeof(KhtVoteParams), hipMemcpyHostToDevice, st));
+	KhtGpuArgs a;
+	a.params = K.params; a.nKernels = static_cast<int>(params.size()); a.counts = K.counts; a.stride = stride;
+	a.rhoN = static_cast<int>(ax.rhoN); a.T = static_cast<int>(ax.T); a.dRho = ax.dRho; a.dThetaDeg = ax.dThetaDeg; a.gs = GS;
+	a.threshold = threshold; a.cells = K.cells; a.cellCount = K.cellCount; a.cellCap = static_cast<int>(cellCap);
+	KCHK(K, launch_kht_vote(a, st));
+	KCHK(K, launch_kht_peaks(a, st));
+	int cellCount = 0;
+	KCHK(K, hipMemcpyAsync(&cellCount, K.cellCount, sizeof(int), hipMemcpyDeviceToHost, st));
+	KCHK(K, hipStreamSynchronize(st));
+	std::vector<KhtCell> cells(static_cast<size_t>(std::min<int>(cellCount, static_cast<int>(cellCap))));
+	if (!cells.empty()) {
+		KCHK(K, hipMemcpyAsync(cells.data(), K.cells, cells.size() * sizeof(KhtCell), hipMemcpyDeviceToHost, st));
+		KCHK(K, hipStreamSynchronize(st));
+	}
+	K.stageMs[4] += msSince(t3);
+	t3 = clk::now();
+	// host: sort + sweep (order dependent, :1195-1247)
+	khtPeaks(ax, cells, maxLines, out);
+	K.stageMs[5] += msSince(t3);
+	return COMPVHIP_OK;
+}
+
+static int khtCheckParams(compvhip_ctx* ctx, size_t W, size_t H, float rho, float thetaDeg, int threshold, size_t clusterMinSize, double kernelMinHeight, KhtAxes& ax)
+{
+	if (!(rho > 0.f) || rho > 1.f || !(thetaDeg > 0.f) || threshold <= 0) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "rho in (0,1], theta > 0, threshold > 0"); // :146-163,491
+	if (!clusterMinSize || !(kernelMinHeight >= 0.0)) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "invalid KHT knob"); // :169-186 (the deviation is unchecked there)
+	if (!W || !H || W > 32767 || H > 32767) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "image size out of range");
+	if (!khtAxes(W, H, rho, thetaDeg, ax)) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "degenerate KHT parameter space");
+	return COMPVHIP_OK;
+}
+
+static void khtCopyLines(const std::vector<KhtLine>& out, compvhip_line* lines, size_t cap)
+{
+	const size_t ncopy = std::min(out.size(), cap);
+	for (size_t i = 0; i < ncopy; ++i) {
+		lines[i].rho = out[i].rho; lines[i].theta = out[i].theta; lines[i].strength = out[i].strength;
+		lines[i].row = out[i].rhoIndex; lines[i].col = out[i].thetaIndex;
+	}
 }
 
 int compvhip_houghkht_kernels_u8(compvhip_ctx* ctx, const uint8_t* edges, size_t W, size_t H, size_t S, double clusterMinDeviation, size_t clusterMinSize,
@@ -1426,8 +1530,10 @@ int compvhip_houghkht_kernels_u8(compvhip_ctx* ctx, const uint8_t* edges, size_t
 	if (!edges || !n || (cap && !kernels7) || S < W || !W || !H || !clusterMinSize) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "null/invalid argument");
 	if (W > 32767 || H > 32767) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "image size out of range");
 	std::vector<KhtKernel> kernels; double hm = 0.0;
-	const int rc = khtBuildKernels(ctx, edges, W, H, S, clusterMinDeviation, clusterMinSize, kernels, hm);
-	if (rc) return rc;
+	ctx->kht.stream = ctx->stream;
+	memset(ctx->kht.stageMs, 0, sizeof(ctx->kht.stageMs));
+	const int rc = khtBuildKernels(ctx, ctx->kht, edges, W, H, S, clusterMinDeviation, clusterMinSize, kernels, hm);
+	if (rc) return fail(ctx, rc, ctx->kht.err.c_str());
 	*n = kernels.size();
 	if (hmax) *hmax = hm;
 	for (size_t i = 0; i < std::min(kernels.size(), cap); ++i) {
@@ -1442,76 +1548,115 @@ int compvhip_houghkht_kernels_u8(compvhip_ctx* ctx, const uint8_t* edges, size_t
 int compvhip_houghkht_stage_ms(compvhip_ctx* ctx, double* ms6)
 {
 	if (!ctx || !ms6) return COMPVHIP_E_INVALID_PARAMETER;
-	memcpy(ms6, ctx->khtStageMs, sizeof(ctx->khtStageMs));
+	memcpy(ms6, ctx->kht.stageMs, sizeof(ctx->kht.stageMs));
 	return COMPVHIP_OK;
 }
 
 int compvhip_houghkht_u8(compvhip_ctx* ctx, const uint8_t* edges, size_t W, size_t H, size_t S, float rho, float thetaDeg, int threshold, int maxLines,
                          double clusterMinDeviation, size_t clusterMinSize, double kernelMinHeight, compvhip_line* lines, size_t cap, size_t* n, double* gs)
 {
-	using clk = std::chrono::steady_clock;
-	auto msSince = [](clk::time_point a) { return std::chrono::duration<double, std::milli>(clk::now() - a).count(); };
 	if (!ctx) return COMPVHIP_E_INVALID_PARAMETER;
 	if (!edges || !n || (cap && !lines) || S < W || !W || !H) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "null/invalid argument"); // houghkht.cxx:210-211
-	if (!(rho > 0.f) || rho > 1.f || !(thetaDeg > 0.f) || threshold <= 0) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "rho in (0,1], theta > 0, threshold > 0"); // :146-163,491
-	if (!clusterMinSize || !(kernelMinHeight >= 0.0)) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "invalid KHT knob"); // :169-186 (the deviation is unchecked there)
-	if (W > 32767 || H > 32767) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "image size out of range");
-	*n = 0;
-	memset(ctx->khtStageMs, 0, sizeof(ctx->khtStageMs));
 	KhtAxes ax;
-	if (!khtAxes(W, H, rho, thetaDeg, ax)) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "degenerate KHT parameter space");
-	std::vector<KhtKernel> kernels;
-	double hmax = 0.0;
-	const int rck = khtBuildKernels(ctx, edges, W, H, S, clusterMinDeviation, clusterMinSize, kernels, hmax);
-	if (rck) return rck;
-	if (kernels.empty()) return COMPVHIP_OK;
-	auto t3 = clk::now();
-	const double GS = khtPruneAndScale(kernels, hmax, kernelMinHeight);
-	if (kernels.empty()) return COMPVHIP_OK;
-	if (gs) *gs = GS;
-	std::vector<KhtVoteParams> params;
-	khtVoteParams(ax, kernels, params);
-
-	// device: Gaussian voting + smoothing/threshold
-	HIPCHK(ctx, hipSetDevice(ctx->device));
-	const int stride = static_cast<int>(alignUp(ax.rhoN + 2, 16));
-	const size_t countsElems = (ax.T + 2) * static_cast<size_t>(stride);
-	if (ctx->khtCountsElems < countsElems) { dfree(ctx, ctx->khtCounts); HIPCHK(ctx, dmalloc(ctx, &ctx->khtCounts, countsElems)); ctx->khtCountsElems = countsElems; }
-	if (ctx->khtParamsCap < params.size()) { dfree(ctx, ctx->khtParams); HIPCHK(ctx, dmalloc(ctx, &ctx->khtParams, params.size())); ctx->khtParamsCap = params.size(); }
-	const size_t cellCap = ax.T * ax.rhoN;
-	if (ctx->khtCellsCap < cellCap) { dfree(ctx, ctx->khtCells); HIPCHK(ctx, dmalloc(ctx, &ctx->khtCells, cellCap)); ctx->khtCellsCap = cellCap; }
-	if (!ctx->khtCellCount) HIPCHK(ctx, dmalloc(ctx, &ctx->khtCellCount, 1));
-	hipStream_t st = ctx->stream;
-	ctx->khtStageMs[3] = msSince(t3);
-	t3 = clk::now();
-	HIPCHK(ctx, hipMemsetAsync(ctx->khtCounts, 0, countsElems * sizeof(int32_t), st));
-	HIPCHK(ctx, hipMemsetAsync(ctx->khtCellCount, 0, sizeof(int), st));
-	HIPCHK(ctx, hipMemcpyAsync(ctx->khtParams, params.data(), params.size() * sizeof(KhtVoteParams), hipMemcpyHostToDevice, st));
-	KhtGpuArgs a;
-	a.params = ctx->khtParams; a.nKernels = static_cast<int>(params.size()); a.counts = ctx->khtCounts; a.stride = stride;
-	a.rhoN = static_cast<int>(ax.rhoN); a.T = static_cast<int>(ax.T); a.dRho = ax.dRho; a.dThetaDeg = ax.dThetaDeg; a.gs = GS;
-	a.threshold = threshold; a.cells = ctx->khtCells; a.cellCount = ctx->khtCellCount; a.cellCap = static_cast<int>(cellCap);
-	HIPCHK(ctx, launch_kht_vote(a, st));
-	HIPCHK(ctx, launch_kht_peaks(a, st));
-	int cellCount = 0;
-	HIPCHK(ctx, hipMemcpyAsync(&cellCount, ctx->khtCellCount, sizeof(int), hipMemcpyDeviceToHost, st));
-	HIPCHK(ctx, hipStreamSynchronize(st));
-	std::vector<KhtCell> cells(static_cast<size_t>(std::min<int>(cellCount, static_cast<int>(cellCap))));
-	if (!cells.empty()) HIPCHK(ctx, hipMemcpy(cells.data(), ctx->khtCells, cells.size() * sizeof(KhtCell), hipMemcpyDeviceToHost));
-
-	ctx->khtStageMs[4] = msSince(t3);
-	t3 = clk::now();
-	// host: sort + sweep (order dependent, :1195-1247)
+	int rc = khtCheckParams(ctx, W, H, rho, thetaDeg, threshold, clusterMinSize, kernelMinHeight, ax);
+	if (rc) return rc;
+	*n = 0;
+	ctx->kht.stream = ctx->stream;
+	memset(ctx->kht.stageMs, 0, sizeof(ctx->kht.stageMs));
 	std::vector<KhtLine> out;
-	khtPeaks(ax, cells, maxLines, out);
-	ctx->khtStageMs[5] = msSince(t3);
+	rc = khtFrame(ctx, ctx->kht, edges, W, H, S, ax, threshold, maxLines, clusterMinDeviation, clusterMinSize, kernelMinHeight, out, gs);
+	if (rc) return fail(ctx, rc, ctx->kht.err.c_str());
 	*n = out.size();
-	const size_t ncopy = std::min(out.size(), cap);
-	for (size_t i = 0; i < ncopy; ++i) {
-		lines[i].rho = out[i].rho; lines[i].theta = out[i].theta; lines[i].strength = out[i].strength;
-		lines[i].row = out[i].rhoIndex; lines[i].col = out[i].thetaIndex;
-	}
+	khtCopyLines(out, lines, cap);
 	if (out.size() > cap) return fail(ctx, COMPVHIP_E_OUT_OF_BOUND, "line buffer too small");
+	return COMPVHIP_OK;
+}
+
+// CompVHoughKht::process on the plan's `frames` device edge maps.  The chain walk of the linker (Appendix A) is sequential per frame and
+// stays on the host -- but frames are independent: a pool of host threads takes them in turn, each with its own HIP stream and scratch
+// buffers.  A worker downloads its frame (pinned buffer, asynchronous copy on its stream), links it, and drives the GPU stages of that
+// frame (subdivision, statistics, voting, peaks); while one worker links, the kernels and copies of the others run, so the GPU work
+// and the PCIe transfers of the batch hide under the host stage that bounds it.
+int compvhip_plan_houghkht(compvhip_plan* p, const uint8_t* d_edges, float rho, float thetaDeg, int threshold, int maxLines, double clusterMinDeviation,
+                           size_t clusterMinSize, double kernelMinHeight, compvhip_line* lines, size_t cap, size_t* counts, double* gs, int hostThreads)
+{
+	if (!p) return COMPVHIP_E_INVALID_PARAMETER;
+	compvhip_ctx* ctx = p->ctx;
+	if (!d_edges || !counts || (cap && !lines)) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "null/invalid argument");
+	const size_t W = p->W, H = p->H, S = p->S, F = p->frames;
+	KhtAxes ax;
+	int rc = khtCheckParams(ctx, W, H, rho, thetaDeg, threshold, clusterMinSize, kernelMinHeight, ax);
+	if (rc) return rc;
+	HIPCHK(ctx, hipSetDevice(ctx->device));
+	unsigned hw = std::thread::hardware_concurrency();
+	if (!hw) hw = 4;
+	size_t T = hostThreads > 0 ? static_cast<size_t>(hostThreads) : std::min<size_t>(16, std::max<size_t>(1, hw / 2));
+	T = std::min(T, F);
+	while (p->khtWorkers.size() < T) {
+		KhtScratch* k = new (std::nothrow) KhtScratch();
+		if (!k) return fail(ctx, COMPVHIP_E_OUT_OF_MEMORY, "KHT worker");
+		p->khtWorkers.push_back(k);
+		if (hipStreamCreateWithFlags(&k->stream, hipStreamNonBlocking) != hipSuccess) return fail(ctx, COMPVHIP_E_HIP, "KHT worker stream");
+		k->ownStream = true;
+	}
+	for (size_t t = 0; t < T; ++t) {
+		KhtScratch& K = *p->khtWorkers[t];
+		if (K.hostEdgesBytes < W * H) {
+			if (K.hostEdges) (void)hipHostFree(K.hostEdges);
+			K.hostEdges = nullptr; K.hostEdgesBytes = 0;
+			if (hipHostMalloc(reinterpret_cast<void**>(&K.hostEdges), W * H) != hipSuccess) return fail(ctx, COMPVHIP_E_OUT_OF_MEMORY, "pinned frame buffer");
+			K.hostEdgesBytes = W * H;
+		}
+		memset(K.stageMs, 0, sizeof(K.stageMs));
+		K.err.clear();
+	}
+	for (size_t f = 0; f < F; ++f) counts[f] = 0;
+	std::atomic<size_t> next{0};
+	std::vector<int> codes(T, COMPVHIP_OK);
+	std::vector<double> dlMs(T, 0.0);
+	std::atomic<int> overflow{0};
+	const auto wall0 = std::chrono::steady_clock::now();
+	auto work = [&](size_t t) {
+		KhtScratch& K = *p->khtWorkers[t];
+		if (hipSetDevice(ctx->device) != hipSuccess) { codes[t] = COMPVHIP_E_HIP; K.err = "hipSetDevice"; return; }
+		std::vector<KhtLine> out;
+		for (;;) {
+			const size_t f = next.fetch_add(1);
+			if (f >= F) break;
+			const auto d0 = std::chrono::steady_clock::now();
+			hipError_t e = hipMemcpy2DAsync(K.hostEdges, W, d_edges + f * S * H, S, W, H, hipMemcpyDeviceToHost, K.stream);
+			if (e == hipSuccess) e = hipStreamSynchronize(K.stream);
+			if (e != hipSuccess) { codes[t] = COMPVHIP_E_HIP; K.err = std::string("frame download: ") + hipGetErrorString(e); return; }
+			dlMs[t] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - d0).count();
+			const int r = khtFrame(ctx, K, K.hostEdges, W, H, W, ax, threshold, maxLines, clusterMinDeviation, clusterMinSize, kernelMinHeight, out, gs ? gs + f : nullptr);
+			if (r) { codes[t] = r; return; }
+			counts[f] = out.size();
+			if (lines) khtCopyLines(out, lines + f * cap, cap);
+			if (out.size() > cap) overflow.store(1);
+		}
+	};
+	if (T == 1) work(0);
+	else {
+		std::vector<std::thread> pool;
+		for (size_t t = 1; t < T; ++t) pool.emplace_back(work, t);
+		work(0);
+		for (auto& th : pool) th.join();
+	}
+	p->khtWallMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+	p->khtThreads = static_cast<int>(T);
+	memset(p->khtStageMs, 0, sizeof(p->khtStageMs));
+	for (size_t t = 0; t < T; ++t) for (int k = 0; k < 6; ++k) p->khtStageMs[k] += p->khtWorkers[t]->stageMs[k];
+	for (size_t t = 0; t < T; ++t) if (codes[t]) return fail(ctx, codes[t], p->khtWorkers[t]->err.c_str());
+	if (overflow.load()) return fail(ctx, COMPVHIP_E_OUT_OF_BOUND, "line buffer too small");
+	return COMPVHIP_OK;
+}
+
+int compvhip_plan_houghkht_stage_ms(compvhip_plan* p, double* ms6, double* wallMs, int* threads)
+{
+	if (!p || !ms6) return COMPVHIP_E_INVALID_PARAMETER;
+	memcpy(ms6, p->khtStageMs, sizeof(p->khtStageMs));
+	if (wallMs) *wallMs = p->khtWallMs;
+	if (threads) *threads = p->khtThreads;
 	return COMPVHIP_OK;
 }
 

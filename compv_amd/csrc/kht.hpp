@@ -59,7 +59,7 @@ struct KhtSubdivArgs {
 	KhtSubdivFrame* stack;     // per-string recursion stacks (same slot layout, + 2 frames per string)
 	uint32_t* counts;          // [nStrings] clusters found per string
 	KhtSpan* clusters;         // compacted, string order
-	uint32_t* total;           // [1]
+	uint32_t* total;           // [2]: clusters found in all strings; flag "a recursion ran out of stack slots" (zeroed by the caller)
 };
 // upper bound on the clusters (and on the recursion depth) of a string of `len` points
 __host__ __device__ inline size_t khtSubdivSlots(size_t len, size_t minSize) { const size_t m = minSize < 2 ? 2 : minSize; return (len > m ? (len - 1) / (m - 1) : 1) + 2; }

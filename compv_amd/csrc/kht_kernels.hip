@@ -94,9 +94,11 @@ __global__ __launch_bounds__(64) void kht_subdivide_kernel(KhtSubdivArgs a)
 			const int maxIndex = maxDev > 0 ? (int)~(uint32_t)(best & 0xffffffffull) : s;
 			const double length = __dsqrt_rn((double)((diffx * diffx) + (diffy * diffy)));
 			const double q = __ddiv_rn((double)maxDev, length);
-			f.ratio = __ddiv_rn(length, q > a.minDev ? q : a.minDev); // length / std::max(maxDev / length, minDev)
+			f.ratio = __ddiv_rn(length, (q < a.minDev) ? a.minDev : q); // length / std::max(maxDev / length, minDev), operand order included
 			f.keep = outCount; f.m = maxIndex;
-			if ((maxIndex - s + 1) >= a.minSize && (e - maxIndex + 1) >= a.minSize && maxIndex > s && sp < maxDepth) {
+			const bool split = (maxIndex - s + 1) >= a.minSize && (e - maxIndex + 1) >= a.minSize && maxIndex > s;
+			if (split && sp >= maxDepth) a.total[1] = 1u;   // out of recursion slots (khtSubdivSlots bounds the depth for minSize >= 2): the call fails
+			if (split && sp < maxDepth) {
 				f.state = 1;
 				st[sp].s = s; st[sp].e = maxIndex; st[sp].state = 0; ++sp;
 			}

@@ -272,6 +272,19 @@ typedef struct compvhip_pipeline_opts {
 COMPVHIP_API int compvhip_plan_pipeline_ex(compvhip_plan* plan, const uint8_t* d_in, const compvhip_pipeline_opts* opts, uint8_t* d_edges,
                                            compvhip_line* d_lines, size_t lineCap, int32_t* d_counts, void* stream, int* ticket);
 
+/* CompVHoughKht::process (compvhip_houghkht_u8 semantics, same knobs) on the plan's `frames` DEVICE edge maps d_edges = [frames][H][S]
+ * ({0, non-zero} bytes, e.g. the edge maps a compvhip_plan_canny / _pipeline call produced); results in HOST memory: lines[f * cap ..] /
+ * counts[f] / gs[f] (gs optional; gs[f] is left untouched for a frame without surviving kernels, like the reference's m_dGS).  Synchronous.
+ * The edge-linking stage is a sequential chain walk per frame and runs on the host; frames are independent, so hostThreads workers
+ * (0 = min(16, hardware threads / 2)) each take frames in turn with their own HIP stream: frame download, linking, and the GPU stages of
+ * one frame overlap with those of the other workers'.  COMPVHIP_E_OUT_OF_BOUND when a frame has more than cap lines (counts[f] tells).
+ * compvhip_plan_houghkht_stage_ms: the six stage clocks of the last call summed over its frames (compvhip_houghkht_stage_ms order), the wall
+ * time of the call and the number of workers. */
+COMPVHIP_API int compvhip_plan_houghkht(compvhip_plan* plan, const uint8_t* d_edges, float rho, float thetaDeg, int threshold, int maxLines,
+                                        double clusterMinDeviation, size_t clusterMinSize, double kernelMinHeight,
+                                        compvhip_line* lines, size_t cap, size_t* counts, double* gs, int hostThreads);
+COMPVHIP_API int compvhip_plan_houghkht_stage_ms(compvhip_plan* plan, double* ms6, double* wallMs, int* threads);
+
 /* Device accumulator of frame f after compvhip_plan_houghsht: uint16 (a cell never exceeds the pixels of a 1-px band),
  * theta-major [T][accPitch] (pitch >= R).  compvhip_plan_acc_export gives the reference's int32 rho-major layout. */
 COMPVHIP_API int compvhip_plan_acc(compvhip_plan* plan, size_t frame, const uint16_t** d_acc, size_t* R, size_t* T, size_t* accPitch);

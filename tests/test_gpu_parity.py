@@ -946,3 +946,50 @@ def test_bench_batches_match_the_reference_fixture(hip_ctx):
     finally:
         for q in lanes:
             q["plan"].close()
+
+
+def test_plan_houghkht_batch(hip_ctx, oracle, golden):
+    """compvhip_plan_houghkht (BASELINE config 5 as a throughput path): a batch of device edge maps, host linking on a pool of worker
+    threads pipelined with the GPU stages.  Every frame's line list (values AND order) and GS against the oracle -- frame 0 also against the
+    fixture recorded from the compiled reference -- for several pool sizes, with an empty frame in the batch, then the error contract."""
+    import torch
+    from compv_amd import capi
+    meta, arrays = golden
+    W, H, F = 1920, 1080, 7
+    dev = torch.device("cuda:0")
+    frames = np.stack([synth_frame(W, H, 12345 + f) for f in range(F)])
+    frames[5] = 77                                   # constant frame: no edges, no lines
+    d_in = torch.from_numpy(frames).to(dev)
+    d_e = torch.empty_like(d_in)
+    plan = capi.Plan(hip_ctx, W, H, W, F, 1.0)
+    try:
+        plan.canny(d_in.data_ptr(), 59.0, 119.0, d_e.data_ptr())
+        torch.cuda.synchronize()
+        exp = []
+        for f in range(F):
+            rc, e = oracle.canny(frames[f], 59.0, 119.0)
+            exp.append(oracle.kht(e, 1.0, 1.0, 1))
+        for threads in (1, 3, 0):
+            lines, gs = plan.houghkht(d_e.data_ptr(), 1.0, 1.0, 1, threads=threads)
+            for f in range(F):
+                el, egs = exp[f]
+                assert _kht_tuple(lines[f]) == [(float(np.float32(l[0])), float(np.float32(l[1])), int(l[2])) for l in el], (threads, f)
+                assert (gs[f] == egs) if len(el) else (gs[f] is None), (threads, f)
+            st = plan.houghkht_stage_ms()
+            assert st["threads"] == (threads if threads else st["threads"]) and st["wall_ms"] > 0 and st["stages"]["link"] > 0
+        assert len(lines[5]) == 0
+        m = meta["fhd_1920x1080"]["kht"]
+        assert repr(gs[0]) == m["gs"] and len(lines[0]) == m["lines"]
+        got = np.stack([lines[0]["rho"].astype(np.float64), lines[0]["theta"].astype(np.float64), lines[0]["strength"].astype(np.float64)], axis=1)
+        assert (got == arrays["fhd_1920x1080/kht_lines"]).all()
+        top, _ = plan.houghkht(d_e.data_ptr(), 1.0, 1.0, 1, max_lines=3)
+        assert _kht_tuple(top[0]) == _kht_tuple(lines[0][:3])
+        with pytest.raises(capi.CompvHipError) as err:
+            plan.houghkht(d_e.data_ptr(), 1.0, 1.0, 1, cap=2)            # fewer slots than lines
+        assert err.value.code == capi.E_OUT_OF_BOUND
+        with pytest.raises(capi.CompvHipError) as err:
+            plan.houghkht(d_e.data_ptr(), 2.0, 1.0, 1)                   # rho must be in (0, 1] (houghkht.cxx:146-163)
+        assert err.value.code == capi.E_INVALID_PARAMETER
+    finally:
+        plan.close()
+    assert hip_ctx.live_allocations() >= 0
