@@ -109,9 +109,10 @@ struct compvhip_plan {
 	int32_t* sinQ = nullptr; int32_t* cosQ = nullptr;
 	uint32_t* edges = nullptr; size_t edgeCap = 0; int* edgeCounts = nullptr;
 	uint16_t* acc = nullptr; size_t accFrameStride = 0;
-	uint64_t* keysA = nullptr; uint64_t* keysB = nullptr; size_t lineCap = 0; int* lineCounts = nullptr;
+	uint32_t* keysA = nullptr; uint32_t* keysB = nullptr; uint32_t* valsA = nullptr; uint32_t* valsB = nullptr; size_t lineCap = 0; int* lineCounts = nullptr;
+	uint8_t* nmsFlags = nullptr; uint32_t* rowBase = nullptr; // NMS survivors (flag planes) and their per-row ranks
 	void* sortTemp = nullptr; size_t sortTempBytes = 0;
-	int cellBits = 0, strengthBits = 16, keyBits = 0;
+	int strengthBits = 16, keyBits = 0;
 	// voting over image tiles (planned at plan creation: the per-tile edge counters live in `counters`)
 	bool voteTiles = false;                      // the tile grid exists
 	ShtTileArgs vt = {};                         // geometry + device tables
@@ -378,19 +379,23 @@ int ensureSht(compvhip_plan* p)
 	HIPCHK(ctx, dmalloc(ctx, &p->edges, p->edgeCap * p->frames));
 	HIPCHK(ctx, dmalloc(ctx, &p->acc, p->accFrameStride * p->frames));
 	HIPCHK(ctx, hipMemset(p->acc, 0, sizeof(uint16_t) * p->accFrameStride * p->frames)); // rows [Rp, accPitch) stay zero for ever
-	// line key = frameTag | strength (strengthBits) | cell index (cellBits): see sht_nms_kernel. A cell of column theta counts the
-	// pixels with (x*cosQ + y*sinQ) in one 65536-wide interval; max(|cosQ|,|sinQ|) >= 46340 so every x (or every y) contributes at
-	// most 2 pixels: count <= 2*max(W,H). Fewer key bits = fewer radix-sort passes.
+	// line key = frameTag | strength (strengthBits); the accumulator cell rides as the sort value (sht_nms / rank / emit kernels).  A cell of
+	// column theta counts the pixels with (x*cosQ + y*sinQ) in one 65536-wide interval; max(|cosQ|,|sinQ|) >= 46340 so every x (or every y)
+	// contributes at most 2 pixels: count <= 2*max(W,H).  Fewer key bits = fewer radix-sort passes.
 	p->strengthBits = 1;
 	while ((static_cast<size_t>(1) << p->strengthBits) <= 2 * (p->W > p->H ? p->W : p->H)) p->strengthBits++;
 	if (p->strengthBits > 16) p->strengthBits = 16; // the accumulator itself is u16
-	p->cellBits = 1;
-	while ((static_cast<size_t>(1) << p->cellBits) <= R * T) p->cellBits++;
 	int frameBits = 0;
 	while ((static_cast<size_t>(1) << frameBits) < p->frames) frameBits++;
-	p->keyBits = frameBits + p->strengthBits + p->cellBits;
-	if (p->cellBits > 31) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "theta step too small: the accumulator has 2^31 cells or more"); // 32-bit cell masks in the kernels
-	if (p->keyBits > 64) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "too many frames x accumulator cells for a 64-bit line key");
+	p->keyBits = frameBits + p->strengthBits;
+	if (R * T >= (static_cast<size_t>(1) << 32)) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "theta step too small: the accumulator has 2^32 cells or more"); // 32-bit cell values
+	if (p->keyBits > 32) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "too many frames for a 32-bit line key");
+	dfree(ctx, p->nmsFlags); dfree(ctx, p->rowBase);
+	{
+		const size_t rows = sht_nms_rows(static_cast<int>(R)), groups = static_cast<size_t>(sht_nms_groups(static_cast<int>(T)));
+		HIPCHK(ctx, dmalloc(ctx, &p->nmsFlags, rows * groups * p->frames));
+		HIPCHK(ctx, dmalloc(ctx, &p->rowBase, rows * p->frames));
+	}
 	p->shtReady = true;
 	return COMPVHIP_OK;
 }
@@ -400,12 +405,14 @@ int ensureLineCap(compvhip_plan* p, size_t cap)
 	compvhip_ctx* ctx = p->ctx;
 	cap = std::min(cap, p->R * p->T);
 	if (cap <= p->lineCap) return COMPVHIP_OK;
-	dfree(ctx, p->keysA); dfree(ctx, p->keysB); dfree(ctx, p->sortTemp);
+	dfree(ctx, p->keysA); dfree(ctx, p->keysB); dfree(ctx, p->valsA); dfree(ctx, p->valsB); dfree(ctx, p->sortTemp);
 	p->lineCap = 0;
 	HIPCHK(ctx, dmalloc(ctx, &p->keysA, cap * p->frames));
 	HIPCHK(ctx, dmalloc(ctx, &p->keysB, cap * p->frames));
+	HIPCHK(ctx, dmalloc(ctx, &p->valsA, cap * p->frames));
+	HIPCHK(ctx, dmalloc(ctx, &p->valsB, cap * p->frames));
 	size_t tb = 0;
-	hipError_t e = sht_sort_keys(nullptr, tb, p->keysA, p->keysB, cap, static_cast<int>(p->frames), p->keyBits, nullptr);
+	hipError_t e = sht_sort_pairs(nullptr, tb, p->keysA, p->keysB, p->valsA, p->valsB, cap, static_cast<int>(p->frames), p->keyBits, nullptr);
 	if (e != hipSuccess) return fail(ctx, COMPVHIP_E_HIP, "radix sort size query", e);
 	p->sortTempBytes = tb;
 	uint8_t* tmp = nullptr;
@@ -419,14 +426,15 @@ ShtArgs shtArgs(compvhip_plan* p, int threshold)
 {
 	ShtArgs a;
 	a.ebits = p->ebits; a.edges = p->edges; a.edgeCounts = p->edgeCounts; a.acc = p->acc;
-	a.sinQ = p->sinQ; a.cosQ = p->cosQ; a.lineKeys = p->keysA; a.lineCounts = p->lineCounts;
+	a.sinQ = p->sinQ; a.cosQ = p->cosQ; a.lineKeys = p->keysA; a.lineVals = p->valsA; a.lineCounts = p->lineCounts;
+	a.nmsFlags = p->nmsFlags; a.rowBase = p->rowBase; a.nmsGroups = sht_nms_groups(static_cast<int>(p->T)); a.nmsRows = static_cast<int>(sht_nms_rows(static_cast<int>(p->R)));
 	a.bitsFrameStride = p->bitsFrameStride; a.edgeCap = p->edgeCap; a.accFrameStride = p->accFrameStride; a.lineCap = p->lineCap;
 	a.W = static_cast<int>(p->W); a.H = static_cast<int>(p->H); a.wb = p->wb;
 	a.R = static_cast<int>(p->R); a.T = static_cast<int>(p->T); a.accPitch = p->accPitch; a.barrier = static_cast<int>(p->W + p->H);
 	a.threshold = threshold;
 	a.nmsLastCol = static_cast<int>((p->T - 1) & ~static_cast<size_t>(3)); // quirk Q2: NMS covers theta columns [1, (T-1)&~3]
 	a.frames = static_cast<int>(p->frames);
-	a.cellBits = p->cellBits; a.strengthBits = p->strengthBits;
+	a.strengthBits = p->strengthBits;
 	return a;
 }
 
@@ -675,7 +683,7 @@ void compvhip_plan_destroy(compvhip_plan* p)
 	dfree(ctx, p->cosT); dfree(ctx, p->invSinT);
 	dfree(ctx, p->dKt); dfree(ctx, p->dRowBase); dfree(ctx, p->partial);
 	dfree(ctx, p->sinQ); dfree(ctx, p->cosQ); dfree(ctx, p->edges); dfree(ctx, p->acc);
-	dfree(ctx, p->keysA); dfree(ctx, p->keysB);
+	dfree(ctx, p->keysA); dfree(ctx, p->keysB); dfree(ctx, p->valsA); dfree(ctx, p->valsB); dfree(ctx, p->nmsFlags); dfree(ctx, p->rowBase);
 	dfree(ctx, p->sortTemp);
 	delete p;
 }
@@ -866,13 +874,13 @@ static int planShtImpl(compvhip_plan* p, const uint8_t* d_edges, int threshold, 
 	{
 		Stamp s(p, st, "sht_sort_lines");
 		size_t tb = p->sortTempBytes;
-		hipError_t e = sht_sort_keys(p->sortTemp, tb, p->keysA, p->keysB, p->lineCap, frames, p->keyBits, st);
+		hipError_t e = sht_sort_pairs(p->sortTemp, tb, p->keysA, p->keysB, p->valsA, p->valsB, p->lineCap, frames, p->keyBits, st);
 		if (e != hipSuccess) return fail(ctx, COMPVHIP_E_HIP, "radix sort", e);
 	}
 	if (d_lines && lineCap) {
 		Stamp s(p, st, "sht_decode_kernel");
-		HIPCHK(ctx, launch_sht_decode(p->keysB, p->lineCounts, p->lineCap, frames, static_cast<int>(p->T), static_cast<int>(p->W + p->H), p->thetaStep, maxLines,
-		                              p->cellBits, p->strengthBits, d_lines, lineCap, st));
+		HIPCHK(ctx, launch_sht_decode(p->keysB, p->valsB, p->lineCounts, p->lineCap, frames, static_cast<int>(p->T), static_cast<int>(p->W + p->H), p->thetaStep, maxLines,
+		                              p->strengthBits, d_lines, lineCap, st));
 	}
 	if (d_counts) HIPCHK(ctx, hipMemcpyAsync(d_counts, p->lineCounts, sizeof(int32_t) * frames, hipMemcpyDeviceToDevice, st));
 	return COMPVHIP_OK;

@@ -103,14 +103,17 @@ struct ShtArgs {
 	uint16_t* acc;            // [frames][T][accPitch], u16: a cell never exceeds 65535
 	const int32_t* sinQ;      // [T]
 	const int32_t* cosQ;      // [T]
-	uint64_t* lineKeys;       // [frames][lineCap] sort keys: strength<<32 | ~(row*T+col)
+	uint32_t* lineKeys;       // [frames][lineCap] sort keys: frameTag << strengthBits | strength
+	uint32_t* lineVals;       // [frames][lineCap] their accumulator cells: row * T + col
+	uint8_t* nmsFlags;        // [frames][nmsGroups][nmsRows] NMS survivors: bit j of byte (group, row) = column 8 group + j
+	uint32_t* rowBase;        // [frames][nmsRows] survivors in the rows above
+	int nmsGroups, nmsRows;
 	int* lineCounts;          // per frame
 	size_t bitsFrameStride, edgeCap, accFrameStride, lineCap;
 	int W, H, wb;
 	int R, T, accPitch, barrier;
 	int threshold, nmsLastCol;
 	int frames;
-	int cellBits;             // bits of the accumulator cell index in a line key (2^cellBits > R*T)
 	int strengthBits;         // bits of the strength field of a line key (2^strengthBits > 2*max(W,H) >= any cell count)
 };
 // voting (sht_tiles_kernels.hip): image tiles, lane = theta
@@ -131,14 +134,16 @@ hipError_t launch_sht_reduce_tiles(const ShtArgs& a, const ShtTileArgs& v, int f
 hipError_t launch_bytes_to_bits(const uint8_t* edges, int W, int H, int S, size_t frameStride, uint32_t* ebits, int wb, size_t bitsFrameStride,
                                 int frames, hipStream_t stream);
 hipError_t launch_sht_nms(const ShtArgs& a, int frames, hipStream_t stream);
-hipError_t launch_sht_decode(const uint64_t* keys, const int* counts, size_t lineCap, int frames, int T, int barrier, float thetaStep,
-                             int maxLines, int cellBits, int strengthBits, void* lines /*compvhip_line*/, size_t outCap, hipStream_t stream);
+hipError_t launch_sht_decode(const uint32_t* keys, const uint32_t* vals, const int* counts, size_t lineCap, int frames, int T, int barrier, float thetaStep,
+                             int maxLines, int strengthBits, void* lines /*compvhip_line*/, size_t outCap, hipStream_t stream);
+size_t sht_nms_rows(int R);
+int sht_nms_groups(int T);
 // acc [T][pitch] -> reference layout [R][stride]
 hipError_t launch_sht_cartesian(const void* lines /*compvhip_line*/, const int* counts, size_t lineCap, int frames, const float* cosT, const float* invSinT,
                                 float widthF, float r, float* out /*[frames][lineCap][4]*/, hipStream_t stream);
 hipError_t launch_sht_acc_transpose(const uint16_t* accT, int R, int T, int accPitch, int32_t* out, size_t outStride, hipStream_t stream);
-// one descending radix sort over the (unique) 64-bit line keys of all frames; temp == nullptr queries tempBytes
-hipError_t sht_sort_keys(void* temp, size_t& tempBytes, const uint64_t* keysIn, uint64_t* keysOut, size_t lineCap, int frames, int keyBits,
-                         hipStream_t stream);
+// one stable descending radix sort over the (key, value) slots of all frames; temp == nullptr queries tempBytes
+hipError_t sht_sort_pairs(void* temp, size_t& tempBytes, const uint32_t* keysIn, uint32_t* keysOut, const uint32_t* valsIn, uint32_t* valsOut, size_t lineCap,
+                          int frames, int keyBits, hipStream_t stream);
 
 } // namespace compvhip

@@ -57,9 +57,17 @@ __global__ __launch_bounds__(256) void bytes_to_bits_kernel(const uint8_t* __res
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// NMS + threshold -> line keys (sht_nms_kernel below: LDS-tiled 3x3 test, one global atomic per workgroup for the key slots).
-// key = frameTag << (strengthBits+cellBits) | strength << cellBits | (cellMask - cell), cell = row*T + col: unique, and a single
-// descending radix sort over all frames yields frame-major, strength-descending, (row,col)-ascending order.
+// NMS + threshold -> lines, in three small steps that make the emission order DETERMINISTIC (accumulator rows, then columns, ascending:
+// nms_apply's own order, houghsht.cxx:546-562), so that the sort only has to order by strength:
+//   sht_nms_kernel   LDS-tiled 3x3 test; the survivors of 8 theta columns x 8 rho rows per thread leave as one flag byte per (row, column
+//                    group): flag planes [frame][column group][row], 8-byte coalesced stores, no atomics;
+//   sht_rank_kernel  one workgroup per frame: survivors per row (popcounts of the row's flag bytes), exclusive scan over the rows ->
+//                    rowBase[frame][row] and the frame's line count;
+//   sht_emit_kernel  one thread per row: the row's survivors in column order -> key = frameTag | strength, value = cell (row * T + col) at
+//                    slot rowBase + i of the frame's key / value arrays.
+// A stable descending radix sort of the (key, value) pairs then gives frame-major, strength-descending, (row, col)-ascending order with
+// frameBits + strengthBits key bits (18 at 4K x 32 frames: two 10-bit onesweep passes; the unique 40-bit keys of rounds 1-2, which carried
+// the cell because the slots were handed out by atomics in arrival order, took four).
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kNmsThreads = 128;
 constexpr int kNmsCols = 8;                  // theta columns per block
@@ -68,13 +76,10 @@ constexpr int kNmsTileRows = kNmsRows + 16;  // + 8 rows of halo either side (ke
 
 // One block owns kNmsCols theta columns x kNmsRows rho rows of the theta-major accumulator. The tile plus a one-cell halo is
 // staged in LDS with 16-byte coalesced loads (each accumulator cell is read (kNmsCols+2)/kNmsCols times), so the 3x3
-// neighbourhood test never issues a scattered global load. Survivors are flagged in a 64-bit mask per thread, slots are
-// reserved with ONE atomic per block, and the keys are rebuilt from the LDS tile.
+// neighbourhood test never issues a scattered global load. A thread's survivors are one byte per row (bit j = column c0 + j).
 __global__ __launch_bounds__(kNmsThreads) void sht_nms_kernel(ShtArgs a)
 {
 	__shared__ __attribute__((aligned(16))) uint16_t s_tile[kNmsCols + 2][kNmsTileRows];
-	__shared__ int s_wave[kNmsThreads / 64];
-	__shared__ int s_base;
 	const int frame = blockIdx.z;
 	const int c0 = blockIdx.y * kNmsCols;
 	const int base = blockIdx.x * kNmsRows;
@@ -119,7 +124,7 @@ __global__ __launch_bounds__(kNmsThreads) void sht_nms_kernel(ShtArgs a)
 #pragma unroll
 		for (int k = 0; k < 8; ++k) side[1][k] = max(max(mid[k], mid[k + 1]), mid[k + 2]);
 	}
-	uint32_t flags[2] = { 0u, 0u };
+	uint32_t flags[2] = { 0u, 0u };   // byte k & 3 of flags[k >> 2] = row k of this thread: bit j = column c0 + j survives
 #pragma unroll
 	for (int j = 0; j < kNmsCols; ++j) {
 		readCol(j + 2, nxt);
@@ -139,46 +144,79 @@ __global__ __launch_bounds__(kNmsThreads) void sht_nms_kernel(ShtArgs a)
 					const int nb = max(max(sl[k], sh[k]), max(mid[k], mid[k + 2]));
 					pass = pass && (nb <= val);
 				}
-				flags[j >> 2] |= (pass ? 1u : 0u) << ((j & 3) * 8 + k);
+				flags[k >> 2] |= (pass ? 1u : 0u) << ((k & 3) * 8 + j);
 			}
 		}
 #pragma unroll
 		for (int k = 0; k < 10; ++k) mid[k] = nxt[k];
 	}
-	const int cnt = __popc(flags[0]) + __popc(flags[1]);
-	int incl = cnt;
-	const int lane = t & 63, wave = t >> 6;
-#pragma unroll
-	for (int o = 1; o < 64; o <<= 1) {
-		const int n = __shfl_up(incl, o);
-		if (lane >= o) incl += n;
-	}
-	if (lane == 63) s_wave[wave] = incl;
+	// flag plane of this column group: rows base + 8 t .. + 7, one 8-byte store per thread (a wave writes 512 consecutive bytes)
+	uint8_t* __restrict__ plane = a.nmsFlags + ((size_t)frame * a.nmsGroups + blockIdx.y) * a.nmsRows;
+	*reinterpret_cast<uint2*>(plane + base + t * 8) = make_uint2(flags[0], flags[1]);
+}
+
+// rowBase[frame][row] = survivors in the rows above; lineCounts[frame] = survivors of the frame.  One workgroup per frame.
+constexpr int kRankThreads = 1024;
+__global__ __launch_bounds__(kRankThreads) void sht_rank_kernel(ShtArgs a)
+{
+	__shared__ int s_wave[kRankThreads / 64];
+	__shared__ int s_carry;
+	const int frame = blockIdx.x;
+	const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+	const uint8_t* __restrict__ planes = a.nmsFlags + (size_t)frame * a.nmsGroups * a.nmsRows;
+	uint32_t* __restrict__ rowBase = a.rowBase + (size_t)frame * a.nmsRows;
+	if (t == 0) s_carry = 0;
 	__syncthreads();
-	int wbase = 0, total = 0;
+	for (int r0 = 0; r0 < a.R; r0 += kRankThreads) {
+		const int r = r0 + t;
+		int cnt = 0;
+		if (r < a.R) for (int g = 0; g < a.nmsGroups; ++g) cnt += __popc((uint32_t)planes[(size_t)g * a.nmsRows + r]);
+		int incl = cnt;
 #pragma unroll
-	for (int k = 0; k < kNmsThreads / 64; ++k) {
-		const int n = s_wave[k];
-		if (k < wave) wbase += n;
-		total += n;
+		for (int o = 1; o < 64; o <<= 1) {
+			const int n = __shfl_up(incl, o);
+			if (lane >= o) incl += n;
+		}
+		if (lane == 63) s_wave[wave] = incl;
+		__syncthreads();
+		int wbase = s_carry, total = 0;
+#pragma unroll
+		for (int k = 0; k < kRankThreads / 64; ++k) {
+			const int n = s_wave[k];
+			if (k < wave) wbase += n;
+			total += n;
+		}
+		if (r < a.R) rowBase[r] = (uint32_t)(wbase + incl - cnt);
+		__syncthreads();
+		if (t == 0) s_carry += total;
+		__syncthreads();
 	}
-	if (total == 0) return; // uniform
-	if (t == 0) s_base = atomicAdd(&a.lineCounts[frame], total);
-	__syncthreads();
-	size_t pos = (size_t)s_base + wbase + (incl - cnt);
-	uint64_t* __restrict__ dst = a.lineKeys + (size_t)frame * a.lineCap;
-	const uint64_t frameTag = (uint64_t)(a.frames - 1 - frame) << (a.strengthBits + a.cellBits);
-	const uint32_t cellMask = (1u << a.cellBits) - 1u;
-#pragma unroll
-	for (int h = 0; h < 2; ++h) {
-		uint32_t f = flags[h];
+	if (t == 0) a.lineCounts[frame] = s_carry;
+}
+
+// one thread per accumulator row: its survivors, columns ascending, into slots rowBase .. of the frame's key / value arrays
+constexpr int kEmitThreads = 256;
+__global__ __launch_bounds__(kEmitThreads) void sht_emit_kernel(ShtArgs a)
+{
+	const int frame = blockIdx.y;
+	const int r = blockIdx.x * kEmitThreads + threadIdx.x;
+	if (r >= a.R) return;
+	const uint8_t* __restrict__ planes = a.nmsFlags + (size_t)frame * a.nmsGroups * a.nmsRows;
+	const uint16_t* __restrict__ acc = a.acc + (size_t)frame * a.accFrameStride;
+	size_t pos = a.rowBase[(size_t)frame * a.nmsRows + r];
+	uint32_t* __restrict__ keys = a.lineKeys + (size_t)frame * a.lineCap;
+	uint32_t* __restrict__ vals = a.lineVals + (size_t)frame * a.lineCap;
+	const uint32_t frameTag = (uint32_t)(a.frames - 1 - frame) << a.strengthBits;
+	for (int g = 0; g < a.nmsGroups; ++g) {
+		uint32_t f = planes[(size_t)g * a.nmsRows + r];
 		while (f) {
-			const int b = __ffs(f) - 1;
+			const int j = __ffs(f) - 1;
 			f &= f - 1;
-			const int j = h * 4 + (b >> 3), k = b & 7;
-			const uint32_t val = s_tile[j + 1][8 + t * 8 + k];
-			const uint32_t cell = (uint32_t)(base + t * 8 + k) * (uint32_t)a.T + (uint32_t)(c0 + j);
-			if (pos < a.lineCap) dst[pos] = frameTag | ((uint64_t)val << a.cellBits) | (uint64_t)(cellMask - cell);
+			const int c = g * kNmsCols + j;
+			if (pos < a.lineCap) {
+				keys[pos] = frameTag | (uint32_t)acc[(size_t)c * a.accPitch + r];
+				vals[pos] = (uint32_t)r * (uint32_t)a.T + (uint32_t)c;
+			}
 			++pos;
 		}
 	}
@@ -187,25 +225,25 @@ __global__ __launch_bounds__(kNmsThreads) void sht_nms_kernel(ShtArgs a)
 // Key slots [min(count, lineCap), lineCap) of every frame are zeroed (a zero key sorts last: every real key carries a strength > 0).
 constexpr int kPadThreads = 256;
 constexpr int kPadSlots = 8;
-__global__ __launch_bounds__(kPadThreads) void sht_pad_keys_kernel(uint64_t* __restrict__ keys, const int* __restrict__ counts, size_t lineCap)
+__global__ __launch_bounds__(kPadThreads) void sht_pad_keys_kernel(uint32_t* __restrict__ keys, const int* __restrict__ counts, size_t lineCap)
 {
 	const int frame = blockIdx.y;
 	const size_t used = (size_t)max(counts[frame], 0);
 	const size_t i0 = ((size_t)blockIdx.x * kPadThreads + threadIdx.x) * kPadSlots;
 	if (i0 + kPadSlots <= used) return;
-	uint64_t* __restrict__ k = keys + (size_t)frame * lineCap;
+	uint32_t* __restrict__ k = keys + (size_t)frame * lineCap;
 #pragma unroll
 	for (int j = 0; j < kPadSlots; ++j) {
 		const size_t i = i0 + j;
-		if (i >= used && i < lineCap) k[i] = 0ull;
+		if (i >= used && i < lineCap) k[i] = 0u;
 	}
 }
 
 struct LineOut { float rho; float theta; int32_t strength; int32_t row; int32_t col; };
 
 // After the global descending sort the lines of frame f start at sum_{g<f} min(count_g, lineCap).
-__global__ __launch_bounds__(256) void sht_decode_kernel(const uint64_t* __restrict__ keys, const int* __restrict__ counts, size_t lineCap, int T, int barrier,
-                                                         float thetaStep, int maxLines, int cellBits, int strengthBits, LineOut* __restrict__ lines, size_t outCap)
+__global__ __launch_bounds__(256) void sht_decode_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ vals, const int* __restrict__ counts, size_t lineCap,
+                                                         int T, int barrier, float thetaStep, int maxLines, int strengthBits, LineOut* __restrict__ lines, size_t outCap)
 {
 	const int frame = blockIdx.y;
 	size_t off = 0;
@@ -219,14 +257,13 @@ __global__ __launch_bounds__(256) void sht_decode_kernel(const uint64_t* __restr
 	if (n > outCap) n = outCap;
 	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
 	if (i >= n) return;
-	const uint64_t k = keys[off + i];
-	const uint32_t cellMask = (1u << cellBits) - 1u;
-	const uint32_t cell = cellMask - (uint32_t)(k & cellMask);
+	const uint32_t k = keys[off + i];
+	const uint32_t cell = vals[off + i];
 	const int row = (int)(cell / (uint32_t)T), col = (int)(cell - (uint32_t)row * (uint32_t)T);
 	LineOut o;
 	o.rho = (float)(barrier - row);              // static_cast<float>(barrier - row), houghsht.cxx:661
 	o.theta = __fmul_rn((float)col, thetaStep);  // col * theta (f32), houghsht.cxx:662
-	o.strength = (int32_t)((k >> cellBits) & ((1u << strengthBits) - 1u));
+	o.strength = (int32_t)(k & ((1u << strengthBits) - 1u));
 	o.row = row; o.col = col;
 	lines[(size_t)frame * outCap + i] = o;
 }
@@ -281,35 +318,39 @@ hipError_t launch_bytes_to_bits(const uint8_t* edges, int W, int H, int S, size_
 	return hipGetLastError();
 }
 
+size_t sht_nms_rows(int R) { return (size_t)((R + kNmsRows - 1) / kNmsRows) * kNmsRows; }   // rows of a flag plane (whole NMS blocks)
+int sht_nms_groups(int T) { return (T + kNmsCols - 1) / kNmsCols; }
+
 hipError_t launch_sht_nms(const ShtArgs& a, int frames, hipStream_t stream)
 {
 	dim3 grid((a.R + kNmsRows - 1) / kNmsRows, (a.T + kNmsCols - 1) / kNmsCols, frames);
 	hipLaunchKernelGGL(sht_nms_kernel, grid, dim3(kNmsThreads), 0, stream, a);
-	// unused key slots must sort last: zero only the slots past each frame's count (the whole array used to be zero-filled before the
-	// NMS -- 16.8 MB per 32-frame step at 4K for 12 % unused slots)
+	hipLaunchKernelGGL(sht_rank_kernel, dim3(frames), dim3(kRankThreads), 0, stream, a);
+	hipLaunchKernelGGL(sht_emit_kernel, dim3((a.R + kEmitThreads - 1) / kEmitThreads, frames), dim3(kEmitThreads), 0, stream, a);
+	// unused key slots must sort last: zero the slots past each frame's count (a zero key sorts last: every real key carries a strength > 0)
 	dim3 pgrid((unsigned)((a.lineCap + kPadThreads * kPadSlots - 1) / (kPadThreads * kPadSlots)), frames);
 	hipLaunchKernelGGL(sht_pad_keys_kernel, pgrid, dim3(kPadThreads), 0, stream, a.lineKeys, a.lineCounts, a.lineCap);
 	return hipGetLastError();
 }
 
-// one descending radix sort over the key slots of all frames (rocPRIM device primitive)
-hipError_t sht_sort_keys(void* temp, size_t& tempBytes, const uint64_t* keysIn, uint64_t* keysOut, size_t lineCap, int frames, int keyBits,
-                         hipStream_t stream)
+// one stable descending radix sort over the (key, value) slots of all frames (rocPRIM device primitive)
+hipError_t sht_sort_pairs(void* temp, size_t& tempBytes, const uint32_t* keysIn, uint32_t* keysOut, const uint32_t* valsIn, uint32_t* valsOut, size_t lineCap,
+                          int frames, int keyBits, hipStream_t stream)
 {
-	// 10-bit digits: the 40-bit key of the 4K benchmark takes 4 onesweep passes instead of the 5 of the library's 8-bit default
+	// 10-bit digits: the 18-bit key of the 4K benchmark (5 frame bits + 13 strength bits) takes two onesweep passes
 	using Onesweep = rocprim::radix_sort_onesweep_config<rocprim::kernel_config<1024, 8>, rocprim::kernel_config<1024, 10>, 10, rocprim::block_radix_rank_algorithm::match>;
 	using Config = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, Onesweep>;
-	return rocprim::radix_sort_keys_desc<Config>(temp, tempBytes, keysIn, keysOut, lineCap * (size_t)frames, 0u, (unsigned int)keyBits, stream);
+	return rocprim::radix_sort_pairs_desc<Config>(temp, tempBytes, keysIn, keysOut, valsIn, valsOut, lineCap * (size_t)frames, 0u, (unsigned int)keyBits, stream);
 }
 
-hipError_t launch_sht_decode(const uint64_t* keys, const int* counts, size_t lineCap, int frames, int T, int barrier, float thetaStep,
-                             int maxLines, int cellBits, int strengthBits, void* lines, size_t outCap, hipStream_t stream)
+hipError_t launch_sht_decode(const uint32_t* keys, const uint32_t* vals, const int* counts, size_t lineCap, int frames, int T, int barrier, float thetaStep,
+                             int maxLines, int strengthBits, void* lines, size_t outCap, hipStream_t stream)
 {
 	size_t n = lineCap < outCap ? lineCap : outCap;
 	if (maxLines > 0 && (size_t)maxLines < n) n = (size_t)maxLines;
 	if (n == 0) return hipSuccess;
 	dim3 grid((unsigned)((n + 255) / 256), frames);
-	hipLaunchKernelGGL(sht_decode_kernel, grid, dim3(256), 0, stream, keys, counts, lineCap, T, barrier, thetaStep, maxLines, cellBits, strengthBits,
+	hipLaunchKernelGGL(sht_decode_kernel, grid, dim3(256), 0, stream, keys, vals, counts, lineCap, T, barrier, thetaStep, maxLines, strengthBits,
 	                   reinterpret_cast<LineOut*>(lines), outCap);
 	return hipGetLastError();
 }
