@@ -106,7 +106,8 @@ struct ShtArgs {
 	uint32_t* lineKeys;       // [frames][lineCap] sort keys: frameTag << strengthBits | strength
 	uint32_t* lineVals;       // [frames][lineCap] their accumulator cells: row * T + col
 	uint8_t* nmsFlags;        // [frames][nmsGroups][nmsRows] NMS survivors: bit j of byte (group, row) = column 8 group + j
-	uint32_t* rowBase;        // [frames][nmsRows] survivors in the rows above
+	uint32_t* rowBase;        // [frames][nmsRows] survivors in the rows above, inside the row's chunk of 1024 rows
+	int* chunkTotals;         // [frames][chunks] survivors per chunk
 	int nmsGroups, nmsRows;
 	int* lineCounts;          // per frame
 	size_t bitsFrameStride, edgeCap, accFrameStride, lineCap;
@@ -137,6 +138,7 @@ hipError_t launch_sht_nms(const ShtArgs& a, int frames, hipStream_t stream);
 hipError_t launch_sht_decode(const uint32_t* keys, const uint32_t* vals, const int* counts, size_t lineCap, int frames, int T, int barrier, float thetaStep,
                              int maxLines, int strengthBits, void* lines /*compvhip_line*/, size_t outCap, hipStream_t stream);
 size_t sht_nms_rows(int R);
+int sht_rank_chunks(int R);
 int sht_nms_groups(int T);
 // acc [T][pitch] -> reference layout [R][stride]
 hipError_t launch_sht_cartesian(const void* lines /*compvhip_line*/, const int* counts, size_t lineCap, int frames, const float* cosT, const float* invSinT,

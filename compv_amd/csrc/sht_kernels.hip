@@ -61,8 +61,8 @@ __global__ __launch_bounds__(256) void bytes_to_bits_kernel(const uint8_t* __res
 // nms_apply's own order, houghsht.cxx:546-562), so that the sort only has to order by strength:
 //   sht_nms_kernel   LDS-tiled 3x3 test; the survivors of 8 theta columns x 8 rho rows per thread leave as one flag byte per (row, column
 //                    group): flag planes [frame][column group][row], 8-byte coalesced stores, no atomics;
-//   sht_rank_kernel  one workgroup per frame: survivors per row (popcounts of the row's flag bytes), exclusive scan over the rows ->
-//                    rowBase[frame][row] and the frame's line count;
+//   sht_rank_kernel  survivors per row (popcounts of the row's flag bytes), exclusive scan inside chunks of 1024 rows -> rowBase[frame][row]
+//                    and the chunk totals (the emit kernel adds the few totals in front of a row's chunk);
 //   sht_emit_kernel  one thread per row: the row's survivors in column order -> key = frameTag | strength, value = cell (row * T + col) at
 //                    slot rowBase + i of the frame's key / value arrays.
 // A stable descending radix sort of the (key, value) pairs then gives frame-major, strength-descending, (row, col)-ascending order with
@@ -155,69 +155,72 @@ __global__ __launch_bounds__(kNmsThreads) void sht_nms_kernel(ShtArgs a)
 	*reinterpret_cast<uint2*>(plane + base + t * 8) = make_uint2(flags[0], flags[1]);
 }
 
-// rowBase[frame][row] = survivors in the rows above; lineCounts[frame] = survivors of the frame.  One workgroup per frame.
+// rowBase[frame][row] = survivors in the rows above INSIDE the row's chunk of kRankThreads rows; chunkTotals[frame][chunk] = survivors of
+// the chunk.  One workgroup per (chunk, frame): a single coalesced pass, one block scan.
 constexpr int kRankThreads = 1024;
 __global__ __launch_bounds__(kRankThreads) void sht_rank_kernel(ShtArgs a)
 {
 	__shared__ int s_wave[kRankThreads / 64];
-	__shared__ int s_carry;
-	const int frame = blockIdx.x;
+	const int frame = blockIdx.y;
 	const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+	const int r = blockIdx.x * kRankThreads + t;
 	const uint8_t* __restrict__ planes = a.nmsFlags + (size_t)frame * a.nmsGroups * a.nmsRows;
-	uint32_t* __restrict__ rowBase = a.rowBase + (size_t)frame * a.nmsRows;
-	if (t == 0) s_carry = 0;
-	__syncthreads();
-	for (int r0 = 0; r0 < a.R; r0 += kRankThreads) {
-		const int r = r0 + t;
-		int cnt = 0;
-		if (r < a.R) for (int g = 0; g < a.nmsGroups; ++g) cnt += __popc((uint32_t)planes[(size_t)g * a.nmsRows + r]);
-		int incl = cnt;
+	int cnt = 0;
+	if (r < a.R) for (int g = 0; g < a.nmsGroups; ++g) cnt += __popc((uint32_t)planes[(size_t)g * a.nmsRows + r]);
+	int incl = cnt;
 #pragma unroll
-		for (int o = 1; o < 64; o <<= 1) {
-			const int n = __shfl_up(incl, o);
-			if (lane >= o) incl += n;
-		}
-		if (lane == 63) s_wave[wave] = incl;
-		__syncthreads();
-		int wbase = s_carry, total = 0;
-#pragma unroll
-		for (int k = 0; k < kRankThreads / 64; ++k) {
-			const int n = s_wave[k];
-			if (k < wave) wbase += n;
-			total += n;
-		}
-		if (r < a.R) rowBase[r] = (uint32_t)(wbase + incl - cnt);
-		__syncthreads();
-		if (t == 0) s_carry += total;
-		__syncthreads();
+	for (int o = 1; o < 64; o <<= 1) {
+		const int n = __shfl_up(incl, o);
+		if (lane >= o) incl += n;
 	}
-	if (t == 0) a.lineCounts[frame] = s_carry;
+	if (lane == 63) s_wave[wave] = incl;
+	__syncthreads();
+	int wbase = 0, total = 0;
+#pragma unroll
+	for (int k = 0; k < kRankThreads / 64; ++k) {
+		const int n = s_wave[k];
+		if (k < wave) wbase += n;
+		total += n;
+	}
+	if (r < a.R) a.rowBase[(size_t)frame * a.nmsRows + r] = (uint32_t)(wbase + incl - cnt);
+	if (t == 0) a.chunkTotals[frame * gridDim.x + blockIdx.x] = total;
 }
 
-// one thread per accumulator row: its survivors, columns ascending, into slots rowBase .. of the frame's key / value arrays
+// one thread per accumulator row: its survivors, columns ascending, into slots base .. of the frame's key / value arrays.  The eight
+// columns of a flag byte are visited with predicated, independent load / store pairs (a loop over the set bits would wait for every
+// accumulator read before it issued the next).  Block x = 0 of every frame also publishes the frame's line count.
 constexpr int kEmitThreads = 256;
-__global__ __launch_bounds__(kEmitThreads) void sht_emit_kernel(ShtArgs a)
+__global__ __launch_bounds__(kEmitThreads) void sht_emit_kernel(ShtArgs a, int chunks)
 {
 	const int frame = blockIdx.y;
 	const int r = blockIdx.x * kEmitThreads + threadIdx.x;
+	const int* __restrict__ ct = a.chunkTotals + frame * chunks;
+	if (blockIdx.x == 0 && threadIdx.x == 0) {
+		int n = 0;
+		for (int k = 0; k < chunks; ++k) n += ct[k];
+		a.lineCounts[frame] = n;
+	}
 	if (r >= a.R) return;
 	const uint8_t* __restrict__ planes = a.nmsFlags + (size_t)frame * a.nmsGroups * a.nmsRows;
-	const uint16_t* __restrict__ acc = a.acc + (size_t)frame * a.accFrameStride;
+	const uint16_t* __restrict__ acc = a.acc + (size_t)frame * a.accFrameStride + r;
 	size_t pos = a.rowBase[(size_t)frame * a.nmsRows + r];
+	for (int k = 0; k < r / kRankThreads; ++k) pos += (size_t)ct[k];
 	uint32_t* __restrict__ keys = a.lineKeys + (size_t)frame * a.lineCap;
 	uint32_t* __restrict__ vals = a.lineVals + (size_t)frame * a.lineCap;
 	const uint32_t frameTag = (uint32_t)(a.frames - 1 - frame) << a.strengthBits;
+	const uint32_t cell0 = (uint32_t)r * (uint32_t)a.T;
 	for (int g = 0; g < a.nmsGroups; ++g) {
-		uint32_t f = planes[(size_t)g * a.nmsRows + r];
-		while (f) {
-			const int j = __ffs(f) - 1;
-			f &= f - 1;
-			const int c = g * kNmsCols + j;
-			if (pos < a.lineCap) {
-				keys[pos] = frameTag | (uint32_t)acc[(size_t)c * a.accPitch + r];
-				vals[pos] = (uint32_t)r * (uint32_t)a.T + (uint32_t)c;
+		const uint32_t f = planes[(size_t)g * a.nmsRows + r];
+		if (!f) continue;
+		uint32_t v[kNmsCols];
+#pragma unroll
+		for (int j = 0; j < kNmsCols; ++j) v[j] = ((f >> j) & 1u) ? (uint32_t)acc[(size_t)(g * kNmsCols + j) * a.accPitch] : 0u;
+#pragma unroll
+		for (int j = 0; j < kNmsCols; ++j) {
+			if ((f >> j) & 1u) {
+				if (pos < a.lineCap) { keys[pos] = frameTag | v[j]; vals[pos] = cell0 + (uint32_t)(g * kNmsCols + j); }
+				++pos;
 			}
-			++pos;
 		}
 	}
 }
@@ -318,6 +321,7 @@ hipError_t launch_bytes_to_bits(const uint8_t* edges, int W, int H, int S, size_
 	return hipGetLastError();
 }
 
+int sht_rank_chunks(int R) { return (R + kRankThreads - 1) / kRankThreads; }
 size_t sht_nms_rows(int R) { return (size_t)((R + kNmsRows - 1) / kNmsRows) * kNmsRows; }   // rows of a flag plane (whole NMS blocks)
 int sht_nms_groups(int T) { return (T + kNmsCols - 1) / kNmsCols; }
 
@@ -325,8 +329,9 @@ hipError_t launch_sht_nms(const ShtArgs& a, int frames, hipStream_t stream)
 {
 	dim3 grid((a.R + kNmsRows - 1) / kNmsRows, (a.T + kNmsCols - 1) / kNmsCols, frames);
 	hipLaunchKernelGGL(sht_nms_kernel, grid, dim3(kNmsThreads), 0, stream, a);
-	hipLaunchKernelGGL(sht_rank_kernel, dim3(frames), dim3(kRankThreads), 0, stream, a);
-	hipLaunchKernelGGL(sht_emit_kernel, dim3((a.R + kEmitThreads - 1) / kEmitThreads, frames), dim3(kEmitThreads), 0, stream, a);
+	const int chunks = (a.R + kRankThreads - 1) / kRankThreads;
+	hipLaunchKernelGGL(sht_rank_kernel, dim3(chunks, frames), dim3(kRankThreads), 0, stream, a);
+	hipLaunchKernelGGL(sht_emit_kernel, dim3((a.R + kEmitThreads - 1) / kEmitThreads, frames), dim3(kEmitThreads), 0, stream, a, chunks);
 	// unused key slots must sort last: zero the slots past each frame's count (a zero key sorts last: every real key carries a strength > 0)
 	dim3 pgrid((unsigned)((a.lineCap + kPadThreads * kPadSlots - 1) / (kPadThreads * kPadSlots)), frames);
 	hipLaunchKernelGGL(sht_pad_keys_kernel, pgrid, dim3(kPadThreads), 0, stream, a.lineKeys, a.lineCounts, a.lineCap);

@@ -19,3 +19,13 @@ except Exception as e:
 PY
 done
 tail -3 $O/bench_default.err
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 --kernel-trace --stats --output-format csv -d $GRAFT_REPO_ROOT/$O/prof -- python $GRAFT_REPO_ROOT/bench.py --no-cpu-baseline --no-extras --inflight 1 --steps 4 --warmup 1 --reps 1 --no-verify > $GRAFT_REPO_ROOT/$O/prof.log 2>&1
+cd $GRAFT_REPO_ROOT
+python - $O/prof <<'PY'
+import csv, glob, sys
+d = sys.argv[1]
+for f in glob.glob(d + "/**/*kernel_stats.csv", recursive=True):
+    for i, row in enumerate(csv.reader(open(f))):
+        if "compvhip" in row[0] or "rocprim" in row[0] or i == 0: print(",".join(x[:60] for x in row[:5]))
+PY
