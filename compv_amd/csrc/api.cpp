@@ -110,7 +110,7 @@ struct compvhip_plan {
 	uint32_t* edges = nullptr; size_t edgeCap = 0; int* edgeCounts = nullptr;
 	uint16_t* acc = nullptr; size_t accFrameStride = 0;
 	uint32_t* keysA = nullptr; uint32_t* keysB = nullptr; uint32_t* valsA = nullptr; uint32_t* valsB = nullptr; size_t lineCap = 0; int* lineCounts = nullptr;
-	uint8_t* nmsFlags = nullptr; uint32_t* rowBase = nullptr; int* chunkTotals = nullptr; // NMS survivors (flag planes) and their ranks
+	uint8_t* nmsFlags = nullptr; uint16_t* nmsOffs = nullptr; uint32_t* rowBase = nullptr; int* chunkTotals = nullptr; // NMS survivors (flag planes) and their ranks
 	void* sortTemp = nullptr; size_t sortTempBytes = 0;
 	int strengthBits = 16, keyBits = 0;
 	// voting over image tiles (planned at plan creation: the per-tile edge counters live in `counters`)
@@ -390,10 +390,11 @@ int ensureSht(compvhip_plan* p)
 	p->keyBits = frameBits + p->strengthBits;
 	if (R * T >= (static_cast<size_t>(1) << 32)) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "theta step too small: the accumulator has 2^32 cells or more"); // 32-bit cell values
 	if (p->keyBits > 32) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "too many frames for a 32-bit line key");
-	dfree(ctx, p->nmsFlags); dfree(ctx, p->rowBase); dfree(ctx, p->chunkTotals);
+	dfree(ctx, p->nmsFlags); dfree(ctx, p->nmsOffs); dfree(ctx, p->rowBase); dfree(ctx, p->chunkTotals);
 	{
 		const size_t rows = sht_nms_rows(static_cast<int>(R)), groups = static_cast<size_t>(sht_nms_groups(static_cast<int>(T)));
 		HIPCHK(ctx, dmalloc(ctx, &p->nmsFlags, rows * groups * p->frames));
+		HIPCHK(ctx, dmalloc(ctx, &p->nmsOffs, rows * groups * p->frames));
 		HIPCHK(ctx, dmalloc(ctx, &p->rowBase, rows * p->frames));
 		HIPCHK(ctx, dmalloc(ctx, &p->chunkTotals, static_cast<size_t>(sht_rank_chunks(static_cast<int>(R))) * p->frames));
 	}
@@ -428,7 +429,7 @@ ShtArgs shtArgs(compvhip_plan* p, int threshold)
 	ShtArgs a;
 	a.ebits = p->ebits; a.edges = p->edges; a.edgeCounts = p->edgeCounts; a.acc = p->acc;
 	a.sinQ = p->sinQ; a.cosQ = p->cosQ; a.lineKeys = p->keysA; a.lineVals = p->valsA; a.lineCounts = p->lineCounts;
-	a.nmsFlags = p->nmsFlags; a.rowBase = p->rowBase; a.chunkTotals = p->chunkTotals; a.nmsGroups = sht_nms_groups(static_cast<int>(p->T)); a.nmsRows = static_cast<int>(sht_nms_rows(static_cast<int>(p->R)));
+	a.nmsFlags = p->nmsFlags; a.nmsOffs = p->nmsOffs; a.rowBase = p->rowBase; a.chunkTotals = p->chunkTotals; a.nmsGroups = sht_nms_groups(static_cast<int>(p->T)); a.nmsRows = static_cast<int>(sht_nms_rows(static_cast<int>(p->R)));
 	a.bitsFrameStride = p->bitsFrameStride; a.edgeCap = p->edgeCap; a.accFrameStride = p->accFrameStride; a.lineCap = p->lineCap;
 	a.W = static_cast<int>(p->W); a.H = static_cast<int>(p->H); a.wb = p->wb;
 	a.R = static_cast<int>(p->R); a.T = static_cast<int>(p->T); a.accPitch = p->accPitch; a.barrier = static_cast<int>(p->W + p->H);
@@ -684,7 +685,7 @@ void compvhip_plan_destroy(compvhip_plan* p)
 	dfree(ctx, p->cosT); dfree(ctx, p->invSinT);
 	dfree(ctx, p->dKt); dfree(ctx, p->dRowBase); dfree(ctx, p->partial);
 	dfree(ctx, p->sinQ); dfree(ctx, p->cosQ); dfree(ctx, p->edges); dfree(ctx, p->acc);
-	dfree(ctx, p->keysA); dfree(ctx, p->keysB); dfree(ctx, p->valsA); dfree(ctx, p->valsB); dfree(ctx, p->nmsFlags); dfree(ctx, p->rowBase); dfree(ctx, p->chunkTotals);
+	dfree(ctx, p->keysA); dfree(ctx, p->keysB); dfree(ctx, p->valsA); dfree(ctx, p->valsB); dfree(ctx, p->nmsFlags); dfree(ctx, p->nmsOffs); dfree(ctx, p->rowBase); dfree(ctx, p->chunkTotals);
 	dfree(ctx, p->sortTemp);
 	delete p;
 }

@@ -106,6 +106,7 @@ struct ShtArgs {
 	uint32_t* lineKeys;       // [frames][lineCap] sort keys: frameTag << strengthBits | strength
 	uint32_t* lineVals;       // [frames][lineCap] their accumulator cells: row * T + col
 	uint8_t* nmsFlags;        // [frames][nmsGroups][nmsRows] NMS survivors: bit j of byte (group, row) = column 8 group + j
+	uint16_t* nmsOffs;        // [frames][nmsGroups][nmsRows] survivors of the row in the column groups before this one
 	uint32_t* rowBase;        // [frames][nmsRows] survivors in the rows above, inside the row's chunk of 1024 rows
 	int* chunkTotals;         // [frames][chunks] survivors per chunk
 	int nmsGroups, nmsRows;

@@ -63,8 +63,8 @@ __global__ __launch_bounds__(256) void bytes_to_bits_kernel(const uint8_t* __res
 //                    group): flag planes [frame][column group][row], 8-byte coalesced stores, no atomics;
 //   sht_rank_kernel  survivors per row (popcounts of the row's flag bytes), exclusive scan inside chunks of 1024 rows -> rowBase[frame][row]
 //                    and the chunk totals (the emit kernel adds the few totals in front of a row's chunk);
-//   sht_emit_kernel  one thread per row: the row's survivors in column order -> key = frameTag | strength, value = cell (row * T + col) at
-//                    slot rowBase + i of the frame's key / value arrays.
+//   sht_emit_kernel  one thread per flag byte: its survivors in column order -> key = frameTag | strength, value = cell (row * T + col) at
+//                    slot chunk base + rowBase + in-row offset of the frame's key / value arrays.
 // A stable descending radix sort of the (key, value) pairs then gives frame-major, strength-descending, (row, col)-ascending order with
 // frameBits + strengthBits key bits (18 at 4K x 32 frames: two 10-bit onesweep passes; the unique 40-bit keys of rounds 1-2, which carried
 // the cell because the slots were handed out by atomics in arrival order, took four).
@@ -165,8 +165,13 @@ __global__ __launch_bounds__(kRankThreads) void sht_rank_kernel(ShtArgs a)
 	const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
 	const int r = blockIdx.x * kRankThreads + t;
 	const uint8_t* __restrict__ planes = a.nmsFlags + (size_t)frame * a.nmsGroups * a.nmsRows;
+	// survivors of the row's earlier column groups, one u16 per (group, row): the emit kernel starts every flag byte at rowBase + this offset
+	uint16_t* __restrict__ offs = a.nmsOffs + (size_t)frame * a.nmsGroups * a.nmsRows;
 	int cnt = 0;
-	if (r < a.R) for (int g = 0; g < a.nmsGroups; ++g) cnt += __popc((uint32_t)planes[(size_t)g * a.nmsRows + r]);
+	if (r < a.R) for (int g = 0; g < a.nmsGroups; ++g) {
+		offs[(size_t)g * a.nmsRows + r] = (uint16_t)cnt;
+		cnt += __popc((uint32_t)planes[(size_t)g * a.nmsRows + r]);
+	}
 	int incl = cnt;
 #pragma unroll
 	for (int o = 1; o < 64; o <<= 1) {
@@ -186,41 +191,39 @@ __global__ __launch_bounds__(kRankThreads) void sht_rank_kernel(ShtArgs a)
 	if (t == 0) a.chunkTotals[frame * gridDim.x + blockIdx.x] = total;
 }
 
-// one thread per accumulator row: its survivors, columns ascending, into slots base .. of the frame's key / value arrays.  The eight
-// columns of a flag byte are visited with predicated, independent load / store pairs (a loop over the set bits would wait for every
-// accumulator read before it issued the next).  Block x = 0 of every frame also publishes the frame's line count.
+// one thread per flag byte (row, column group): its up to 8 survivors, columns ascending, into slots chunk base + rowBase + in-row offset
+// of the frame's key / value arrays -- every accumulator read of the kernel is independent of every other.  Block (0, 0) of every frame
+// also publishes the frame's line count.
 constexpr int kEmitThreads = 256;
 __global__ __launch_bounds__(kEmitThreads) void sht_emit_kernel(ShtArgs a, int chunks)
 {
-	const int frame = blockIdx.y;
+	const int frame = blockIdx.z, g = blockIdx.y;
 	const int r = blockIdx.x * kEmitThreads + threadIdx.x;
 	const int* __restrict__ ct = a.chunkTotals + frame * chunks;
-	if (blockIdx.x == 0 && threadIdx.x == 0) {
+	if (blockIdx.x == 0 && g == 0 && threadIdx.x == 0) {
 		int n = 0;
 		for (int k = 0; k < chunks; ++k) n += ct[k];
 		a.lineCounts[frame] = n;
 	}
 	if (r >= a.R) return;
-	const uint8_t* __restrict__ planes = a.nmsFlags + (size_t)frame * a.nmsGroups * a.nmsRows;
-	const uint16_t* __restrict__ acc = a.acc + (size_t)frame * a.accFrameStride + r;
-	size_t pos = a.rowBase[(size_t)frame * a.nmsRows + r];
-	for (int k = 0; k < r / kRankThreads; ++k) pos += (size_t)ct[k];
+	const size_t pi = ((size_t)frame * a.nmsGroups + g) * a.nmsRows + r;
+	const uint32_t f = a.nmsFlags[pi];
+	if (!f) return;
+	const uint16_t* __restrict__ acc = a.acc + (size_t)frame * a.accFrameStride + (size_t)(g * kNmsCols) * a.accPitch + r;
+	uint32_t v[kNmsCols];
+#pragma unroll
+	for (int j = 0; j < kNmsCols; ++j) v[j] = ((f >> j) & 1u) ? (uint32_t)acc[(size_t)j * a.accPitch] : 0u;
+	size_t pos = (size_t)a.rowBase[(size_t)frame * a.nmsRows + r] + (size_t)a.nmsOffs[pi];
+	for (int k = 0; k < r / kRankThreads; ++k) pos += (size_t)ct[k];      // uniform: a block's rows lie in one chunk
 	uint32_t* __restrict__ keys = a.lineKeys + (size_t)frame * a.lineCap;
 	uint32_t* __restrict__ vals = a.lineVals + (size_t)frame * a.lineCap;
 	const uint32_t frameTag = (uint32_t)(a.frames - 1 - frame) << a.strengthBits;
-	const uint32_t cell0 = (uint32_t)r * (uint32_t)a.T;
-	for (int g = 0; g < a.nmsGroups; ++g) {
-		const uint32_t f = planes[(size_t)g * a.nmsRows + r];
-		if (!f) continue;
-		uint32_t v[kNmsCols];
+	const uint32_t cell0 = (uint32_t)r * (uint32_t)a.T + (uint32_t)(g * kNmsCols);
 #pragma unroll
-		for (int j = 0; j < kNmsCols; ++j) v[j] = ((f >> j) & 1u) ? (uint32_t)acc[(size_t)(g * kNmsCols + j) * a.accPitch] : 0u;
-#pragma unroll
-		for (int j = 0; j < kNmsCols; ++j) {
-			if ((f >> j) & 1u) {
-				if (pos < a.lineCap) { keys[pos] = frameTag | v[j]; vals[pos] = cell0 + (uint32_t)(g * kNmsCols + j); }
-				++pos;
-			}
+	for (int j = 0; j < kNmsCols; ++j) {
+		if ((f >> j) & 1u) {
+			if (pos < a.lineCap) { keys[pos] = frameTag | v[j]; vals[pos] = cell0 + (uint32_t)j; }
+			++pos;
 		}
 	}
 }
@@ -331,7 +334,7 @@ hipError_t launch_sht_nms(const ShtArgs& a, int frames, hipStream_t stream)
 	hipLaunchKernelGGL(sht_nms_kernel, grid, dim3(kNmsThreads), 0, stream, a);
 	const int chunks = (a.R + kRankThreads - 1) / kRankThreads;
 	hipLaunchKernelGGL(sht_rank_kernel, dim3(chunks, frames), dim3(kRankThreads), 0, stream, a);
-	hipLaunchKernelGGL(sht_emit_kernel, dim3((a.R + kEmitThreads - 1) / kEmitThreads, frames), dim3(kEmitThreads), 0, stream, a, chunks);
+	hipLaunchKernelGGL(sht_emit_kernel, dim3((a.R + kEmitThreads - 1) / kEmitThreads, a.nmsGroups, frames), dim3(kEmitThreads), 0, stream, a, chunks);
 	// unused key slots must sort last: zero the slots past each frame's count (a zero key sorts last: every real key carries a strength > 0)
 	dim3 pgrid((unsigned)((a.lineCap + kPadThreads * kPadSlots - 1) / (kPadThreads * kPadSlots)), frames);
 	hipLaunchKernelGGL(sht_pad_keys_kernel, pgrid, dim3(kPadThreads), 0, stream, a.lineKeys, a.lineCounts, a.lineCap);
