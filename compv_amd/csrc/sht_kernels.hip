@@ -63,8 +63,8 @@ __global__ __launch_bounds__(256) void bytes_to_bits_kernel(const uint8_t* __res
 //                    group): flag planes [frame][column group][row], 8-byte coalesced stores, no atomics;
 //   sht_rank_kernel  survivors per row (popcounts of the row's flag bytes), exclusive scan inside chunks of 1024 rows -> rowBase[frame][row]
 //                    and the chunk totals (the emit kernel adds the few totals in front of a row's chunk);
-//   sht_emit_kernel  one thread per flag byte: its survivors in column order -> key = frameTag | strength, value = cell (row * T + col) at
-//                    slot chunk base + rowBase + in-row offset of the frame's key / value arrays.
+//   sht_emit_kernel  one workgroup per 64 rows: their survivors in (row, column) order -> key = frameTag | strength, value = cell (row * T + col)
+//                    at slot chunk base + rowBase + in-row offset of the frame's key / value arrays (staged in the LDS, coalesced stores).
 // A stable descending radix sort of the (key, value) pairs then gives frame-major, strength-descending, (row, col)-ascending order with
 // frameBits + strengthBits key bits (18 at 4K x 32 frames: two 10-bit onesweep passes; the unique 40-bit keys of rounds 1-2, which carried
 // the cell because the slots were handed out by atomics in arrival order, took four).
@@ -191,40 +191,66 @@ __global__ __launch_bounds__(kRankThreads) void sht_rank_kernel(ShtArgs a)
 	if (t == 0) a.chunkTotals[frame * gridDim.x + blockIdx.x] = total;
 }
 
-// one thread per flag byte (row, column group): its up to 8 survivors, columns ascending, into slots chunk base + rowBase + in-row offset
-// of the frame's key / value arrays -- every accumulator read of the kernel is independent of every other.  Block (0, 0) of every frame
-// also publishes the frame's line count.
+// One workgroup = kEmitRows consecutive accumulator rows, all column groups (thread = (row, group phase)): the survivors of those rows
+// occupy ONE contiguous slot range of the frame's key / value arrays (rows ascending, columns ascending), so they are put in place in
+// the LDS first and leave as coalesced stores (a thread storing its own few items would touch 64 different cache lines per instruction).
+// Every accumulator read is independent of every other.  Block 0 of every frame also publishes the frame's line count.
 constexpr int kEmitThreads = 256;
+constexpr int kEmitRows = 64;
+constexpr int kEmitStage = 2048;   // slots staged in the LDS; denser row blocks store directly
 __global__ __launch_bounds__(kEmitThreads) void sht_emit_kernel(ShtArgs a, int chunks)
 {
-	const int frame = blockIdx.z, g = blockIdx.y;
-	const int r = blockIdx.x * kEmitThreads + threadIdx.x;
+	__shared__ uint32_t s_keys[kEmitStage], s_vals[kEmitStage];
+	const int frame = blockIdx.y;
+	const int r0 = blockIdx.x * kEmitRows;
+	const int r = r0 + (threadIdx.x & (kEmitRows - 1)), phase = threadIdx.x / kEmitRows;
 	const int* __restrict__ ct = a.chunkTotals + frame * chunks;
-	if (blockIdx.x == 0 && g == 0 && threadIdx.x == 0) {
+	if (blockIdx.x == 0 && threadIdx.x == 0) {
 		int n = 0;
 		for (int k = 0; k < chunks; ++k) n += ct[k];
 		a.lineCounts[frame] = n;
 	}
-	if (r >= a.R) return;
-	const size_t pi = ((size_t)frame * a.nmsGroups + g) * a.nmsRows + r;
-	const uint32_t f = a.nmsFlags[pi];
-	if (!f) return;
-	const uint16_t* __restrict__ acc = a.acc + (size_t)frame * a.accFrameStride + (size_t)(g * kNmsCols) * a.accPitch + r;
-	uint32_t v[kNmsCols];
-#pragma unroll
-	for (int j = 0; j < kNmsCols; ++j) v[j] = ((f >> j) & 1u) ? (uint32_t)acc[(size_t)j * a.accPitch] : 0u;
-	size_t pos = (size_t)a.rowBase[(size_t)frame * a.nmsRows + r] + (size_t)a.nmsOffs[pi];
-	for (int k = 0; k < r / kRankThreads; ++k) pos += (size_t)ct[k];      // uniform: a block's rows lie in one chunk
+	// slot range of this block: [first, last) (kRankThreads is a multiple of kEmitRows: the block's rows lie in one chunk)
+	size_t chunkBase = 0;
+	for (int k = 0; k < r0 / kRankThreads; ++k) chunkBase += (size_t)ct[k];
+	const uint32_t* __restrict__ rb = a.rowBase + (size_t)frame * a.nmsRows;
+	const int rEnd = min(r0 + kEmitRows, a.R);
+	const size_t first = chunkBase + rb[r0];
+	size_t last;
+	if (rEnd < a.R && (rEnd % kRankThreads) != 0) last = chunkBase + rb[rEnd];
+	else last = chunkBase + (size_t)ct[r0 / kRankThreads];          // the block ends its chunk (or the accumulator)
+	const size_t span = last - first;
+	const bool staged = span <= (size_t)kEmitStage;
 	uint32_t* __restrict__ keys = a.lineKeys + (size_t)frame * a.lineCap;
 	uint32_t* __restrict__ vals = a.lineVals + (size_t)frame * a.lineCap;
-	const uint32_t frameTag = (uint32_t)(a.frames - 1 - frame) << a.strengthBits;
-	const uint32_t cell0 = (uint32_t)r * (uint32_t)a.T + (uint32_t)(g * kNmsCols);
+	if (r < a.R) {
+		const size_t rowPos = chunkBase + rb[r];
+		const uint32_t frameTag = (uint32_t)(a.frames - 1 - frame) << a.strengthBits;
+		for (int g = phase; g < a.nmsGroups; g += kEmitThreads / kEmitRows) {
+			const size_t pi = ((size_t)frame * a.nmsGroups + g) * a.nmsRows + r;
+			const uint32_t f = a.nmsFlags[pi];
+			if (!f) continue;
+			const uint16_t* __restrict__ acc = a.acc + (size_t)frame * a.accFrameStride + (size_t)(g * kNmsCols) * a.accPitch + r;
+			uint32_t v[kNmsCols];
 #pragma unroll
-	for (int j = 0; j < kNmsCols; ++j) {
-		if ((f >> j) & 1u) {
-			if (pos < a.lineCap) { keys[pos] = frameTag | v[j]; vals[pos] = cell0 + (uint32_t)j; }
-			++pos;
+			for (int j = 0; j < kNmsCols; ++j) v[j] = ((f >> j) & 1u) ? (uint32_t)acc[(size_t)j * a.accPitch] : 0u;
+			size_t pos = rowPos + (size_t)a.nmsOffs[pi];
+			const uint32_t cell0 = (uint32_t)r * (uint32_t)a.T + (uint32_t)(g * kNmsCols);
+#pragma unroll
+			for (int j = 0; j < kNmsCols; ++j) {
+				if ((f >> j) & 1u) {
+					if (staged) { s_keys[pos - first] = frameTag | v[j]; s_vals[pos - first] = cell0 + (uint32_t)j; }
+					else if (pos < a.lineCap) { keys[pos] = frameTag | v[j]; vals[pos] = cell0 + (uint32_t)j; }
+					++pos;
+				}
+			}
 		}
+	}
+	if (!staged) return; // uniform
+	__syncthreads();
+	for (size_t i = threadIdx.x; i < span; i += kEmitThreads) {
+		const size_t pos = first + i;
+		if (pos < a.lineCap) { keys[pos] = s_keys[i]; vals[pos] = s_vals[i]; }
 	}
 }
 
@@ -334,7 +360,7 @@ hipError_t launch_sht_nms(const ShtArgs& a, int frames, hipStream_t stream)
 	hipLaunchKernelGGL(sht_nms_kernel, grid, dim3(kNmsThreads), 0, stream, a);
 	const int chunks = (a.R + kRankThreads - 1) / kRankThreads;
 	hipLaunchKernelGGL(sht_rank_kernel, dim3(chunks, frames), dim3(kRankThreads), 0, stream, a);
-	hipLaunchKernelGGL(sht_emit_kernel, dim3((a.R + kEmitThreads - 1) / kEmitThreads, a.nmsGroups, frames), dim3(kEmitThreads), 0, stream, a, chunks);
+	hipLaunchKernelGGL(sht_emit_kernel, dim3((a.R + kEmitRows - 1) / kEmitRows, frames), dim3(kEmitThreads), 0, stream, a, chunks);
 	// unused key slots must sort last: zero the slots past each frame's count (a zero key sorts last: every real key carries a strength > 0)
 	dim3 pgrid((unsigned)((a.lineCap + kPadThreads * kPadSlots - 1) / (kPadThreads * kPadSlots)), frames);
 	hipLaunchKernelGGL(sht_pad_keys_kernel, pgrid, dim3(kPadThreads), 0, stream, a.lineKeys, a.lineCounts, a.lineCap);
