@@ -72,46 +72,41 @@ __global__ __launch_bounds__(256) void bytes_to_bits_kernel(const uint8_t* __res
 constexpr int kNmsThreads = 128;
 constexpr int kNmsCols = 8;                  // theta columns per block
 constexpr int kNmsRows = kNmsThreads * 8;    // rho rows per block: 8 per thread
-constexpr int kNmsTileRows = kNmsRows + 16;  // + 8 rows of halo either side (keeps every 16-byte load aligned)
 
-// One block owns kNmsCols theta columns x kNmsRows rho rows of the theta-major accumulator. The tile plus a one-cell halo is
-// staged in LDS with 16-byte coalesced loads (each accumulator cell is read (kNmsCols+2)/kNmsCols times), so the 3x3
-// neighbourhood test never issues a scattered global load. A thread's survivors are one byte per row (bit j = column c0 + j).
+// One block owns kNmsCols theta columns x kNmsRows rho rows of the theta-major accumulator; a thread 8 consecutive rows of all columns
+// (+ one column either side): ten 16-byte coalesced loads straight into registers (each accumulator cell is read (kNmsCols+2)/kNmsCols
+// times).  The rows above / below a thread's eight come from the neighbouring lanes (lane shuffles), for the first / last lane of a wave
+// from two extra loads: no LDS tile, no barrier -- the waves of the launch are independent and hide each other's load latency (the
+// LDS-tiled version of rounds 1-2 ran load -> barrier -> compute per block at 3.5 waves per SIMD: 45 us for 87 MB).
+// A thread's survivors are one byte per row (bit j = column c0 + j).
 __global__ __launch_bounds__(kNmsThreads) void sht_nms_kernel(ShtArgs a)
 {
-	__shared__ __attribute__((aligned(16))) uint16_t s_tile[kNmsCols + 2][kNmsTileRows];
 	const int frame = blockIdx.z;
 	const int c0 = blockIdx.y * kNmsCols;
 	const int base = blockIdx.x * kNmsRows;
-	const int t = threadIdx.x;
+	const int t = threadIdx.x, lane = t & 63;
 	const uint16_t* __restrict__ acc = a.acc + (size_t)frame * a.accFrameStride;
 	const size_t p = a.accPitch;
-	{
-		uint4 v[kNmsCols + 2];
-		uint4 x = make_uint4(0, 0, 0, 0);
-		const int r0 = base - 8 + t * 8;
-		const int xr0 = base - 8 + (kNmsThreads + (t & 1)) * 8; // the two extra 8-row groups: threads 2j, 2j+1 fetch them for tile column j
-		const int xc = c0 - 1 + (t >> 1);
+	const int r0 = base + t * 8;
+	uint4 v[kNmsCols + 2];
+	uint32_t up[kNmsCols + 2], dn[kNmsCols + 2];   // rows r0 - 1 and r0 + 8 of every column (only read on lanes 0 / 63)
 #pragma unroll
-		for (int j = 0; j < kNmsCols + 2; ++j) {
-			const int c = c0 - 1 + j;
-			v[j] = make_uint4(0, 0, 0, 0);
-			if (c >= 0 && c < a.T && r0 >= 0 && r0 < a.accPitch) v[j] = *reinterpret_cast<const uint4*>(acc + (size_t)c * p + r0);
-		}
-		if (t < 2 * (kNmsCols + 2) && xc >= 0 && xc < a.T && xr0 < a.accPitch) x = *reinterpret_cast<const uint4*>(acc + (size_t)xc * p + xr0);
-#pragma unroll
-		for (int j = 0; j < kNmsCols + 2; ++j) *reinterpret_cast<uint4*>(&s_tile[j][t * 8]) = v[j];
-		if (t < 2 * (kNmsCols + 2)) *reinterpret_cast<uint4*>(&s_tile[t >> 1][(kNmsThreads + (t & 1)) * 8]) = x;
+	for (int j = 0; j < kNmsCols + 2; ++j) {
+		const int c = c0 - 1 + j;
+		const bool cok = (c >= 0 && c < a.T);
+		v[j] = make_uint4(0, 0, 0, 0);
+		if (cok && r0 < a.accPitch) v[j] = *reinterpret_cast<const uint4*>(acc + (size_t)c * p + r0);   // accPitch is a multiple of 64 rows
+		up[j] = (lane == 0 && cok && r0 >= 1 && r0 - 1 < a.accPitch) ? (uint32_t)acc[(size_t)c * p + r0 - 1] : 0u;
+		dn[j] = (lane == 63 && cok && r0 + 8 < a.accPitch) ? (uint32_t)acc[(size_t)c * p + r0 + 8] : 0u;
 	}
-	__syncthreads();
-
-	// column j of the block = tile column j+1; this thread's rows are tile rows [8+8t, 16+8t), neighbours at 7+8t and 16+8t
+	// x[1..8] = the thread's rows of tile column tj, x[0] / x[9] the rows above / below
 	auto readCol = [&](int tj, int (&x)[10]) {
-		const uint4 w = *reinterpret_cast<const uint4*>(&s_tile[tj][8 + t * 8]);
-		x[0] = s_tile[tj][7 + t * 8];
+		const uint4 w = v[tj];
+		const uint32_t above = __shfl_up(w.w >> 16, 1), below = __shfl_down(w.x & 0xffffu, 1);
+		x[0] = (int)(lane == 0 ? up[tj] : above);
 		x[1] = w.x & 0xffffu; x[2] = w.x >> 16; x[3] = w.y & 0xffffu; x[4] = w.y >> 16;
 		x[5] = w.z & 0xffffu; x[6] = w.z >> 16; x[7] = w.w & 0xffffu; x[8] = w.w >> 16;
-		x[9] = s_tile[tj][16 + t * 8];
+		x[9] = (int)(lane == 63 ? dn[tj] : below);
 	};
 	int side[3][8]; // max(x[k], x[k+1], x[k+2]) of tile columns j, j+1, j+2 (ring)
 	int mid[10], nxt[10];
@@ -278,11 +273,17 @@ __global__ __launch_bounds__(256) void sht_decode_kernel(const uint32_t* __restr
                                                          int T, int barrier, float thetaStep, int maxLines, int strengthBits, LineOut* __restrict__ lines, size_t outCap)
 {
 	const int frame = blockIdx.y;
-	size_t off = 0;
-	for (int g = 0; g < frame; ++g) {
-		const size_t cg = (size_t)max(counts[g], 0);
-		off += cg < lineCap ? cg : lineCap;
+	__shared__ size_t s_off;
+	if (threadIdx.x == 0) {   // once per block, not once per thread
+		size_t o = 0;
+		for (int g = 0; g < frame; ++g) {
+			const size_t cg = (size_t)max(counts[g], 0);
+			o += cg < lineCap ? cg : lineCap;
+		}
+		s_off = o;
 	}
+	__syncthreads();
+	const size_t off = s_off;
 	size_t n = (size_t)max(counts[frame], 0);
 	if (n > lineCap) n = lineCap;
 	if (maxLines > 0 && n > (size_t)maxLines) n = (size_t)maxLines;
