@@ -75,38 +75,48 @@ constexpr int kNmsRows = kNmsThreads * 8;    // rho rows per block: 8 per thread
 
 // One block owns kNmsCols theta columns x kNmsRows rho rows of the theta-major accumulator; a thread 8 consecutive rows of all columns
 // (+ one column either side): ten 16-byte coalesced loads straight into registers (each accumulator cell is read (kNmsCols+2)/kNmsCols
-// times).  The rows above / below a thread's eight come from the neighbouring lanes (lane shuffles), for the first / last lane of a wave
-// from two extra loads: no LDS tile, no barrier -- the waves of the launch are independent and hide each other's load latency (the
-// LDS-tiled version of rounds 1-2 ran load -> barrier -> compute per block at 3.5 waves per SIMD: 45 us for 87 MB).
+// times), the rows above / below its eight with two 2-byte loads per column (lines its neighbours fetch anyway): no LDS tile, no
+// barrier -- the waves of the launch are independent and hide each other's load latency (the LDS-tiled version of rounds 1-2 ran
+// load -> barrier -> compute per block at 3.5 waves per SIMD: 45 us for 87 MB).
 // A thread's survivors are one byte per row (bit j = column c0 + j).
 __global__ __launch_bounds__(kNmsThreads) void sht_nms_kernel(ShtArgs a)
 {
 	const int frame = blockIdx.z;
 	const int c0 = blockIdx.y * kNmsCols;
 	const int base = blockIdx.x * kNmsRows;
-	const int t = threadIdx.x, lane = t & 63;
+	const int t = threadIdx.x;
 	const uint16_t* __restrict__ acc = a.acc + (size_t)frame * a.accFrameStride;
 	const size_t p = a.accPitch;
 	const int r0 = base + t * 8;
+	// All 30 loads of a thread are unconditional (clamped addresses, invalid cells zeroed afterwards), so they are in flight together.
+	const int rc = min(r0, a.accPitch - 8);                       // accPitch is a multiple of 64 rows
+	const int ru = max(r0 - 1, 0), rd = min(r0 + 8, a.accPitch - 1);
+	const bool rok = r0 < a.accPitch, uok = r0 >= 1 && r0 - 1 < a.accPitch, dok = r0 + 8 < a.accPitch;
 	uint4 v[kNmsCols + 2];
-	uint32_t up[kNmsCols + 2], dn[kNmsCols + 2];   // rows r0 - 1 and r0 + 8 of every column (only read on lanes 0 / 63)
+	uint32_t up[kNmsCols + 2], dn[kNmsCols + 2];   // rows r0 - 1 and r0 + 8 of every column
+#pragma unroll
+	for (int j = 0; j < kNmsCols + 2; ++j) {
+		const int c = c0 - 1 + j;
+		const uint16_t* __restrict__ col = acc + (size_t)min(max(c, 0), a.T - 1) * p;
+		v[j] = *reinterpret_cast<const uint4*>(col + rc);
+		up[j] = col[ru];
+		dn[j] = col[rd];
+	}
 #pragma unroll
 	for (int j = 0; j < kNmsCols + 2; ++j) {
 		const int c = c0 - 1 + j;
 		const bool cok = (c >= 0 && c < a.T);
-		v[j] = make_uint4(0, 0, 0, 0);
-		if (cok && r0 < a.accPitch) v[j] = *reinterpret_cast<const uint4*>(acc + (size_t)c * p + r0);   // accPitch is a multiple of 64 rows
-		up[j] = (lane == 0 && cok && r0 >= 1 && r0 - 1 < a.accPitch) ? (uint32_t)acc[(size_t)c * p + r0 - 1] : 0u;
-		dn[j] = (lane == 63 && cok && r0 + 8 < a.accPitch) ? (uint32_t)acc[(size_t)c * p + r0 + 8] : 0u;
+		if (!(cok && rok)) v[j] = make_uint4(0, 0, 0, 0);
+		if (!(cok && uok)) up[j] = 0u;
+		if (!(cok && dok)) dn[j] = 0u;
 	}
 	// x[1..8] = the thread's rows of tile column tj, x[0] / x[9] the rows above / below
 	auto readCol = [&](int tj, int (&x)[10]) {
 		const uint4 w = v[tj];
-		const uint32_t above = __shfl_up(w.w >> 16, 1), below = __shfl_down(w.x & 0xffffu, 1);
-		x[0] = (int)(lane == 0 ? up[tj] : above);
+		x[0] = (int)up[tj];
 		x[1] = w.x & 0xffffu; x[2] = w.x >> 16; x[3] = w.y & 0xffffu; x[4] = w.y >> 16;
 		x[5] = w.z & 0xffffu; x[6] = w.z >> 16; x[7] = w.w & 0xffffu; x[8] = w.w >> 16;
-		x[9] = (int)(lane == 63 ? dn[tj] : below);
+		x[9] = (int)dn[tj];
 	};
 	int side[3][8]; // max(x[k], x[k+1], x[k+2]) of tile columns j, j+1, j+2 (ring)
 	int mid[10], nxt[10];
