@@ -90,7 +90,7 @@ __global__ __launch_bounds__(kNmsThreads) void sht_nms_kernel(ShtArgs a)
 	const int r0 = base + t * 8;
 	// All 30 loads of a thread are unconditional (clamped addresses, invalid cells zeroed afterwards), so they are in flight together.
 	const int rc = min(r0, a.accPitch - 8);                       // accPitch is a multiple of 64 rows
-	const int ru = max(r0 - 1, 0), rd = min(r0 + 8, a.accPitch - 1);
+	const int ru = min(max(r0 - 1, 0), a.accPitch - 1), rd = min(r0 + 8, a.accPitch - 1);
 	const bool rok = r0 < a.accPitch, uok = r0 >= 1 && r0 - 1 < a.accPitch, dok = r0 + 8 < a.accPitch;
 	uint4 v[kNmsCols + 2];
 	uint32_t up[kNmsCols + 2], dn[kNmsCols + 2];   // rows r0 - 1 and r0 + 8 of every column
