@@ -389,16 +389,12 @@ __global__ __launch_bounds__(kResolveThreads) void canny_resolve_kernel(ResolveA
 		haveU |= (u[j] != 0);
 	}
 	if (!__syncthreads_or(haveU)) { if (tid == 0) *mine = 0; return; }  // nothing unresolved in this band
-	// E rows with their halo: wave = row (stride: the workgroup's waves), lane = word -- no division by the (odd) row pitch
-	for (int r = tid >> 6; r < rows + 2; r += kResolveThreads / 64) {
-		const int y = y0 - 1 + r;
-		const bool yok = (y >= 0 && y < a.H);
-		for (int c = tid & 63; c < ew; c += 64) {
-			const int w = w0 - 1 + c;
-			uint32_t v = 0;
-			if (yok && w >= 0 && w < wb) v = gE[(size_t)y * wb + w];
-			sE[r * ew + c] = v;
-		}
+	for (int i = tid; i < (rows + 2) * ew; i += kResolveThreads) {
+		const int r = i / ew, c = i - r * ew;
+		const int y = y0 - 1 + r, w = w0 - 1 + c;
+		uint32_t v = 0;
+		if (y >= 0 && y < a.H && w >= 0 && w < wb) v = gE[(size_t)y * wb + w];
+		sE[i] = v;
 	}
 	__syncthreads();
 	uint32_t* const col = sE + (size_t)(n > 0 ? r0 : 0) * ew + k + 1;   // LDS word of (row r0 - 1, column k); row j of the group is col[(j + 1) * ew]

@@ -8,8 +8,6 @@ echo "pytest exit $?" >> $O/pytest.log
 tail -4 $O/pytest.log
 B="python bench.py --no-cpu-baseline"
 $B > $O/bench_default.json 2> $O/bench_default.err
-$B --no-extras --inflight 3 > $O/bench_inflight3.json 2> $O/bench_inflight3.err
-$B --no-extras --inflight 1 > $O/bench_inflight1.json 2> $O/bench_inflight1.err
 for f in $O/bench_*.json; do python - "$f" <<'PY'
 import json,sys
 try:
