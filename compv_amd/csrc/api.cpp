@@ -117,7 +117,8 @@ struct compvhip_plan {
 	bool voteTiles = false;                      // the tile grid exists
 	ShtTileArgs vt = {};                         // geometry + device tables
 	std::vector<int32_t> vtKt, vtRowBase;        // host copies of the [tiles][T] tables
-	int32_t* dKt = nullptr; int32_t* dRowBase = nullptr; uint16_t* partial = nullptr; int* tileCounts = nullptr;
+	std::vector<uint32_t> vtExcl;                // [tiles][T] window rows [lo, hi) (lo | hi << 16) no other tile's window covers
+	int32_t* dKt = nullptr; int32_t* dRowBase = nullptr; uint32_t* dExcl = nullptr; uint16_t* partial = nullptr; int* tileCounts = nullptr;
 	// batched KHT (compvhip_plan_houghkht): one scratch set + stream per worker thread, stage clocks of the last call
 	std::vector<KhtScratch*> khtWorkers;
 	double khtStageMs[6] = {}; double khtWallMs = 0.0; int khtThreads = 0;
@@ -367,13 +368,35 @@ int ensureSht(compvhip_plan* p)
 	}
 	{
 		if (p->vt.tiles <= 0 || p->vtKt.size() != static_cast<size_t>(p->vt.tiles) * T) return fail(ctx, COMPVHIP_E_INVALID_STATE, "vote tiles were not planned");
-		dfree(ctx, p->dKt); dfree(ctx, p->dRowBase); dfree(ctx, p->partial);
+		dfree(ctx, p->dKt); dfree(ctx, p->dRowBase); dfree(ctx, p->dExcl); dfree(ctx, p->partial);
+		{
+			// Exclusive part of every window: the windows of one theta all have Rw rows, so what the other tiles' windows leave of a window is
+			// one interval [lo, hi) (window rows, multiples of 8).  The vote kernel stores those rows straight into the accumulator; only the
+			// rows two or more windows share go through the partial windows and the reduce kernel.
+			const int tiles = p->vt.tiles, Rw = p->vt.Rw;
+			p->vtExcl.assign(static_cast<size_t>(tiles) * T, 0u);
+			for (size_t t = 0; t < T; ++t) for (int i = 0; i < tiles; ++i) {
+				const int lo = p->vtRowBase[static_cast<size_t>(i) * T + t];
+				int exLo = lo, exHi = lo + Rw;
+				for (int u = 0; u < tiles; ++u) {
+					if (u == i) continue;
+					const int blo = p->vtRowBase[static_cast<size_t>(u) * T + t], bhi = blo + Rw;
+					if (bhi <= lo || blo >= lo + Rw) continue;       // disjoint
+					if (blo <= lo) exLo = std::max(exLo, bhi);       // covers a prefix (everything when blo == lo)
+					else exHi = std::min(exHi, blo);                 // covers a suffix
+				}
+				if (exHi < exLo) exHi = exLo;
+				p->vtExcl[static_cast<size_t>(i) * T + t] = static_cast<uint32_t>(exLo - lo) | (static_cast<uint32_t>(exHi - lo) << 16);
+			}
+		}
+		HIPCHK(ctx, dmalloc(ctx, &p->dExcl, p->vtExcl.size()));
+		HIPCHK(ctx, hipMemcpy(p->dExcl, p->vtExcl.data(), p->vtExcl.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
 		HIPCHK(ctx, dmalloc(ctx, &p->dKt, p->vtKt.size()));
 		HIPCHK(ctx, dmalloc(ctx, &p->dRowBase, p->vtRowBase.size()));
 		HIPCHK(ctx, hipMemcpy(p->dKt, p->vtKt.data(), p->vtKt.size() * sizeof(int32_t), hipMemcpyHostToDevice));
 		HIPCHK(ctx, hipMemcpy(p->dRowBase, p->vtRowBase.data(), p->vtRowBase.size() * sizeof(int32_t), hipMemcpyHostToDevice));
 		HIPCHK(ctx, dmalloc(ctx, &p->partial, p->frames * p->vt.tiles * static_cast<size_t>(p->vt.Tpad) * p->vt.rwPitch));
-		p->vt.kt = p->dKt; p->vt.rowBase = p->dRowBase; p->vt.partial = p->partial; p->vt.tileCounts = p->tileCounts;
+		p->vt.kt = p->dKt; p->vt.rowBase = p->dRowBase; p->vt.excl = p->dExcl; p->vt.partial = p->partial; p->vt.tileCounts = p->tileCounts;
 		p->edgeCap = static_cast<size_t>(p->vt.tiles) * p->vt.tileCap; // per frame: one list of TW * TH entries per tile
 	}
 	HIPCHK(ctx, dmalloc(ctx, &p->edges, p->edgeCap * p->frames));
@@ -683,7 +706,7 @@ void compvhip_plan_destroy(compvhip_plan* p)
 	for (KhtScratch* k : p->khtWorkers) { khtScratchFree(ctx, *k); delete k; }
 	p->khtWorkers.clear();
 	dfree(ctx, p->cosT); dfree(ctx, p->invSinT);
-	dfree(ctx, p->dKt); dfree(ctx, p->dRowBase); dfree(ctx, p->partial);
+	dfree(ctx, p->dKt); dfree(ctx, p->dRowBase); dfree(ctx, p->dExcl); dfree(ctx, p->partial);
 	dfree(ctx, p->sinQ); dfree(ctx, p->cosQ); dfree(ctx, p->edges); dfree(ctx, p->acc);
 	dfree(ctx, p->keysA); dfree(ctx, p->keysB); dfree(ctx, p->valsA); dfree(ctx, p->valsB); dfree(ctx, p->nmsFlags); dfree(ctx, p->nmsOffs); dfree(ctx, p->rowBase); dfree(ctx, p->chunkTotals);
 	dfree(ctx, p->sortTemp);

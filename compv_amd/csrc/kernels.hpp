@@ -122,6 +122,7 @@ struct ShtArgs {
 struct ShtTileArgs {
 	const int32_t* kt;        // [tiles][T]  window constant K of (tile, theta): window row = (K - lx cosQ - ly sinQ) >> 16
 	const int32_t* rowBase;   // [tiles][T]  accumulator row of window row 0
+	const uint32_t* excl;     // [tiles][T]  window rows [lo, hi) (lo | hi << 16, multiples of 8) that no other tile's window of this theta covers
 	uint16_t* partial;        // [frames][tiles][Tpad][rwPitch]  theta-major partial accumulators (one window per tile and theta)
 	int* tileCounts;          // [frames][tiles] edges per tile
 	int nx, ny, TW, TH, tiles;  // tile grid; TW % 32 == 0

@@ -199,9 +199,14 @@ __global__ __launch_bounds__(kVtThreads) void sht_vote_tiles_kernel(ShtArgs a, S
 	__syncthreads();
 
 	// flush, theta-major: lane = theta reads 8 consecutive window rows of its own column (bank = lane: conflict-free) and writes them
-	// as one 16-byte store into partial[frame][tile][theta][w .. w + 7]
+	// as one 16-byte store -- straight into the accumulator where this tile's window is the only one that covers the rows (80 % of the
+	// cells at 4K), into partial[frame][tile][theta][w .. w + 7] where windows overlap (the reduce kernel adds those)
 	uint16_t* __restrict__ part = v.partial + (((size_t)unit * v.Tpad) + (size_t)g * 64 + lane) * v.rwPitch;
 	const int sh = (lane & 32) ? 16 : 0;
+	const uint32_t ex = v.excl[(size_t)tile * a.T + tt];
+	const int exLo = (t < a.T) ? (int)(ex & 0xffffu) : 0, exHi = (t < a.T) ? (int)(ex >> 16) : 0;   // a theta past T has no accumulator column
+	const int rb = v.rowBase[(size_t)tile * a.T + tt];
+	uint16_t* __restrict__ accCol = a.acc + (size_t)frame * a.accFrameStride + (size_t)tt * a.accPitch + rb;
 	// (a wave writes 64 consecutive rows = one whole 128-byte line per theta back to back, so the L2 merges the eight 16-byte pieces
 	// before the line is evicted: 301 MB of HBM writes per launch for 179 MB of partials when the pieces came from eight different waves)
 	for (int wb = wave * 64; wb < v.Rw; wb += (kVtThreads / 64) * 64)
@@ -213,7 +218,9 @@ __global__ __launch_bounds__(kVtThreads) void sht_vote_tiles_kernel(ShtArgs a, S
 		u32x4 o;
 		o.x = c[0] | (c[1] << 16); o.y = c[2] | (c[3] << 16); o.z = c[4] | (c[5] << 16); o.w = c[6] | (c[7] << 16);
 		// (one 16-byte store, spelled out: the loop vectoriser otherwise splits it into four dword stores, 4x the store instructions)
-		asm volatile("global_store_dwordx4 %0, %1, off" : : "v"(part + w0), "v"(o) : "memory");
+		const bool direct = (w0 >= exLo) && (w0 < exHi) && (rb + w0 + 8 <= a.accPitch);
+		uint16_t* const dst = direct ? accCol + w0 : part + w0;
+		asm volatile("global_store_dwordx4 %0, %1, off" : : "v"(dst), "v"(o) : "memory");
 	}
 }
 
@@ -232,18 +239,25 @@ __global__ __launch_bounds__(kRdThreads) void sht_reduce_tiles_kernel(ShtArgs a,
 	const int rb0 = blockIdx.x * (kRdThreads * kRdRows);
 	const int r0 = rb0 + threadIdx.x * kRdRows;
 	const uint16_t* __restrict__ part = v.partial + ((size_t)frame * v.tiles * v.Tpad + theta) * v.rwPitch;
-	uint4 sum = make_uint4(0, 0, 0, 0); // 8 u16 cells; a cell never exceeds 2 max(W, H) < 65536: the packed halves cannot carry
+	// Rows covered by exactly one window were stored by that tile's vote workgroup already, rows no window covers never receive a vote
+	// and stay zero for ever: only the rows two or more windows share are summed here.
+	int covers = 0;
 	for (int tile = 0; tile < v.tiles; ++tile) {
 		const int base = v.rowBase[(size_t)tile * a.T + theta]; // a multiple of 8 (planVoteTiles), like r0 and Rw
-		if (base >= rb0 + kRdThreads * kRdRows || base + v.Rw <= rb0) continue; // uniform
+		const int w0 = r0 - base;
+		covers += (w0 >= 0 && w0 < v.Rw) ? 1 : 0;
+	}
+	if (covers < 2 || r0 >= a.accPitch) return;
+	uint4 sum = make_uint4(0, 0, 0, 0); // 8 u16 cells; a cell never exceeds 2 max(W, H) < 65536: the packed halves cannot carry
+	for (int tile = 0; tile < v.tiles; ++tile) {
+		const int base = v.rowBase[(size_t)tile * a.T + theta];
 		const int w0 = r0 - base;
 		if (w0 >= 0 && w0 < v.Rw) {
 			const uint4 c = *reinterpret_cast<const uint4*>(part + (size_t)tile * v.Tpad * v.rwPitch + w0);
 			sum.x += c.x; sum.y += c.y; sum.z += c.z; sum.w += c.w;
 		}
 	}
-	// accPitch is a multiple of 64; rows [R, accPitch) must stay zero and do: no window cell past row R - 1 ever receives a vote
-	if (r0 < a.accPitch) *reinterpret_cast<uint4*>(a.acc + (size_t)frame * a.accFrameStride + (size_t)theta * a.accPitch + r0) = sum;
+	*reinterpret_cast<uint4*>(a.acc + (size_t)frame * a.accFrameStride + (size_t)theta * a.accPitch + r0) = sum;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
