@@ -218,7 +218,8 @@ __global__ __launch_bounds__(kVtThreads) void sht_vote_tiles_kernel(ShtArgs a, S
 		u32x4 o;
 		o.x = c[0] | (c[1] << 16); o.y = c[2] | (c[3] << 16); o.z = c[4] | (c[5] << 16); o.w = c[6] | (c[7] << 16);
 		// (one 16-byte store, spelled out: the loop vectoriser otherwise splits it into four dword stores, 4x the store instructions)
-		const bool direct = (w0 >= exLo) && (w0 < exHi) && (rb + w0 + 8 <= a.accPitch);
+		// (tiles at the image border are not clipped: part of their windows lies outside the accumulator's rows and never receives a vote)
+		const bool direct = (w0 >= exLo) && (w0 < exHi) && (rb + w0 >= 0) && (rb + w0 + 8 <= a.accPitch);
 		uint16_t* const dst = direct ? accCol + w0 : part + w0;
 		asm volatile("global_store_dwordx4 %0, %1, off" : : "v"(dst), "v"(o) : "memory");
 	}
