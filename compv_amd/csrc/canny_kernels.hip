@@ -389,8 +389,9 @@ __global__ __launch_bounds__(kResolveThreads) void canny_resolve_kernel(ResolveA
 		haveU |= (u[j] != 0);
 	}
 	if (!__syncthreads_or(haveU)) { if (tid == 0) *mine = 0; return; }  // nothing unresolved in this band
+	const uint32_t ewInv = (1u << 19) / (uint32_t)ew + 1u;   // i / ew == (i * ewInv) >> 19 for every i < 66 * 66, 3 <= ew <= 66 (verified exhaustively)
 	for (int i = tid; i < (rows + 2) * ew; i += kResolveThreads) {
-		const int r = i / ew, c = i - r * ew;
+		const int r = (int)(((uint32_t)i * ewInv) >> 19), c = i - r * ew;
 		const int y = y0 - 1 + r, w = w0 - 1 + c;
 		uint32_t v = 0;
 		if (y >= 0 && y < a.H && w >= 0 && w < wb) v = gE[(size_t)y * wb + w];

@@ -43,6 +43,7 @@ __global__ __launch_bounds__(kTcThreads) void sht_compact_tiles_kernel(ShtArgs a
 	const int ty = tile / v.nx, tx = tile - ty * v.nx;
 	const int x0 = tx * v.TW, y0 = ty * v.TH;
 	const int wpr = v.TW >> 5;                                  // mask words per tile row
+	const uint32_t wprInv = (1u << 20) / (uint32_t)wpr + 1u;    // i / wpr == (i * wprInv) >> 20 for every i < 64 * 40 and wpr <= 40 (verified exhaustively)
 	const int ly0 = chunk * kTcRows;
 	const int rows = min(min(kTcRows, v.TH - ly0), a.H - (y0 + ly0));
 	const int nwords = max(rows, 0) * wpr;
@@ -56,7 +57,7 @@ __global__ __launch_bounds__(kTcThreads) void sht_compact_tiles_kernel(ShtArgs a
 		const int i = threadIdx.x + k * kTcThreads;
 		wv[k] = 0u; wl[k] = 0;
 		if (i < nwords) {
-			const int r = i / wpr, c = i - r * wpr;
+			const int r = (int)(((uint32_t)i * wprInv) >> 20), c = i - r * wpr;   // (an integer division per word cost a third of the kernel)
 			if (w0 + c < a.wb) wv[k] = bits[(size_t)(y0 + ly0 + r) * a.wb + w0 + c];
 			wl[k] = ((ly0 + r) << 16) | (c << 5);
 			cnt += __popc(wv[k]);

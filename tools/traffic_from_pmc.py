@@ -7,12 +7,16 @@ Units and corrections (MI355X_MICROARCH.md, HBM section; re-calibrated here on a
   * FETCH_SIZE reports exactly 1/2 of the bytes of a coalesced streaming read on gfx950: the pure-read calibration kernel
     edge_dete_kernel<.,.,false> must fetch 32*3840*2160 * 66/64 B = 267300 KiB and the counter reads 133587 (x2.00).
 So hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE) * 1024 per launch."""
-import csv, glob, json, os, sys
+import csv, glob, hashlib, json, os, subprocess, sys, tempfile
 from collections import defaultdict
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
 
 
 # device kernel -> the stage name bench.py / compvhip_plan_get_timing use
-STAGE_NAMES = {"sht_vote_tiles_kernel": "sht_vote_kernel", "sht_reduce_tiles_kernel": "sht_reduce_kernel", "sht_compact_tiles_kernel": "sht_compact_kernel"}
+STAGE_NAMES = {"sht_vote_tiles_kernel": "sht_vote_kernel", "sht_reduce_tiles_kernel": "sht_reduce_kernel", "sht_compact_tiles_kernel": "sht_compact_kernel",
+               "canny_swar_tile_kernel": "canny_tile_kernel"}
 
 
 def mean_counter(d, counter):
@@ -25,10 +29,35 @@ def mean_counter(d, counter):
     return {k: v[0] / v[1] for k, v in agg.items()}
 
 
+def valu_mix(src, kernel_substr):
+    """Static VALU mix of a kernel (tools/isa_cost.py classes over hipcc's assembly of `src`): average issue cycles per wave64 VALU
+    instruction with the microbenchmark costs (2.3 fast / 4.3 everything else).  Whole-kernel static counts: the row loops dominate them."""
+    import isa_cost
+    with tempfile.TemporaryDirectory() as td:
+        asm = os.path.join(td, "k.s")
+        subprocess.check_call(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-Wno-inline-asm", "--cuda-device-only",
+                               "-S", os.path.join(ROOT, "compv_amd", "csrc", src), "-o", asm], stderr=subprocess.DEVNULL)
+        fast = slow = 0
+        cur = None
+        for raw in open(asm):
+            line = raw.split(";")[0].rstrip()
+            if line and not line[0].isspace() and line.endswith(":") and line.startswith("_Z"):
+                cur = line[:-1]
+            if not cur or kernel_substr not in cur or not line.strip() or line.lstrip().startswith("."):
+                continue
+            k, _ = isa_cost.classify(line)
+            fast += k == "vfast"
+            slow += k == "vslow"
+    n = fast + slow
+    return {"static_valu_fast": fast, "static_valu_other": slow, "valu_cycles_per_instruction": round((fast * isa_cost.C_FAST + slow * isa_cost.C_SLOW) / max(n, 1), 3)}
+
+
 def main(prof_dir, out):
     fetch = mean_counter(os.path.join(prof_dir, "pmc_FETCH_SIZE"), "FETCH_SIZE")
     write = mean_counter(os.path.join(prof_dir, "pmc_WRITE_SIZE"), "WRITE_SIZE")
-    res = {"workload": {"W": 3840, "H": 2160, "frames": 32}, "units": "bytes per launch", "kernels": {}}
+    valu = mean_counter(os.path.join(prof_dir, "pmc_sq1"), "SQ_INSTS_VALU")
+    so = hashlib.sha256(open(os.path.join(ROOT, "compv_amd", "lib", "libcompv_hip.so"), "rb").read()).hexdigest()
+    res = {"workload": {"W": 3840, "H": 2160, "frames": 32}, "units": "bytes per launch", "so_sha256": so, "kernels": {}}
     for k in sorted(set(fetch) | set(write)):
         if not k.startswith("compvhip"):
             continue
@@ -37,7 +66,14 @@ def main(prof_dir, out):
         if not name.startswith("edge_dete_kernel"):   # the two edge_dete instantiations are the read / write calibration kernels
             name = name.split("<")[0]
         name = STAGE_NAMES.get(name, name)
-        res["kernels"][name] = {
+        extra = {}
+        if k in valu:
+            extra["SQ_INSTS_VALU"] = int(valu[k])
+        if name == "canny_tile_kernel":
+            extra.update(valu_mix("canny_swar_kernels.hip", "canny_swar_tile_kernel"))
+        if name == "sht_vote_kernel":
+            extra.update(valu_mix("sht_tiles_kernels.hip", "sht_vote_tiles_kernel"))
+        res["kernels"][name] = {**extra,
             "FETCH_SIZE_KiB": round(f, 1), "WRITE_SIZE_KiB": round(w, 1),
             "hbm_read_bytes": int(2 * f * 1024), "hbm_write_bytes": int(w * 1024), "hbm_bytes": int((2 * f + w) * 1024)}
     json.dump(res, open(out, "w"), indent=1, sort_keys=True)
