@@ -118,6 +118,17 @@ __global__ __launch_bounds__(kNmsThreads) void sht_nms_kernel(ShtArgs a)
 		x[5] = w.z & 0xffffu; x[6] = w.z >> 16; x[7] = w.w & 0xffffu; x[8] = w.w >> 16;
 		x[9] = (int)dn[tj];
 	};
+	// Per-row masks of this thread (rows r0 .. r0 + 7): mV = the row exists (r < R), mN = the row takes part in the NMS (1 <= r <= R - 2).
+	// The per-cell test below is straight-line code on them -- the version with `if (nmsCol && r >= 1 && ...)` per cell spent as many
+	// scalar branch / exec-mask instructions as vector ones (PMC: 754 SALU + 844 VALU per wave).
+	int mV[8], mN[8];
+#pragma unroll
+	for (int k = 0; k < 8; ++k) {
+		const int r = r0 + k;
+		mV[k] = (r < a.R) ? -1 : 0;
+		mN[k] = (r >= 1 && r <= a.R - 2) ? -1 : 0;
+		asm volatile("" : "+v"(mV[k]), "+v"(mN[k]));   // real register masks (the compiler otherwise keeps them as lane masks and selects per cell)
+	}
 	int side[3][8]; // max(x[k], x[k+1], x[k+2]) of tile columns j, j+1, j+2 (ring)
 	int mid[10], nxt[10];
 	{
@@ -138,19 +149,16 @@ __global__ __launch_bounds__(kNmsThreads) void sht_nms_kernel(ShtArgs a)
 #pragma unroll
 		for (int k = 0; k < 8; ++k) sh[k] = max(max(nxt[k], nxt[k + 1]), nxt[k + 2]);
 		const int c = c0 + j;
-		const bool nmsCol = (c >= 1 && c <= a.nmsLastCol);
-		if (c < a.T) {
+		int colN = (c >= 1 && c <= a.nmsLastCol) ? -1 : 0;   // quirk Q2: NMS covers theta columns [1, (T-1)&~3]
+		int colV = (c < a.T) ? -1 : 0;
+		asm volatile("" : "+v"(colN), "+v"(colV));
 #pragma unroll
-			for (int k = 0; k < 8; ++k) {
-				const int r = base + t * 8 + k;
-				const int val = mid[k + 1];
-				bool pass = (r < a.R) && (val > a.threshold);
-				if (nmsCol && r >= 1 && r <= a.R - 2) {
-					const int nb = max(max(sl[k], sh[k]), max(mid[k], mid[k + 2]));
-					pass = pass && (nb <= val);
-				}
-				flags[k >> 2] |= (pass ? 1u : 0u) << ((k & 3) * 8 + j);
-			}
+		for (int k = 0; k < 8; ++k) {
+			const int val = mid[k + 1] & (mV[k] & colV);                                          // 0 where there is no cell: never above the threshold
+			const int nb = max(max(sl[k], sh[k]), max(mid[k], mid[k + 2])) & (mN[k] & colN);     // 0 where no NMS applies: never above val
+			// pass = (val > threshold) && (nb <= val), from the signs of two differences (all values < 65536): no compare -> scalar mask -> select chain
+			const uint32_t p = (uint32_t)(a.threshold - val) & ~(uint32_t)(val - nb);
+			flags[k >> 2] |= (p >> (31 - ((k & 3) * 8 + j))) & (1u << ((k & 3) * 8 + j));
 		}
 #pragma unroll
 		for (int k = 0; k < 10; ++k) mid[k] = nxt[k];
