@@ -377,7 +377,7 @@ static hipError_t launch_swar(const CannyArgs& a0, int frames, bool gap, hipStre
 hipError_t launch_canny_tiles_swar(const CannyArgs& a0, int frames, bool gap, hipStream_t stream)
 {
 	// One wave per workgroup (every LDS address of the kernel is lane * k + constant), 32 rows per wave tile: 68 704 workgroups for 32 4K
-	// frames.  Measured per 32 x 4K launch (same run): 128 rows 0.232 ms, 64 rows 0.202 ms, 32 rows 0.192 ms, 16 rows 3 % below 32 -- the
+	// frames.  Measured per 32 x 4K launch (same run): 128 rows 0.232 ms, 64 rows 0.202 ms, 32 rows 0.192 ms, 16 / 24 rows the same as 32 within 1 % -- the
 	// 4-row halo costs 12.5 % more gradient rows than at 64 rows, but twice as many, shorter waves balance the SIMDs better at the end of
 	// the launch (a tile's time follows its candidate count).
 	return launch_swar<1, 32>(a0, frames, gap, stream);
