@@ -1412,17 +1412,23 @@ int compvhip_houghsht_u8(compvhip_ctx* ctx, const uint8_t* edges, size_t W, size
 
 // host linking, then cluster subdivision (kht_subdivide_kernel) and per-cluster statistics (kht_stats_kernel) on the GPU; kernels in cluster order
 static int khtBuildKernels(compvhip_ctx* ctx, KhtScratch& K, const uint8_t* edges, size_t W, size_t H, size_t S, double clusterMinDeviation, size_t clusterMinSize,
-                           std::vector<KhtKernel>& kernels, double& hmax)
+                           std::vector<KhtKernel>& kernels, double& hmax, uint8_t* scratchEdges = nullptr)
 {
 	using clk = std::chrono::steady_clock;
 	auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
 	kernels.clear(); hmax = 0.0;
 	const auto t0 = clk::now();
-	// clone the edges (the linker destroys them, :323-336), link, subdivide
-	std::vector<uint8_t> work(W * H);
-	for (size_t j = 0; j < H; ++j) memcpy(&work[j * W], edges + j * S, W);
+	// the linker destroys the edges it visits (:323-336): it works on a clone -- or in place when the caller hands over a private copy
+	// (scratchEdges: the pinned frame buffer of a plan worker, dense rows)
+	std::vector<uint8_t> work;
+	uint8_t* e = scratchEdges;
+	if (!e) {
+		work.resize(W * H);
+		for (size_t j = 0; j < H; ++j) memcpy(&work[j * W], edges + j * S, W);
+		e = work.data();
+	}
 	std::vector<KhtPos> poss; std::vector<KhtRange> strings;
-	khtLink(work.data(), W, H, W, clusterMinSize, poss, strings);
+	khtLink(e, W, H, W, clusterMinSize, poss, strings);
 	const auto t1 = clk::now();
 	K.stageMs[0] += ms(t0, t1);
 	if (strings.empty()) return COMPVHIP_OK;
@@ -1484,14 +1490,14 @@ static int khtBuildKernels(compvhip_ctx* ctx, KhtScratch& K, const uint8_t* edge
 
 // one frame, host edge map -> lines in the reference's order (the body of CompVHoughKht::process, houghkht.cxx:208-447)
 static int khtFrame(compvhip_ctx* ctx, KhtScratch& K, const uint8_t* edges, size_t W, size_t H, size_t S, const KhtAxes& ax, int threshold, int maxLines,
-                    double clusterMinDeviation, size_t clusterMinSize, double kernelMinHeight, std::vector<KhtLine>& out, double* gs)
+                    double clusterMinDeviation, size_t clusterMinSize, double kernelMinHeight, std::vector<KhtLine>& out, double* gs, uint8_t* scratchEdges = nullptr)
 {
 	using clk = std::chrono::steady_clock;
 	auto msSince = [](clk::time_point a) { return std::chrono::duration<double, std::milli>(clk::now() - a).count(); };
 	out.clear();
 	std::vector<KhtKernel> kernels;
 	double hmax = 0.0;
-	const int rck = khtBuildKernels(ctx, K, edges, W, H, S, clusterMinDeviation, clusterMinSize, kernels, hmax);
+	const int rck = khtBuildKernels(ctx, K, edges, W, H, S, clusterMinDeviation, clusterMinSize, kernels, hmax, scratchEdges);
 	if (rck) return rck;
 	if (kernels.empty()) return COMPVHIP_OK;
 	auto t3 = clk::now();
@@ -1623,7 +1629,7 @@ int compvhip_plan_houghkht(compvhip_plan* p, const uint8_t* d_edges, float rho, 
 	HIPCHK(ctx, hipSetDevice(ctx->device));
 	unsigned hw = std::thread::hardware_concurrency();
 	if (!hw) hw = 4;
-	size_t T = hostThreads > 0 ? static_cast<size_t>(hostThreads) : std::min<size_t>(16, std::max<size_t>(1, hw / 2));
+	size_t T = hostThreads > 0 ? static_cast<size_t>(hostThreads) : std::min<size_t>(32, std::max<size_t>(1, hw / 2));   // measured at 4K x 32 frames: 8 / 16 / 32 workers 1.25 / 0.77 / 0.55 ms per frame
 	T = std::min(T, F);
 	while (p->khtWorkers.size() < T) {
 		KhtScratch* k = new (std::nothrow) KhtScratch();
@@ -1661,7 +1667,8 @@ int compvhip_plan_houghkht(compvhip_plan* p, const uint8_t* d_edges, float rho, 
 			if (e == hipSuccess) e = hipStreamSynchronize(K.stream);
 			if (e != hipSuccess) { codes[t] = COMPVHIP_E_HIP; K.err = std::string("frame download: ") + hipGetErrorString(e); return; }
 			dlMs[t] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - d0).count();
-			const int r = khtFrame(ctx, K, K.hostEdges, W, H, W, ax, threshold, maxLines, clusterMinDeviation, clusterMinSize, kernelMinHeight, out, gs ? gs + f : nullptr);
+			const int r = khtFrame(ctx, K, K.hostEdges, W, H, W, ax, threshold, maxLines, clusterMinDeviation, clusterMinSize, kernelMinHeight, out, gs ? gs + f : nullptr,
+			                       K.hostEdges);   // the worker's private download: linked in place
 			if (r) { codes[t] = r; return; }
 			counts[f] = out.size();
 			if (lines) khtCopyLines(out, lines + f * cap, cap);

@@ -276,7 +276,7 @@ COMPVHIP_API int compvhip_plan_pipeline_ex(compvhip_plan* plan, const uint8_t* d
  * ({0, non-zero} bytes, e.g. the edge maps a compvhip_plan_canny / _pipeline call produced); results in HOST memory: lines[f * cap ..] /
  * counts[f] / gs[f] (gs optional; gs[f] is left untouched for a frame without surviving kernels, like the reference's m_dGS).  Synchronous.
  * The edge-linking stage is a sequential chain walk per frame and runs on the host; frames are independent, so hostThreads workers
- * (0 = min(16, hardware threads / 2)) each take frames in turn with their own HIP stream: frame download, linking, and the GPU stages of
+ * (0 = min(32, hardware threads / 2)) each take frames in turn with their own HIP stream: frame download, linking, and the GPU stages of
  * one frame overlap with those of the other workers'.  COMPVHIP_E_OUT_OF_BOUND when a frame has more than cap lines (counts[f] tells).
  * compvhip_plan_houghkht_stage_ms: the six stage clocks of the last call summed over its frames (compvhip_houghkht_stage_ms order), the wall
  * time of the call and the number of workers. */
