@@ -185,6 +185,17 @@ def so_sha256():
     return h.hexdigest()
 
 
+def src_sha256():
+    """sha256 over the sources the library is built from (compv_amd/csrc/*.{hip,hpp,cpp}, Makefile, include/compv_hip.h), names included."""
+    h = hashlib.sha256()
+    d = os.path.join(ROOT, "compv_amd", "csrc")
+    files = sorted(f for f in os.listdir(d) if f.endswith((".hip", ".hpp", ".cpp")) or f == "Makefile")
+    for f in [os.path.join(d, x) for x in files] + [os.path.join(ROOT, "include", "compv_hip.h")]:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, "rb").read())
+    return h.hexdigest()
+
+
 def committed_counters(W, H, F):
     """PMC results committed under profiles/ (rocprofv3 --pmc passes, tools/pmc_pass.sh + tools/traffic_from_pmc.py).  They are only
     valid for the library build they were collected with: the file stores that build's sha256 and a stale file is ignored."""
@@ -193,9 +204,11 @@ def committed_counters(W, H, F):
         t = json.load(open(os.path.join(ROOT, "profiles", rounds[-1], "traffic.json")))
         if t.get("workload") != {"W": W, "H": H, "frames": F}:
             return None, "profiles/%s/traffic.json is for another workload" % rounds[-1]
-        if t.get("so_sha256") != so_sha256():
-            return None, "profiles/%s/traffic.json was collected with another build of libcompv_hip.so (stale): traffic = null" % rounds[-1]
-        return t, "committed PMC pass profiles/%s/traffic.json (rocprofv3 --pmc, separate runs, same library build: sha256 %s...)" % (rounds[-1], t["so_sha256"][:12])
+        same_so, same_src = t.get("so_sha256") == so_sha256(), t.get("src_sha256") == src_sha256()
+        if not (same_so or same_src):
+            return None, "profiles/%s/traffic.json was collected with another build of libcompv_hip.so (neither the binary nor its sources match): traffic = null" % rounds[-1]
+        return t, "committed PMC pass profiles/%s/traffic.json (rocprofv3 --pmc, separate runs; %s)" % (
+            rounds[-1], ("same library binary, sha256 %s..." % t["so_sha256"][:12]) if same_so else ("same library sources, sha256 %s..." % t["src_sha256"][:12]))
     except Exception as e:
         return None, "no committed PMC pass (%s)" % e
 

@@ -57,7 +57,9 @@ def main(prof_dir, out):
     write = mean_counter(os.path.join(prof_dir, "pmc_WRITE_SIZE"), "WRITE_SIZE")
     valu = mean_counter(os.path.join(prof_dir, "pmc_sq1"), "SQ_INSTS_VALU")
     so = hashlib.sha256(open(os.path.join(ROOT, "compv_amd", "lib", "libcompv_hip.so"), "rb").read()).hexdigest()
-    res = {"workload": {"W": 3840, "H": 2160, "frames": 32}, "units": "bytes per launch", "so_sha256": so, "kernels": {}}
+    sys.path.insert(0, ROOT)
+    import bench
+    res = {"workload": {"W": 3840, "H": 2160, "frames": 32}, "units": "bytes per launch", "so_sha256": so, "src_sha256": bench.src_sha256(), "kernels": {}}
     for k in sorted(set(fetch) | set(write)):
         if not k.startswith("compvhip"):
             continue
