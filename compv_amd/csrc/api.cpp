@@ -110,6 +110,7 @@ struct compvhip_plan {
 	uint32_t* edges = nullptr; size_t edgeCap = 0; int* edgeCounts = nullptr;
 	uint16_t* acc = nullptr; size_t accFrameStride = 0;
 	uint32_t* keysA = nullptr; uint32_t* keysB = nullptr; uint32_t* valsA = nullptr; uint32_t* valsB = nullptr; size_t lineCap = 0; int* lineCounts = nullptr;
+	int2* nmsRange = nullptr;                    // [column groups of the NMS] accumulator rows the windows can reach
 	uint8_t* nmsFlags = nullptr; uint16_t* nmsOffs = nullptr; uint32_t* rowBase = nullptr; int* chunkTotals = nullptr; // NMS survivors (flag planes) and their ranks
 	void* sortTemp = nullptr; size_t sortTempBytes = 0;
 	int strengthBits = 16, keyBits = 0;
@@ -389,6 +390,25 @@ int ensureSht(compvhip_plan* p)
 				p->vtExcl[static_cast<size_t>(i) * T + t] = static_cast<uint32_t>(exLo - lo) | (static_cast<uint32_t>(exHi - lo) << 16);
 			}
 		}
+		{
+			// accumulator rows the NMS has to look at, per group of 8 theta columns (+ the column either side): the union of the tiles' windows
+			const int tiles = p->vt.tiles, Rw = p->vt.Rw, groups = sht_nms_groups(static_cast<int>(T));
+			std::vector<int2> range(static_cast<size_t>(groups));
+			for (int g = 0; g < groups; ++g) {
+				int lo = INT32_MAX, hi = INT32_MIN;
+				for (int c = 8 * g - 1; c <= 8 * g + 8; ++c) {
+					if (c < 0 || c >= static_cast<int>(T)) continue;
+					for (int i = 0; i < tiles; ++i) {
+						const int b = p->vtRowBase[static_cast<size_t>(i) * T + c];
+						lo = std::min(lo, b); hi = std::max(hi, b + Rw);
+					}
+				}
+				range[g] = make_int2(lo - 1, hi + 1);
+			}
+			dfree(ctx, p->nmsRange);
+			HIPCHK(ctx, dmalloc(ctx, &p->nmsRange, range.size()));
+			HIPCHK(ctx, hipMemcpy(p->nmsRange, range.data(), range.size() * sizeof(int2), hipMemcpyHostToDevice));
+		}
 		HIPCHK(ctx, dmalloc(ctx, &p->dExcl, p->vtExcl.size()));
 		HIPCHK(ctx, hipMemcpy(p->dExcl, p->vtExcl.data(), p->vtExcl.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
 		HIPCHK(ctx, dmalloc(ctx, &p->dKt, p->vtKt.size()));
@@ -417,6 +437,7 @@ int ensureSht(compvhip_plan* p)
 	{
 		const size_t rows = sht_nms_rows(static_cast<int>(R)), groups = static_cast<size_t>(sht_nms_groups(static_cast<int>(T)));
 		HIPCHK(ctx, dmalloc(ctx, &p->nmsFlags, rows * groups * p->frames));
+		HIPCHK(ctx, hipMemset(p->nmsFlags, 0, rows * groups * p->frames)); // the NMS kernel skips the blocks no window reaches
 		HIPCHK(ctx, dmalloc(ctx, &p->nmsOffs, rows * groups * p->frames));
 		HIPCHK(ctx, dmalloc(ctx, &p->rowBase, rows * p->frames));
 		HIPCHK(ctx, dmalloc(ctx, &p->chunkTotals, static_cast<size_t>(sht_rank_chunks(static_cast<int>(R))) * p->frames));
@@ -452,7 +473,7 @@ ShtArgs shtArgs(compvhip_plan* p, int threshold)
 	ShtArgs a;
 	a.ebits = p->ebits; a.edges = p->edges; a.edgeCounts = p->edgeCounts; a.acc = p->acc;
 	a.sinQ = p->sinQ; a.cosQ = p->cosQ; a.lineKeys = p->keysA; a.lineVals = p->valsA; a.lineCounts = p->lineCounts;
-	a.nmsFlags = p->nmsFlags; a.nmsOffs = p->nmsOffs; a.rowBase = p->rowBase; a.chunkTotals = p->chunkTotals; a.nmsGroups = sht_nms_groups(static_cast<int>(p->T)); a.nmsRows = static_cast<int>(sht_nms_rows(static_cast<int>(p->R)));
+	a.nmsRange = p->nmsRange; a.nmsFlags = p->nmsFlags; a.nmsOffs = p->nmsOffs; a.rowBase = p->rowBase; a.chunkTotals = p->chunkTotals; a.nmsGroups = sht_nms_groups(static_cast<int>(p->T)); a.nmsRows = static_cast<int>(sht_nms_rows(static_cast<int>(p->R)));
 	a.bitsFrameStride = p->bitsFrameStride; a.edgeCap = p->edgeCap; a.accFrameStride = p->accFrameStride; a.lineCap = p->lineCap;
 	a.W = static_cast<int>(p->W); a.H = static_cast<int>(p->H); a.wb = p->wb;
 	a.R = static_cast<int>(p->R); a.T = static_cast<int>(p->T); a.accPitch = p->accPitch; a.barrier = static_cast<int>(p->W + p->H);
@@ -709,7 +730,7 @@ void compvhip_plan_destroy(compvhip_plan* p)
 	dfree(ctx, p->dKt); dfree(ctx, p->dRowBase); dfree(ctx, p->dExcl); dfree(ctx, p->partial);
 	dfree(ctx, p->sinQ); dfree(ctx, p->cosQ); dfree(ctx, p->edges); dfree(ctx, p->acc);
 	dfree(ctx, p->keysA); dfree(ctx, p->keysB); dfree(ctx, p->valsA); dfree(ctx, p->valsB); dfree(ctx, p->nmsFlags); dfree(ctx, p->nmsOffs); dfree(ctx, p->rowBase); dfree(ctx, p->chunkTotals);
-	dfree(ctx, p->sortTemp);
+	dfree(ctx, p->nmsRange); dfree(ctx, p->sortTemp);
 	delete p;
 }
 

@@ -109,6 +109,7 @@ struct ShtArgs {
 	uint16_t* nmsOffs;        // [frames][nmsGroups][nmsRows] survivors of the row in the column groups before this one
 	uint32_t* rowBase;        // [frames][nmsRows] survivors in the rows above, inside the row's chunk of 1024 rows
 	int* chunkTotals;         // [frames][chunks] survivors per chunk
+	const int2* nmsRange;     // [nmsGroups] accumulator rows [x, y) the windows of the group's columns (+ one either side) can reach, widened by one row
 	int nmsGroups, nmsRows;
 	int* lineCounts;          // per frame
 	size_t bitsFrameStride, edgeCap, accFrameStride, lineCap;

@@ -85,6 +85,10 @@ __global__ __launch_bounds__(kNmsThreads) void sht_nms_kernel(ShtArgs a)
 	const int c0 = blockIdx.y * kNmsCols;
 	const int base = blockIdx.x * kNmsRows;
 	const int t = threadIdx.x;
+	// Two thirds of the accumulator's cells lie outside every tile's rho window of their theta (no pixel of the image maps there): they are
+	// never written, stay zero, and their flag bytes (zeroed when the plan was made) are never written either.
+	const int2 reach = a.nmsRange[blockIdx.y];
+	if (base >= reach.y || base + kNmsRows <= reach.x) return; // uniform
 	const uint16_t* __restrict__ acc = a.acc + (size_t)frame * a.accFrameStride;
 	const size_t p = a.accPitch;
 	const int r0 = base + t * 8;

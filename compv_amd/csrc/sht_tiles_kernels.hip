@@ -203,8 +203,8 @@ __global__ __launch_bounds__(kVtThreads) void sht_vote_tiles_kernel(ShtArgs a, S
 	__syncthreads();
 
 	// flush, theta-major: lane = theta reads 8 consecutive window rows of its own column (bank = lane: conflict-free) and writes them
-	// as one 16-byte store -- straight into the accumulator where this tile's window is the only one that covers the rows (80 % of the
-	// cells at 4K), into partial[frame][tile][theta][w .. w + 7] where windows overlap (the reduce kernel adds those)
+	// as one 16-byte store -- straight into the accumulator where this tile's window is the only one that covers the rows (4 % of the
+	// window cells at 4K: tiles along a line's direction share its rows), into partial[frame][tile][theta][w .. w + 7] where windows overlap (the reduce kernel adds those)
 	uint16_t* __restrict__ part = v.partial + (((size_t)unit * v.Tpad) + (size_t)g * 64 + lane) * v.rwPitch;
 	const int sh = (lane & 32) ? 16 : 0;
 	const uint32_t ex = v.excl[(size_t)tile * a.T + tt];
@@ -232,8 +232,8 @@ __global__ __launch_bounds__(kVtThreads) void sht_vote_tiles_kernel(ShtArgs a, S
 // ---------------------------------------------------------------------------------------------------------------
 // reduce: acc[frame][theta][r] = sum over the tiles whose window of that theta covers row r.  For a fixed theta the window rows of
 // a tile are contiguous in r: every read and the write are coalesced along r.  One thread = 8 consecutive rows (one 16-byte store), one
-// workgroup = 2048 rows of one theta; a tile whose window misses the workgroup's rows is skipped by a scalar test (a row is covered
-// by ~1.2 of the 12 tiles of a 4K frame).
+// workgroup = 2048 rows of one theta; a tile whose window misses the workgroup's rows is skipped by a scalar test (at 4K 67 % of the
+// accumulator's cells are covered by no tile, 5 % by one, the rest by 3.7 of the 12 on average).
 // ---------------------------------------------------------------------------------------------------------------
 constexpr int kRdThreads = 256;
 constexpr int kRdRows = 8;
