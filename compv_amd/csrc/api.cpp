@@ -110,6 +110,7 @@ struct compvhip_plan {
 	uint32_t* edges = nullptr; size_t edgeCap = 0; int* edgeCounts = nullptr;
 	uint16_t* acc = nullptr; size_t accFrameStride = 0;
 	uint32_t* keysA = nullptr; uint32_t* keysB = nullptr; uint32_t* valsA = nullptr; uint32_t* valsB = nullptr; size_t lineCap = 0; int* lineCounts = nullptr;
+	int2* reach = nullptr;                       // [T] accumulator rows the windows of a theta cover
 	int2* nmsRange = nullptr;                    // [column groups of the NMS] accumulator rows the windows can reach
 	uint8_t* nmsFlags = nullptr; uint16_t* nmsOffs = nullptr; uint32_t* rowBase = nullptr; int* chunkTotals = nullptr; // NMS survivors (flag planes) and their ranks
 	void* sortTemp = nullptr; size_t sortTempBytes = 0;
@@ -118,8 +119,7 @@ struct compvhip_plan {
 	bool voteTiles = false;                      // the tile grid exists
 	ShtTileArgs vt = {};                         // geometry + device tables
 	std::vector<int32_t> vtKt, vtRowBase;        // host copies of the [tiles][T] tables
-	std::vector<uint32_t> vtExcl;                // [tiles][T] window rows [lo, hi) (lo | hi << 16) no other tile's window covers
-	int32_t* dKt = nullptr; int32_t* dRowBase = nullptr; uint32_t* dExcl = nullptr; uint16_t* partial = nullptr; int* tileCounts = nullptr;
+	int32_t* dKt = nullptr; int32_t* dRowBase = nullptr; uint8_t* partLo = nullptr; uint8_t* partHi = nullptr; uint8_t* colFlag = nullptr; int* tileCounts = nullptr;
 	// batched KHT (compvhip_plan_houghkht): one scratch set + stream per worker thread, stage clocks of the last call
 	std::vector<KhtScratch*> khtWorkers;
 	double khtStageMs[6] = {}; double khtWallMs = 0.0; int khtThreads = 0;
@@ -264,17 +264,17 @@ bool planVoteTiles(size_t W, size_t H, const std::vector<int32_t>& sinQ, const s
 					if (k == 0 || q < qmin) qmin = q;
 					if (k == 0 || q > qmax) qmax = q;
 				}
-				// the window starts on a multiple of 8 accumulator rows (d extra rows at its top): the reduce kernel adds whole 16-byte groups
+				// the window starts on a multiple of 16 accumulator rows (d extra rows at its top): the reduce kernel adds whole 16-byte groups of count bytes
 				const long long base = barrier - Chi - qmax;
-				const long long d = ((base % 8) + 8) % 8;
+				const long long d = ((base % 16) + 16) % 16;
 				worst = std::max(worst, qmax - qmin + 1 + d);
 				kt[(static_cast<size_t>(ty) * nx + tx) * T + t] = static_cast<int32_t>((qmax + d) * 65536 + 65535 - Clo);
 				rowBase[(static_cast<size_t>(ty) * nx + tx) * T + t] = static_cast<int32_t>(base - d);
 			}
 		}
-		if (alignUp(static_cast<size_t>(worst), 8) <= static_cast<size_t>(kShtMaxWindow) && TW <= 1280 && static_cast<long long>(TW - 1) * 65535 + static_cast<long long>(TH - 1) * 65535 < 0x7f000000LL) {
+		if (alignUp(static_cast<size_t>(worst), 16) <= static_cast<size_t>(kShtMaxWindow) && TW <= 1280 && static_cast<long long>(TW - 1) * 65535 + static_cast<long long>(TH - 1) * 65535 < 0x7f000000LL) {
 			v.nx = nx; v.ny = ny; v.TW = TW; v.TH = TH; v.tiles = tiles;
-			v.Rw = static_cast<int>(alignUp(static_cast<size_t>(worst), 8)); v.rwPitch = v.Rw;
+			v.Rw = static_cast<int>(alignUp(static_cast<size_t>(worst), 16)); v.rwPitch = v.Rw;
 			v.groups = static_cast<int>((T + 63) / 64); v.Tpad = v.groups * 64;
 			v.tileCap = static_cast<size_t>(TW) * TH;
 			return true;
@@ -369,27 +369,7 @@ int ensureSht(compvhip_plan* p)
 	}
 	{
 		if (p->vt.tiles <= 0 || p->vtKt.size() != static_cast<size_t>(p->vt.tiles) * T) return fail(ctx, COMPVHIP_E_INVALID_STATE, "vote tiles were not planned");
-		dfree(ctx, p->dKt); dfree(ctx, p->dRowBase); dfree(ctx, p->dExcl); dfree(ctx, p->partial);
-		{
-			// Exclusive part of every window: the windows of one theta all have Rw rows, so what the other tiles' windows leave of a window is
-			// one interval [lo, hi) (window rows, multiples of 8).  The vote kernel stores those rows straight into the accumulator; only the
-			// rows two or more windows share go through the partial windows and the reduce kernel.
-			const int tiles = p->vt.tiles, Rw = p->vt.Rw;
-			p->vtExcl.assign(static_cast<size_t>(tiles) * T, 0u);
-			for (size_t t = 0; t < T; ++t) for (int i = 0; i < tiles; ++i) {
-				const int lo = p->vtRowBase[static_cast<size_t>(i) * T + t];
-				int exLo = lo, exHi = lo + Rw;
-				for (int u = 0; u < tiles; ++u) {
-					if (u == i) continue;
-					const int blo = p->vtRowBase[static_cast<size_t>(u) * T + t], bhi = blo + Rw;
-					if (bhi <= lo || blo >= lo + Rw) continue;       // disjoint
-					if (blo <= lo) exLo = std::max(exLo, bhi);       // covers a prefix (everything when blo == lo)
-					else exHi = std::min(exHi, blo);                 // covers a suffix
-				}
-				if (exHi < exLo) exHi = exLo;
-				p->vtExcl[static_cast<size_t>(i) * T + t] = static_cast<uint32_t>(exLo - lo) | (static_cast<uint32_t>(exHi - lo) << 16);
-			}
-		}
+		dfree(ctx, p->dKt); dfree(ctx, p->dRowBase); dfree(ctx, p->partLo); dfree(ctx, p->partHi); dfree(ctx, p->colFlag);
 		{
 			// accumulator rows the NMS has to look at, per group of 8 theta columns (+ the column either side): the union of the tiles' windows
 			const int tiles = p->vt.tiles, Rw = p->vt.Rw, groups = sht_nms_groups(static_cast<int>(T));
@@ -405,18 +385,35 @@ int ensureSht(compvhip_plan* p)
 				}
 				range[g] = make_int2(lo - 1, hi + 1);
 			}
+			std::vector<int2> reach(T);
+			for (size_t t = 0; t < T; ++t) {
+				int lo = INT32_MAX, hi = INT32_MIN;
+				for (int i = 0; i < tiles; ++i) {
+					const int b = p->vtRowBase[static_cast<size_t>(i) * T + t];
+					lo = std::min(lo, b); hi = std::max(hi, b + Rw);
+				}
+				reach[t] = make_int2(lo, hi);
+			}
+			dfree(ctx, p->reach);
+			HIPCHK(ctx, dmalloc(ctx, &p->reach, reach.size()));
+			HIPCHK(ctx, hipMemcpy(p->reach, reach.data(), reach.size() * sizeof(int2), hipMemcpyHostToDevice));
 			dfree(ctx, p->nmsRange);
 			HIPCHK(ctx, dmalloc(ctx, &p->nmsRange, range.size()));
 			HIPCHK(ctx, hipMemcpy(p->nmsRange, range.data(), range.size() * sizeof(int2), hipMemcpyHostToDevice));
 		}
-		HIPCHK(ctx, dmalloc(ctx, &p->dExcl, p->vtExcl.size()));
-		HIPCHK(ctx, hipMemcpy(p->dExcl, p->vtExcl.data(), p->vtExcl.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
 		HIPCHK(ctx, dmalloc(ctx, &p->dKt, p->vtKt.size()));
 		HIPCHK(ctx, dmalloc(ctx, &p->dRowBase, p->vtRowBase.size()));
 		HIPCHK(ctx, hipMemcpy(p->dKt, p->vtKt.data(), p->vtKt.size() * sizeof(int32_t), hipMemcpyHostToDevice));
 		HIPCHK(ctx, hipMemcpy(p->dRowBase, p->vtRowBase.data(), p->vtRowBase.size() * sizeof(int32_t), hipMemcpyHostToDevice));
-		HIPCHK(ctx, dmalloc(ctx, &p->partial, p->frames * p->vt.tiles * static_cast<size_t>(p->vt.Tpad) * p->vt.rwPitch));
-		p->vt.kt = p->dKt; p->vt.rowBase = p->dRowBase; p->vt.excl = p->dExcl; p->vt.partial = p->partial; p->vt.tileCounts = p->tileCounts;
+		{
+			// partial windows: one byte plane for the low bytes of the counts, one for the high bytes (only written / read for the few columns
+			// that hold a count >= 256: a tile's share of a strong line), one flag byte per column
+			const size_t cols = p->frames * p->vt.tiles * static_cast<size_t>(p->vt.Tpad);
+			HIPCHK(ctx, dmalloc(ctx, &p->partLo, cols * p->vt.rwPitch));
+			HIPCHK(ctx, dmalloc(ctx, &p->partHi, cols * p->vt.rwPitch));
+			HIPCHK(ctx, dmalloc(ctx, &p->colFlag, cols));
+		}
+		p->vt.kt = p->dKt; p->vt.rowBase = p->dRowBase; p->vt.partLo = p->partLo; p->vt.partHi = p->partHi; p->vt.colFlag = p->colFlag; p->vt.reach = p->reach; p->vt.tileCounts = p->tileCounts;
 		p->edgeCap = static_cast<size_t>(p->vt.tiles) * p->vt.tileCap; // per frame: one list of TW * TH entries per tile
 	}
 	HIPCHK(ctx, dmalloc(ctx, &p->edges, p->edgeCap * p->frames));
@@ -727,10 +724,10 @@ void compvhip_plan_destroy(compvhip_plan* p)
 	for (KhtScratch* k : p->khtWorkers) { khtScratchFree(ctx, *k); delete k; }
 	p->khtWorkers.clear();
 	dfree(ctx, p->cosT); dfree(ctx, p->invSinT);
-	dfree(ctx, p->dKt); dfree(ctx, p->dRowBase); dfree(ctx, p->dExcl); dfree(ctx, p->partial);
+	dfree(ctx, p->dKt); dfree(ctx, p->dRowBase); dfree(ctx, p->partLo); dfree(ctx, p->partHi); dfree(ctx, p->colFlag);
 	dfree(ctx, p->sinQ); dfree(ctx, p->cosQ); dfree(ctx, p->edges); dfree(ctx, p->acc);
 	dfree(ctx, p->keysA); dfree(ctx, p->keysB); dfree(ctx, p->valsA); dfree(ctx, p->valsB); dfree(ctx, p->nmsFlags); dfree(ctx, p->nmsOffs); dfree(ctx, p->rowBase); dfree(ctx, p->chunkTotals);
-	dfree(ctx, p->nmsRange); dfree(ctx, p->sortTemp);
+	dfree(ctx, p->nmsRange); dfree(ctx, p->reach); dfree(ctx, p->sortTemp);
 	delete p;
 }
 

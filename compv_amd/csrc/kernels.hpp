@@ -123,11 +123,13 @@ struct ShtArgs {
 struct ShtTileArgs {
 	const int32_t* kt;        // [tiles][T]  window constant K of (tile, theta): window row = (K - lx cosQ - ly sinQ) >> 16
 	const int32_t* rowBase;   // [tiles][T]  accumulator row of window row 0
-	const uint32_t* excl;     // [tiles][T]  window rows [lo, hi) (lo | hi << 16, multiples of 8) that no other tile's window of this theta covers
-	uint16_t* partial;        // [frames][tiles][Tpad][rwPitch]  theta-major partial accumulators (one window per tile and theta)
+	uint8_t* partLo;          // [frames][tiles][Tpad][rwPitch]  theta-major partial accumulators (one window per tile and theta): low bytes of the counts
+	uint8_t* partHi;          // same shape: high bytes, valid only for the (tile, theta) columns whose colFlag is set (some count of the column >= 256)
+	uint8_t* colFlag;         // [frames][tiles][Tpad]  written by every vote workgroup for its 64 columns
+	const int2* reach;        // [T]  accumulator rows [x, y) the tiles' windows of a theta cover (their union's hull)
 	int* tileCounts;          // [frames][tiles] edges per tile
 	int nx, ny, TW, TH, tiles;  // tile grid; TW % 32 == 0
-	int Rw, rwPitch;          // window rows (<= 1264), pitch of a partial row (multiple of 8)
+	int Rw, rwPitch;          // window rows (<= 1264), pitch of a partial row (multiples of 16)
 	int Tpad, groups;         // theta bins padded to groups * 64
 	size_t tileCap;           // edge-list entries per tile (TW * TH)
 };

@@ -12,8 +12,9 @@
 // lane l always hits bank l & 31: conflict-free by construction, no two lanes of an instruction ever share an address, and the
 // edge coordinates are wave-uniform (scalar loads, scalar operands).  64 full rho columns do not fit the LDS, so the edges are
 // binned into image tiles: a tile of diagonal d only reaches a window of <= d + 1 rho rows per theta (<= 1264 rows = 158 KB).
-// A workgroup = (frame, tile, 64 theta bins); it writes its window theta-major to a partial accumulator and a small reduce kernel
-// adds the tiles' windows into the accumulator (each partial cell is written once and read once: 2 x 5.5 MB per 4K frame).
+// A workgroup = (frame, tile, 64 theta bins); it writes its window theta-major to a partial accumulator -- a plane of count bytes,
+// plus the high bytes of the few columns that hold a count >= 256 -- and a small reduce kernel adds the tiles' windows into the
+// accumulator (each partial cell is written once and read once: 2 x 2.8 MB per 4K frame).
 // This also removes the W + H <= 20 479 limit of the first generation: the LDS only ever holds one tile's window.
 //
 // Exactness: rho = (x cosQ + y sinQ) >> 16 with x = x0 + lx, y = y0 + ly.  With C = x0 cosQ + y0 sinQ = Chi * 65536 + Clo
@@ -128,6 +129,7 @@ constexpr int kVtUnroll = 32;   // edges per block of scalar loads
 __global__ __launch_bounds__(kVtThreads) void sht_vote_tiles_kernel(ShtArgs a, ShtTileArgs v)
 {
 	extern __shared__ __attribute__((aligned(16))) uint32_t hist[]; // [Rw][32]: dword l of row w = counters of theta l (low half) and 32 + l (high half)
+	// (the voting code addresses the histogram from LDS offset 0: no static LDS objects in this kernel)
 	// XCD-aware order (workgroup b runs on XCD b % 8): the groups of one (frame, tile) unit run on the same XCD, so the unit's edge list
 	// is fetched from HBM once and re-read from that XCD's L2 by the other groups.
 	const int units = a.frames * v.tiles;
@@ -141,6 +143,8 @@ __global__ __launch_bounds__(kVtThreads) void sht_vote_tiles_kernel(ShtArgs a, S
 
 	const int n = min(v.tileCounts[unit], (int)v.tileCap);
 	const int words = v.Rw * 32;
+	uint32_t* const s_any = hist + words;   // two dwords behind the histogram: lane mask of the columns that hold a count >= 256
+	if (tid < 2) s_any[tid] = 0u;
 	for (int i = tid * 4; i < words; i += kVtThreads * 4) *reinterpret_cast<uint4*>(&hist[i]) = make_uint4(0, 0, 0, 0);
 
 	const int t = g * 64 + lane;
@@ -202,67 +206,110 @@ __global__ __launch_bounds__(kVtThreads) void sht_vote_tiles_kernel(ShtArgs a, S
 	__builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): the asm ds_add are invisible to the compiler's counters
 	__syncthreads();
 
-	// flush, theta-major: lane = theta reads 8 consecutive window rows of its own column (bank = lane: conflict-free) and writes them
-	// as one 16-byte store -- straight into the accumulator where this tile's window is the only one that covers the rows (4 % of the
-	// window cells at 4K: tiles along a line's direction share its rows), into partial[frame][tile][theta][w .. w + 7] where windows overlap (the reduce kernel adds those)
-	uint16_t* __restrict__ part = v.partial + (((size_t)unit * v.Tpad) + (size_t)g * 64 + lane) * v.rwPitch;
-	const int sh = (lane & 32) ? 16 : 0;
-	const uint32_t ex = v.excl[(size_t)tile * a.T + tt];
-	const int exLo = (t < a.T) ? (int)(ex & 0xffffu) : 0, exHi = (t < a.T) ? (int)(ex >> 16) : 0;   // a theta past T has no accumulator column
-	const int rb = v.rowBase[(size_t)tile * a.T + tt];
-	uint16_t* __restrict__ accCol = a.acc + (size_t)frame * a.accFrameStride + (size_t)tt * a.accPitch + rb;
-	// (a wave writes 64 consecutive rows = one whole 128-byte line per theta back to back, so the L2 merges the eight 16-byte pieces
-	// before the line is evicted: 301 MB of HBM writes per launch for 179 MB of partials when the pieces came from eight different waves)
-	for (int wb = wave * 64; wb < v.Rw; wb += (kVtThreads / 64) * 64)
-	for (int w0 = wb; w0 < min(wb + 64, v.Rw); w0 += 8) {
-		uint32_t c[8];
+	// flush, theta-major, into the tile's partial window partLo[frame][tile][theta][w]: lane = theta reads 16 consecutive window rows of its own
+	// column (bank = lane: conflict-free) and stores the LOW BYTES of the 16 counts as one 16-byte store.  Counts of 256 and more are rare (a
+	// tile's share of a strong line: 0.03 % of the window cells of the benchmark frames, in 2 - 5 of a tile's 180 columns): the columns that
+	// hold one are flagged, and a second pass stores the high bytes of those columns only.  The reduce kernel adds the byte planes back together.
+	// Round 3 stored u16 counts (167 MB written + 172 MB read back per 32 x 4K launch; 96 % of the window cells are shared by 3.7 tiles on
+	// average, so they do have to make the round trip -- as bytes now).
+	// (a wave writes 128 consecutive rows = one whole 128-byte line per theta back to back, so that the L2 merges the eight 16-byte pieces
+	// before the line is evicted)
+	const size_t column = ((size_t)unit * v.Tpad) + (size_t)g * 64 + lane;
+	uint8_t* __restrict__ partLo = v.partLo + column * v.rwPitch;
+	uint8_t* __restrict__ partHi = v.partHi + column * v.rwPitch;
+	// two counter dwords -> (lo0, lo1, hi0, hi1); lanes 32..63 own the high halves
+	const uint32_t sel1 = (lane & 32) ? 0x07030602u : 0x05010400u;
+	typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+	auto bytes16 = [&](int w0, u32x4& lo, u32x4& hi) {   // Rw is a multiple of 16
+		uint32_t h[16];
 #pragma unroll
-		for (int j = 0; j < 8; ++j) c[j] = (hist[(w0 + j) * 32 + (lane & 31)] >> sh) & 0xffffu; // Rw is a multiple of 8
-		typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-		u32x4 o;
-		o.x = c[0] | (c[1] << 16); o.y = c[2] | (c[3] << 16); o.z = c[4] | (c[5] << 16); o.w = c[6] | (c[7] << 16);
+		for (int j = 0; j < 16; ++j) h[j] = hist[(w0 + j) * 32 + (lane & 31)];
+#pragma unroll
+		for (int q = 0; q < 4; ++q) {
+			const uint32_t p01 = __builtin_amdgcn_perm(h[4 * q + 1], h[4 * q], sel1), p23 = __builtin_amdgcn_perm(h[4 * q + 3], h[4 * q + 2], sel1);
+			lo[q] = __builtin_amdgcn_perm(p23, p01, 0x05040100u);
+			hi[q] = __builtin_amdgcn_perm(p23, p01, 0x07060302u);
+		}
+	};
+	uint32_t any = 0u;
+	for (int wb = wave * 128; wb < v.Rw; wb += (kVtThreads / 64) * 128)
+	for (int w0 = wb; w0 < min(wb + 128, v.Rw); w0 += 16) {
+		u32x4 lo, hi;
+		bytes16(w0, lo, hi);
+		any |= hi.x | hi.y | hi.z | hi.w;
 		// (one 16-byte store, spelled out: the loop vectoriser otherwise splits it into four dword stores, 4x the store instructions)
 		// (tiles at the image border are not clipped: part of their windows lies outside the accumulator's rows and never receives a vote)
-		const bool direct = (w0 >= exLo) && (w0 < exHi) && (rb + w0 >= 0) && (rb + w0 + 8 <= a.accPitch);
-		uint16_t* const dst = direct ? accCol + w0 : part + w0;
-		asm volatile("global_store_dwordx4 %0, %1, off" : : "v"(dst), "v"(o) : "memory");
+		uint8_t* const dst = partLo + w0;
+		asm volatile("global_store_dwordx4 %0, %1, off" : : "v"(dst), "v"(lo) : "memory");
+	}
+	const uint64_t mine = __ballot(any != 0u);
+	if (lane == 0 && mine) { atomicOr(&s_any[0], (uint32_t)mine); atomicOr(&s_any[1], (uint32_t)(mine >> 32)); }
+	__syncthreads();
+	const uint32_t m0 = s_any[0], m1 = s_any[1];
+	const bool flagged = (((lane & 32) ? m1 : m0) >> (lane & 31)) & 1u;
+	if (wave == 0) v.colFlag[column] = flagged ? 1 : 0;
+	if ((m0 | m1) == 0u) return; // uniform
+	if (flagged) {
+		for (int wb = wave * 128; wb < v.Rw; wb += (kVtThreads / 64) * 128)
+		for (int w0 = wb; w0 < min(wb + 128, v.Rw); w0 += 16) {
+			u32x4 lo, hi;
+			bytes16(w0, lo, hi);
+			uint8_t* const dst = partHi + w0;
+			asm volatile("global_store_dwordx4 %0, %1, off" : : "v"(dst), "v"(hi) : "memory");
+		}
 	}
 }
 
 // ---------------------------------------------------------------------------------------------------------------
 // reduce: acc[frame][theta][r] = sum over the tiles whose window of that theta covers row r.  For a fixed theta the window rows of
-// a tile are contiguous in r: every read and the write are coalesced along r.  One thread = 8 consecutive rows (one 16-byte store), one
-// workgroup = 2048 rows of one theta; a tile whose window misses the workgroup's rows is skipped by a scalar test (at 4K 67 % of the
-// accumulator's cells are covered by no tile, 5 % by one, the rest by 3.7 of the 12 on average).
+// a tile are contiguous in r: every read and the write are coalesced along r.  One thread = 16 consecutive rows (16 count bytes per
+// window, two 16-byte stores), one workgroup = 1024 rows of one theta (workgroups whose rows no window of the theta reaches return at once); a tile whose window misses the thread's rows is skipped (at 4K
+// 67 % of the accumulator's cells are covered by no tile -- they are never written and stay zero --, 5 % by one, the rest by 3.7 of the
+// 12 on average).  The byte planes are added two cells per 32-bit lane (even bytes / odd bytes of a dword), the high-byte plane only for
+// the flagged columns.
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int kRdThreads = 256;
-constexpr int kRdRows = 8;
+constexpr int kRdThreads = 64;
+constexpr int kRdRows = 16;
 
 __global__ __launch_bounds__(kRdThreads) void sht_reduce_tiles_kernel(ShtArgs a, ShtTileArgs v)
 {
 	const int frame = blockIdx.z, theta = blockIdx.y;
-	const int rb0 = blockIdx.x * (kRdThreads * kRdRows);
-	const int r0 = rb0 + threadIdx.x * kRdRows;
-	const uint16_t* __restrict__ part = v.partial + ((size_t)frame * v.tiles * v.Tpad + theta) * v.rwPitch;
-	// Rows covered by exactly one window were stored by that tile's vote workgroup already, rows no window covers never receive a vote
-	// and stay zero for ever: only the rows two or more windows share are summed here.
+	const int2 reach = v.reach[theta];
+	if ((int)(blockIdx.x * kRdThreads * kRdRows) >= reach.y || (int)((blockIdx.x + 1) * kRdThreads * kRdRows) <= reach.x) return;   // uniform: no window of this theta comes near
+	const int r0 = (blockIdx.x * kRdThreads + threadIdx.x) * kRdRows;   // a multiple of 16, like every window start and Rw (planVoteTiles)
+	if (r0 >= a.accPitch) return;                                          // accPitch is a multiple of 64
+	uint32_t E[4] = { 0, 0, 0, 0 }, O[4] = { 0, 0, 0, 0 };   // per dword d of the 16 bytes: cells 4d, 4d + 2 (halves of E[d]) and 4d + 1, 4d + 3 (O[d])
 	int covers = 0;
-	for (int tile = 0; tile < v.tiles; ++tile) {
-		const int base = v.rowBase[(size_t)tile * a.T + theta]; // a multiple of 8 (planVoteTiles), like r0 and Rw
-		const int w0 = r0 - base;
-		covers += (w0 >= 0 && w0 < v.Rw) ? 1 : 0;
-	}
-	if (covers < 2 || r0 >= a.accPitch) return;
-	uint4 sum = make_uint4(0, 0, 0, 0); // 8 u16 cells; a cell never exceeds 2 max(W, H) < 65536: the packed halves cannot carry
 	for (int tile = 0; tile < v.tiles; ++tile) {
 		const int base = v.rowBase[(size_t)tile * a.T + theta];
 		const int w0 = r0 - base;
-		if (w0 >= 0 && w0 < v.Rw) {
-			const uint4 c = *reinterpret_cast<const uint4*>(part + (size_t)tile * v.Tpad * v.rwPitch + w0);
-			sum.x += c.x; sum.y += c.y; sum.z += c.z; sum.w += c.w;
+		if (w0 < 0 || w0 >= v.Rw) continue;
+		++covers;
+		const size_t column = ((size_t)frame * v.tiles + tile) * v.Tpad + theta;
+		const uint4 c = *reinterpret_cast<const uint4*>(v.partLo + column * v.rwPitch + w0);
+		E[0] += c.x & 0x00ff00ffu; O[0] += (c.x >> 8) & 0x00ff00ffu;
+		E[1] += c.y & 0x00ff00ffu; O[1] += (c.y >> 8) & 0x00ff00ffu;
+		E[2] += c.z & 0x00ff00ffu; O[2] += (c.z >> 8) & 0x00ff00ffu;
+		E[3] += c.w & 0x00ff00ffu; O[3] += (c.w >> 8) & 0x00ff00ffu;
+		if (v.colFlag[column]) {   // uniform in the workgroup (one theta)
+			const uint4 h = *reinterpret_cast<const uint4*>(v.partHi + column * v.rwPitch + w0);
+			// a cell never exceeds 2 max(W, H) < 65536: the packed halves cannot carry
+			E[0] += (h.x & 0x00ff00ffu) << 8; O[0] += h.x & 0xff00ff00u;
+			E[1] += (h.y & 0x00ff00ffu) << 8; O[1] += h.y & 0xff00ff00u;
+			E[2] += (h.z & 0x00ff00ffu) << 8; O[2] += h.z & 0xff00ff00u;
+			E[3] += (h.w & 0x00ff00ffu) << 8; O[3] += h.w & 0xff00ff00u;
 		}
 	}
-	*reinterpret_cast<uint4*>(a.acc + (size_t)frame * a.accFrameStride + (size_t)theta * a.accPitch + r0) = sum;
+	if (!covers) return;
+	uint32_t o[8];
+#pragma unroll
+	for (int d = 0; d < 4; ++d) {
+		o[2 * d] = (E[d] & 0xffffu) | (O[d] << 16);
+		o[2 * d + 1] = (E[d] >> 16) | (O[d] & 0xffff0000u);
+	}
+	uint4* dst = reinterpret_cast<uint4*>(a.acc + (size_t)frame * a.accFrameStride + (size_t)theta * a.accPitch + r0);
+	dst[0] = make_uint4(o[0], o[1], o[2], o[3]);
+	dst[1] = make_uint4(o[4], o[5], o[6], o[7]);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -274,7 +321,7 @@ hipError_t launch_sht_compact_tiles(const ShtArgs& a, const ShtTileArgs& v, int 
 	return hipGetLastError();
 }
 
-size_t sht_vote_tiles_lds_bytes(int Rw) { return (size_t)Rw * 128; }
+size_t sht_vote_tiles_lds_bytes(int Rw) { return (size_t)Rw * 128 + 16; }   // histogram + the column flags of the flush
 
 hipError_t launch_sht_vote_tiles(const ShtArgs& a, const ShtTileArgs& v, int frames, hipStream_t stream)
 {

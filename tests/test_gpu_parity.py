@@ -253,6 +253,27 @@ def test_houghsht_empty_and_full_maps(hip_ctx, oracle):
     assert _lines_tuple(lines) == _orc_tuple(oracle.sht_lines_from_acc_reference_order(acc_exp, W, H, 1.0, 50))
 
 
+def test_houghsht_counts_above_255_in_several_tiles(hip_ctx, oracle):
+    """The partial windows of the voting tiles travel as byte planes: low bytes always, high bytes only for the (tile, theta) columns
+    that hold a count of 256 or more.  A nearly full 1600x1300 map spans several tiles and puts counts of up to ~1600 (high bytes up to
+    6) into many columns of every tile, next to columns that stay below 256; a sparse call afterwards must not see stale high bytes."""
+    W, H = 1600, 1300
+    rng = np.random.default_rng(11)
+    full = np.full((H, W), 0xff, np.uint8)
+    full[rng.random((H, W)) < 0.02] = 0
+    full[:, 700:760] = 0                                      # a gap: some columns of some tiles stay small
+    acc_exp = oracle.sht_acc(full, 1.0)
+    assert acc_exp.max() > 1500
+    lines, acc = hip_ctx.houghsht(full, 1.0, 1200, want_acc=True)
+    assert (acc == acc_exp).all(), int((acc != acc_exp).sum())
+    assert _lines_tuple(lines) == _orc_tuple(oracle.sht_lines_from_acc_reference_order(acc_exp, W, H, 1.0, 1200))
+    sparse = (rng.random((H, W)) < 0.01).astype(np.uint8)
+    acc_exp = oracle.sht_acc(sparse, 1.0)
+    lines, acc = hip_ctx.houghsht(sparse, 1.0, 40, want_acc=True)
+    assert (acc == acc_exp).all(), int((acc != acc_exp).sum())
+    assert _lines_tuple(lines) == _orc_tuple(oracle.sht_lines_from_acc_reference_order(acc_exp, W, H, 1.0, 40))
+
+
 def test_houghsht_error_behaviour(hip_ctx):
     from compv_amd import capi
     e = np.zeros((32, 32), np.uint8)
