@@ -88,7 +88,7 @@ struct compvhip_plan {
 	int tilesX = 0, tilesY = 0, wb = 0;
 	size_t bitsFrameStride = 0;
 	uint32_t* ebits = nullptr; uint32_t* ubits = nullptr;
-	int* counters = nullptr;  // ONE device allocation zeroed by ONE memset per step: [edgeCounts frames][lineCounts frames][tileCounts frames*tiles][flags kMaxRounds]
+	int* counters = nullptr;  // ONE device allocation zeroed by ONE memset per step: [edgeCounts frames][lineCounts frames][tileCounts frames*tiles][blockCounts frames*lineBlocks][flags kMaxRounds]
 	size_t nCounts = 0;       // ints in front of the flags
 	int* flags = nullptr; int* hFlags = nullptr; // device (inside counters) / pinned host (kAsyncDepth + 1 slots)
 	int roundsUsed = 0;
@@ -112,7 +112,8 @@ struct compvhip_plan {
 	uint32_t* keysA = nullptr; uint32_t* keysB = nullptr; uint32_t* valsA = nullptr; uint32_t* valsB = nullptr; size_t lineCap = 0; int* lineCounts = nullptr;
 	int2* reach = nullptr;                       // [T] accumulator rows the windows of a theta cover
 	int2* nmsRange = nullptr;                    // [column groups of the NMS] accumulator rows the windows can reach
-	uint8_t* nmsFlags = nullptr; uint16_t* nmsOffs = nullptr; uint32_t* rowBase = nullptr; int* chunkTotals = nullptr; // NMS survivors (flag planes) and their ranks
+	uint8_t* nmsFlags = nullptr;                 // NMS survivors (flag planes)
+	int* blockCounts = nullptr; int lineBlocks = 0;   // NMS survivors per 64 accumulator rows (part of `counters`)
 	void* sortTemp = nullptr; size_t sortTempBytes = 0;
 	int strengthBits = 16, keyBits = 0;
 	// voting over image tiles (planned at plan creation: the per-tile edge counters live in `counters`)
@@ -430,14 +431,12 @@ int ensureSht(compvhip_plan* p)
 	p->keyBits = frameBits + p->strengthBits;
 	if (R * T >= (static_cast<size_t>(1) << 32)) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "theta step too small: the accumulator has 2^32 cells or more"); // 32-bit cell values
 	if (p->keyBits > 32) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "too many frames for a 32-bit line key");
-	dfree(ctx, p->nmsFlags); dfree(ctx, p->nmsOffs); dfree(ctx, p->rowBase); dfree(ctx, p->chunkTotals);
+	dfree(ctx, p->nmsFlags);
 	{
-		const size_t rows = sht_nms_rows(static_cast<int>(R)), groups = static_cast<size_t>(sht_nms_groups(static_cast<int>(T)));
-		HIPCHK(ctx, dmalloc(ctx, &p->nmsFlags, rows * groups * p->frames));
-		HIPCHK(ctx, hipMemset(p->nmsFlags, 0, rows * groups * p->frames)); // the NMS kernel skips the blocks no window reaches
-		HIPCHK(ctx, dmalloc(ctx, &p->nmsOffs, rows * groups * p->frames));
-		HIPCHK(ctx, dmalloc(ctx, &p->rowBase, rows * p->frames));
-		HIPCHK(ctx, dmalloc(ctx, &p->chunkTotals, static_cast<size_t>(sht_rank_chunks(static_cast<int>(R))) * p->frames));
+		const size_t frows = sht_nms_rows(static_cast<int>(R)), fgroups = static_cast<size_t>(sht_nms_groups(static_cast<int>(T)));
+		HIPCHK(ctx, dmalloc(ctx, &p->nmsFlags, frows * fgroups * p->frames));
+		HIPCHK(ctx, hipMemset(p->nmsFlags, 0, frows * fgroups * p->frames)); // the NMS kernel skips the blocks no window reaches
+		if (sht_lines_blocks(static_cast<int>(R)) != p->lineBlocks) return fail(ctx, COMPVHIP_E_INVALID_STATE, "row-block counters were sized for another accumulator");
 	}
 	p->shtReady = true;
 	return COMPVHIP_OK;
@@ -470,7 +469,7 @@ ShtArgs shtArgs(compvhip_plan* p, int threshold)
 	ShtArgs a;
 	a.ebits = p->ebits; a.edges = p->edges; a.edgeCounts = p->edgeCounts; a.acc = p->acc;
 	a.sinQ = p->sinQ; a.cosQ = p->cosQ; a.lineKeys = p->keysA; a.lineVals = p->valsA; a.lineCounts = p->lineCounts;
-	a.nmsRange = p->nmsRange; a.nmsFlags = p->nmsFlags; a.nmsOffs = p->nmsOffs; a.rowBase = p->rowBase; a.chunkTotals = p->chunkTotals; a.nmsGroups = sht_nms_groups(static_cast<int>(p->T)); a.nmsRows = static_cast<int>(sht_nms_rows(static_cast<int>(p->R)));
+	a.nmsRange = p->nmsRange; a.blockCounts = p->blockCounts; a.lineBlocks = p->lineBlocks; a.nmsFlags = p->nmsFlags; a.nmsRows = static_cast<int>(sht_nms_rows(static_cast<int>(p->R))); a.nmsGroups = sht_nms_groups(static_cast<int>(p->T));
 	a.bitsFrameStride = p->bitsFrameStride; a.edgeCap = p->edgeCap; a.accFrameStride = p->accFrameStride; a.lineCap = p->lineCap;
 	a.W = static_cast<int>(p->W); a.H = static_cast<int>(p->H); a.wb = p->wb;
 	a.R = static_cast<int>(p->R); a.T = static_cast<int>(p->T); a.accPitch = p->accPitch; a.barrier = static_cast<int>(p->W + p->H);
@@ -693,10 +692,11 @@ int compvhip_plan_create(compvhip_ctx* ctx, size_t W, size_t H, size_t S, size_t
 				if (!planVoteTiles(W, H, sq, cq, p->vt, p->vtKt, p->vtRowBase)) p->voteTiles = false;
 			}
 			else p->voteTiles = false;
-			p->nCounts = (2 + static_cast<size_t>(p->voteTiles ? p->vt.tiles : 0)) * frames;
+			p->lineBlocks = p->voteTiles ? sht_lines_blocks(static_cast<int>(R)) : 0;
+			p->nCounts = (2 + static_cast<size_t>(p->voteTiles ? p->vt.tiles : 0) + static_cast<size_t>(p->lineBlocks)) * frames;
 		}
 		if (dmalloc(ctx, &p->counters, p->nCounts + kMaxRounds) != hipSuccess) { rc = COMPVHIP_E_OUT_OF_MEMORY; break; }
-		p->edgeCounts = p->counters; p->lineCounts = p->counters + frames; p->tileCounts = p->counters + 2 * frames; p->flags = p->counters + p->nCounts;
+		p->edgeCounts = p->counters; p->lineCounts = p->counters + frames; p->tileCounts = p->counters + 2 * frames; p->blockCounts = p->counters + (2 + static_cast<size_t>(p->voteTiles ? p->vt.tiles : 0)) * frames; p->flags = p->counters + p->nCounts;
 		if (const char* e = getenv("COMPVHIP_RESOLVE_WRAP")) { const int v = atoi(e); if (v >= 8 && v <= kMaxRounds && (v & 3) == 0) p->maxRounds = v; }
 		if (hipMemset(p->counters, 0, sizeof(int) * (p->nCounts + kMaxRounds)) != hipSuccess) { rc = COMPVHIP_E_HIP; break; }
 		if (dmalloc(ctx, &p->thrDev, frames) != hipSuccess) { rc = COMPVHIP_E_OUT_OF_MEMORY; break; }
@@ -726,7 +726,7 @@ void compvhip_plan_destroy(compvhip_plan* p)
 	dfree(ctx, p->cosT); dfree(ctx, p->invSinT);
 	dfree(ctx, p->dKt); dfree(ctx, p->dRowBase); dfree(ctx, p->partLo); dfree(ctx, p->partHi); dfree(ctx, p->colFlag);
 	dfree(ctx, p->sinQ); dfree(ctx, p->cosQ); dfree(ctx, p->edges); dfree(ctx, p->acc);
-	dfree(ctx, p->keysA); dfree(ctx, p->keysB); dfree(ctx, p->valsA); dfree(ctx, p->valsB); dfree(ctx, p->nmsFlags); dfree(ctx, p->nmsOffs); dfree(ctx, p->rowBase); dfree(ctx, p->chunkTotals);
+	dfree(ctx, p->keysA); dfree(ctx, p->keysB); dfree(ctx, p->valsA); dfree(ctx, p->valsB); dfree(ctx, p->nmsFlags);
 	dfree(ctx, p->nmsRange); dfree(ctx, p->reach); dfree(ctx, p->sortTemp);
 	delete p;
 }
@@ -913,7 +913,7 @@ static int planShtImpl(compvhip_plan* p, const uint8_t* d_edges, int threshold, 
 	{ Stamp s(p, st, "sht_compact_kernel"); HIPCHK(ctx, launch_sht_compact_tiles(a, p->vt, frames, st)); }
 	{ Stamp s(p, st, "sht_vote_kernel"); HIPCHK(ctx, launch_sht_vote_tiles(a, p->vt, frames, st)); }
 	{ Stamp s(p, st, "sht_reduce_kernel"); HIPCHK(ctx, launch_sht_reduce_tiles(a, p->vt, frames, st)); }
-	{ Stamp s(p, st, "sht_nms_kernel"); HIPCHK(ctx, launch_sht_nms(a, frames, st)); }
+	{ Stamp s(p, st, "sht_lines_kernel"); HIPCHK(ctx, launch_sht_lines(a, frames, st)); }
 	{
 		Stamp s(p, st, "sht_sort_lines");
 		size_t tb = p->sortTempBytes;

@@ -106,11 +106,11 @@ struct ShtArgs {
 	uint32_t* lineKeys;       // [frames][lineCap] sort keys: frameTag << strengthBits | strength
 	uint32_t* lineVals;       // [frames][lineCap] their accumulator cells: row * T + col
 	uint8_t* nmsFlags;        // [frames][nmsGroups][nmsRows] NMS survivors: bit j of byte (group, row) = column 8 group + j
-	uint16_t* nmsOffs;        // [frames][nmsGroups][nmsRows] survivors of the row in the column groups before this one
-	uint32_t* rowBase;        // [frames][nmsRows] survivors in the rows above, inside the row's chunk of 1024 rows
-	int* chunkTotals;         // [frames][chunks] survivors per chunk
+	int nmsRows;              // rows of a flag plane
+	int* blockCounts;         // [frames][lineBlocks] NMS survivors per 64 accumulator rows (one row block of sht_lines_kernel); written by sht_count_kernel
+	int lineBlocks;
 	const int2* nmsRange;     // [nmsGroups] accumulator rows [x, y) the windows of the group's columns (+ one either side) can reach, widened by one row
-	int nmsGroups, nmsRows;
+	int nmsGroups;            // groups of 8 theta columns
 	int* lineCounts;          // per frame
 	size_t bitsFrameStride, edgeCap, accFrameStride, lineCap;
 	int W, H, wb;
@@ -139,12 +139,12 @@ hipError_t launch_sht_vote_tiles(const ShtArgs& a, const ShtTileArgs& v, int fra
 hipError_t launch_sht_reduce_tiles(const ShtArgs& a, const ShtTileArgs& v, int frames, hipStream_t stream);
 hipError_t launch_bytes_to_bits(const uint8_t* edges, int W, int H, int S, size_t frameStride, uint32_t* ebits, int wb, size_t bitsFrameStride,
                                 int frames, hipStream_t stream);
-hipError_t launch_sht_nms(const ShtArgs& a, int frames, hipStream_t stream);
+hipError_t launch_sht_lines(const ShtArgs& a, int frames, hipStream_t stream);
 hipError_t launch_sht_decode(const uint32_t* keys, const uint32_t* vals, const int* counts, size_t lineCap, int frames, int T, int barrier, float thetaStep,
                              int maxLines, int strengthBits, void* lines /*compvhip_line*/, size_t outCap, hipStream_t stream);
-size_t sht_nms_rows(int R);
-int sht_rank_chunks(int R);
 int sht_nms_groups(int T);
+size_t sht_nms_rows(int R);
+int sht_lines_blocks(int R);
 // acc [T][pitch] -> reference layout [R][stride]
 hipError_t launch_sht_cartesian(const void* lines /*compvhip_line*/, const int* counts, size_t lineCap, int frames, const float* cosT, const float* invSinT,
                                 float widthF, float r, float* out /*[frames][lineCap][4]*/, hipStream_t stream);

@@ -57,14 +57,20 @@ __global__ __launch_bounds__(256) void bytes_to_bits_kernel(const uint8_t* __res
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// NMS + threshold -> lines, in three small steps that make the emission order DETERMINISTIC (accumulator rows, then columns, ascending:
-// nms_apply's own order, houghsht.cxx:546-562), so that the sort only has to order by strength:
-//   sht_nms_kernel   LDS-tiled 3x3 test; the survivors of 8 theta columns x 8 rho rows per thread leave as one flag byte per (row, column
-//                    group): flag planes [frame][column group][row], 8-byte coalesced stores, no atomics;
-//   sht_rank_kernel  survivors per row (popcounts of the row's flag bytes), exclusive scan inside chunks of 1024 rows -> rowBase[frame][row]
-//                    and the chunk totals (the emit kernel adds the few totals in front of a row's chunk);
-//   sht_emit_kernel  one workgroup per 64 rows: their survivors in (row, column) order -> key = frameTag | strength, value = cell (row * T + col)
-//                    at slot chunk base + rowBase + in-row offset of the frame's key / value arrays (staged in the LDS, coalesced stores).
+// NMS + threshold -> (key, value) pairs in DETERMINISTIC order (accumulator rows, then columns, ascending: nms_apply's own order,
+// houghsht.cxx:546-562), so that the sort only has to order by strength.  Three kernels:
+//   sht_nms_kernel    3x3 test of 8 theta columns x 8 rho rows per thread straight from registers; the survivors leave as one flag byte per
+//                     (row, column group): flag planes [frame][column group][row], 8-byte coalesced stores, no atomics;
+//   sht_lines_kernel  a workgroup (one wave, lane = row) owns 64 COMPLETE accumulator rows (all theta columns), so its survivors occupy one contiguous
+//                     range of the frame's key / value arrays: the rows' survivors are counted and prefix-summed in the wave, the range's
+//                     start is the sum of the earlier blocks' survivor counts (sht_count_kernel: one wave per row block, no atomics), key = frameTag | strength and value = cell (row * T + col) are put in place in
+//                     the LDS and stored coalesced.  The last workgroup of a frame publishes the line count and zeroes the unused key slots.
+//   sht_count_kernel  survivors per 64 rows (one wave per row block);
+//                     (Measured and dropped: a decoupled look-back chain instead of sht_count_kernel -- every block waits for atomic round
+//                     trips to the L2: 27 us of that kernel's 42; one atomicAdd per NMS thread instead of sht_count_kernel -- 184 adds on
+//                     every counter: +30 us in the NMS; the NMS inside this kernel too -- no flag planes, no second read of the strengths: 0.106 ms
+//                     against 0.021 + 0.03: at 150 VGPRs four 3-wave workgroups fit a CU, and load -> test -> barrier -> scan -> look-back ->
+//                     barrier -> emit is one latency chain per workgroup.)
 // A stable descending radix sort of the (key, value) pairs then gives frame-major, strength-descending, (row, col)-ascending order with
 // frameBits + strengthBits key bits (18 at 4K x 32 frames: two 10-bit onesweep passes; the unique 40-bit keys of rounds 1-2, which carried
 // the cell because the slots were handed out by atomics in arrival order, took four).
@@ -172,119 +178,154 @@ __global__ __launch_bounds__(kNmsThreads) void sht_nms_kernel(ShtArgs a)
 	*reinterpret_cast<uint2*>(plane + base + t * 8) = make_uint2(flags[0], flags[1]);
 }
 
-// rowBase[frame][row] = survivors in the rows above INSIDE the row's chunk of kRankThreads rows; chunkTotals[frame][chunk] = survivors of
-// the chunk.  One workgroup per (chunk, frame): a single coalesced pass, one block scan.
-constexpr int kRankThreads = 1024;
-__global__ __launch_bounds__(kRankThreads) void sht_rank_kernel(ShtArgs a)
+constexpr int kLnRows = 64;               // rows per workgroup = lanes of its one wave
+constexpr int kLnStage = 512;             // (key, value) slots staged in the LDS (a 64-row block of a 4K frame holds ~300; 4 KB keep all 32 wave slots of a CU usable); denser row blocks store directly
+
+// The flag bytes of one accumulator row (lane = row) for 32 column groups starting at cg0, packed into 8 registers: 32 independent
+// (clamped, hence unconditional) loads in flight together -- a `count += popc(load)` loop is compiled into load -> wait -> add per column
+// group, 23 exposed memory latencies.
+__device__ __forceinline__ void sht_load_flags(const uint8_t* __restrict__ planes, int nmsRows, int groups, int cg0, uint32_t (&fw)[8])
 {
-	__shared__ int s_wave[kRankThreads / 64];
-	const int frame = blockIdx.y;
-	const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-	const int r = blockIdx.x * kRankThreads + t;
-	const uint8_t* __restrict__ planes = a.nmsFlags + (size_t)frame * a.nmsGroups * a.nmsRows;
-	// survivors of the row's earlier column groups, one u16 per (group, row): the emit kernel starts every flag byte at rowBase + this offset
-	uint16_t* __restrict__ offs = a.nmsOffs + (size_t)frame * a.nmsGroups * a.nmsRows;
-	int cnt = 0;
-	if (r < a.R) for (int g = 0; g < a.nmsGroups; ++g) {
-		offs[(size_t)g * a.nmsRows + r] = (uint16_t)cnt;
-		cnt += __popc((uint32_t)planes[(size_t)g * a.nmsRows + r]);
-	}
-	int incl = cnt;
+	uint32_t b[32];
 #pragma unroll
-	for (int o = 1; o < 64; o <<= 1) {
-		const int n = __shfl_up(incl, o);
-		if (lane >= o) incl += n;
-	}
-	if (lane == 63) s_wave[wave] = incl;
-	__syncthreads();
-	int wbase = 0, total = 0;
+	for (int i = 0; i < 32; ++i) b[i] = (uint32_t)planes[(size_t)min(cg0 + i, groups - 1) * nmsRows];
 #pragma unroll
-	for (int k = 0; k < kRankThreads / 64; ++k) {
-		const int n = s_wave[k];
-		if (k < wave) wbase += n;
-		total += n;
-	}
-	if (r < a.R) a.rowBase[(size_t)frame * a.nmsRows + r] = (uint32_t)(wbase + incl - cnt);
-	if (t == 0) a.chunkTotals[frame * gridDim.x + blockIdx.x] = total;
+	for (int i = 0; i < 32; ++i) b[i] = (cg0 + i < groups) ? b[i] : 0u;
+#pragma unroll
+	for (int i = 0; i < 8; ++i) fw[i] = b[4 * i] | (b[4 * i + 1] << 8) | (b[4 * i + 2] << 16) | (b[4 * i + 3] << 24);
 }
 
-// One workgroup = kEmitRows consecutive accumulator rows, all column groups (thread = (row, group phase)): the survivors of those rows
-// occupy ONE contiguous slot range of the frame's key / value arrays (rows ascending, columns ascending), so they are put in place in
-// the LDS first and leave as coalesced stores (a thread storing its own few items would touch 64 different cache lines per instruction).
-// Every accumulator read is independent of every other.  Block 0 of every frame also publishes the frame's line count.
-constexpr int kEmitThreads = 256;
-constexpr int kEmitRows = 64;
-constexpr int kEmitStage = 2048;   // slots staged in the LDS; denser row blocks store directly
-__global__ __launch_bounds__(kEmitThreads) void sht_emit_kernel(ShtArgs a, int chunks)
+// survivors per 64 accumulator rows: blockCounts[frame][row block] (one wave per row block, same placement as sht_lines_kernel)
+__global__ __launch_bounds__(kLnRows) void sht_count_kernel(ShtArgs a)
 {
-	__shared__ uint32_t s_keys[kEmitStage], s_vals[kEmitStage];
-	const int frame = blockIdx.y;
-	const int r0 = blockIdx.x * kEmitRows;
-	const int r = r0 + (threadIdx.x & (kEmitRows - 1)), phase = threadIdx.x / kEmitRows;
-	const int* __restrict__ ct = a.chunkTotals + frame * chunks;
-	if (blockIdx.x == 0 && threadIdx.x == 0) {
-		int n = 0;
-		for (int k = 0; k < chunks; ++k) n += ct[k];
-		a.lineCounts[frame] = n;
+	const int nblk = (a.R + kLnRows - 1) / kLnRows;
+	const int xcd = blockIdx.x & 7, kk = blockIdx.x >> 3;
+	const int frame = (kk / nblk) * 8 + xcd, blk = kk % nblk;
+	if (frame >= a.frames) return; // uniform
+	const int lane = threadIdx.x, groups = a.nmsGroups;
+	const uint8_t* __restrict__ planes = a.nmsFlags + (size_t)frame * groups * a.nmsRows + blk * kLnRows + lane;
+	uint32_t cnt = 0;
+	for (int cg0 = 0; cg0 < groups; cg0 += 32) {
+		uint32_t fw[8];
+		sht_load_flags(planes, a.nmsRows, groups, cg0, fw);
+#pragma unroll
+		for (int i = 0; i < 8; ++i) cnt += (uint32_t)__popc(fw[i]);
 	}
-	// slot range of this block: [first, last) (kRankThreads is a multiple of kEmitRows: the block's rows lie in one chunk)
-	size_t chunkBase = 0;
-	for (int k = 0; k < r0 / kRankThreads; ++k) chunkBase += (size_t)ct[k];
-	const uint32_t* __restrict__ rb = a.rowBase + (size_t)frame * a.nmsRows;
-	const int rEnd = min(r0 + kEmitRows, a.R);
-	const size_t first = chunkBase + rb[r0];
-	size_t last;
-	if (rEnd < a.R && (rEnd % kRankThreads) != 0) last = chunkBase + rb[rEnd];
-	else last = chunkBase + (size_t)ct[r0 / kRankThreads];          // the block ends its chunk (or the accumulator)
-	const size_t span = last - first;
-	const bool staged = span <= (size_t)kEmitStage;
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
+	if (lane == 0) a.blockCounts[frame * nblk + blk] = (int)cnt;
+}
+
+// One WAVE per 64 complete accumulator rows, lane = row: no barriers, every workgroup of the launch resident at once (the version with
+// 184-thread workgroups and LDS tables ran load -> barrier -> scan -> look-back -> barrier -> emit as one latency chain per workgroup:
+// 0.07 ms against the 0.046 ms of the rank / emit / pad kernels it replaced).
+__global__ __launch_bounds__(kLnRows) void sht_lines_kernel(ShtArgs a)
+{
+	__shared__ uint32_t s_keys[kLnStage], s_vals[kLnStage];
+	// XCD-aware order (workgroup i runs on XCD i % 8): the row blocks of one frame run on ONE XCD: neighbouring blocks share
+	// the cache lines of the flag planes and of the key / value arrays through that XCD's L2
+	const int nblk = (a.R + kLnRows - 1) / kLnRows;
+	const int xcd = blockIdx.x & 7, kk = blockIdx.x >> 3;
+	const int frame = (kk / nblk) * 8 + xcd, blk = kk % nblk;
+	if (frame >= a.frames) return; // uniform
+	const int lane = threadIdx.x;
+	const int r = blk * kLnRows + lane;                       // < nmsRows (whole NMS blocks); rows >= R have no survivors
+	const int groups = a.nmsGroups;
+	const uint8_t* __restrict__ planes = a.nmsFlags + (size_t)frame * groups * a.nmsRows + r;
+	const uint16_t* __restrict__ acc = a.acc + (size_t)frame * a.accFrameStride + r;
+
+	// 1. survivors of the lane's row, exclusive scan over the block's rows
+	auto loadFlags = [&](int cg0, uint32_t (&fw)[8]) { sht_load_flags(planes, a.nmsRows, groups, cg0, fw); };
+	uint32_t fw0[8];      // column groups 0 .. 31: all of them up to T = 256
+	loadFlags(0, fw0);
+	uint32_t cnt = 0;
+#pragma unroll
+	for (int i = 0; i < 8; ++i) cnt += (uint32_t)__popc(fw0[i]);
+	for (int cg0 = 32; cg0 < groups; cg0 += 32) {
+		uint32_t fw[8];
+		loadFlags(cg0, fw);
+#pragma unroll
+		for (int i = 0; i < 8; ++i) cnt += (uint32_t)__popc(fw[i]);
+	}
+	uint32_t incl = cnt;
+#pragma unroll
+	for (int o = 1; o < 64; o <<= 1) {
+		const uint32_t n = __shfl_up(incl, o);
+		if (lane >= o) incl += n;
+	}
+	const uint32_t total = __shfl(incl, 63);
+	// 2. the block's first slot = the survivors of the frame's earlier row blocks (sht_count_kernel): a few independent loads and a
+	// wave reduction.  (A decoupled look-back chain over the blocks -- no counters, status words written by this kernel -- cost 27 us of this
+	// kernel's 42: every block waits for atomic round trips to the L2.)
+	const int* __restrict__ bc = a.blockCounts + (size_t)frame * nblk;
+	uint32_t first = 0;
+	for (int i0 = 0; i0 < blk; i0 += 4 * kLnRows) {
+		uint32_t v[4];
+#pragma unroll
+		for (int u = 0; u < 4; ++u) v[u] = (uint32_t)bc[min(i0 + u * kLnRows + lane, nblk - 1)];   // clamped: unconditional loads
+#pragma unroll
+		for (int u = 0; u < 4; ++u) first += (i0 + u * kLnRows + lane < blk) ? v[u] : 0u;
+	}
+#pragma unroll
+	for (int o = 32; o > 0; o >>= 1) first += __shfl_xor(first, o);
 	uint32_t* __restrict__ keys = a.lineKeys + (size_t)frame * a.lineCap;
 	uint32_t* __restrict__ vals = a.lineVals + (size_t)frame * a.lineCap;
-	if (r < a.R) {
-		const size_t rowPos = chunkBase + rb[r];
+	// 3. the survivors in (row, column) order: key = frameTag | strength, value = cell (row * T + col), put in place in the LDS and stored
+	// coalesced (a lane storing its own few items would touch 64 different cache lines per instruction)
+	if (total) {
+		const bool staged = total <= (uint32_t)kLnStage;
 		const uint32_t frameTag = (uint32_t)(a.frames - 1 - frame) << a.strengthBits;
-		for (int g = phase; g < a.nmsGroups; g += kEmitThreads / kEmitRows) {
-			const size_t pi = ((size_t)frame * a.nmsGroups + g) * a.nmsRows + r;
-			const uint32_t f = a.nmsFlags[pi];
-			if (!f) continue;
-			const uint16_t* __restrict__ acc = a.acc + (size_t)frame * a.accFrameStride + (size_t)(g * kNmsCols) * a.accPitch + r;
-			uint32_t v[kNmsCols];
+		uint32_t pos = incl - cnt;   // block-local
+		// A lane only puts its survivors' cells in place (LDS); the strengths are gathered afterwards, one staged slot per lane: independent
+		// loads, 64 in flight (a lane gathering its own row's strengths one after the other exposed a memory latency per survivor)
+		auto emitFlags = [&](int cg0, const uint32_t (&fw)[8]) {
 #pragma unroll
-			for (int j = 0; j < kNmsCols; ++j) v[j] = ((f >> j) & 1u) ? (uint32_t)acc[(size_t)j * a.accPitch] : 0u;
-			size_t pos = rowPos + (size_t)a.nmsOffs[pi];
-			const uint32_t cell0 = (uint32_t)r * (uint32_t)a.T + (uint32_t)(g * kNmsCols);
-#pragma unroll
-			for (int j = 0; j < kNmsCols; ++j) {
-				if ((f >> j) & 1u) {
-					if (staged) { s_keys[pos - first] = frameTag | v[j]; s_vals[pos - first] = cell0 + (uint32_t)j; }
-					else if (pos < a.lineCap) { keys[pos] = frameTag | v[j]; vals[pos] = cell0 + (uint32_t)j; }
+			for (int i = 0; i < 8; ++i) {
+				uint32_t f = fw[i];                        // 4 column groups = 32 theta columns, ascending
+				const int c0 = (cg0 + 4 * i) * kNmsCols;
+				while (f) {
+					const int j = __ffs(f) - 1;
+					f &= f - 1;
+					const uint32_t c = (uint32_t)(c0 + j), val = (uint32_t)r * (uint32_t)a.T + c;
+					if (staged) { s_keys[pos] = (c << 6) | (uint32_t)lane; s_vals[pos] = val; }
+					else if ((size_t)first + pos < a.lineCap) { keys[(size_t)first + pos] = frameTag | (uint32_t)acc[(size_t)c * a.accPitch]; vals[(size_t)first + pos] = val; }
 					++pos;
+				}
+			}
+		};
+		if (cnt) emitFlags(0, fw0);
+		for (int cg0 = 32; cg0 < groups; cg0 += 32) {
+			uint32_t fw[8];
+			loadFlags(cg0, fw);
+			emitFlags(cg0, fw);
+		}
+		if (staged) {
+			__syncthreads();   // one wave: the LDS stores of the other lanes
+			const uint16_t* __restrict__ acc0 = a.acc + (size_t)frame * a.accFrameStride + (size_t)blk * kLnRows;
+			// four slots per lane and step: the four strength loads are in flight together
+			for (uint32_t i0 = lane; i0 < total; i0 += 4 * kLnRows) {
+				uint32_t pk[4], vv[4], st4[4];
+#pragma unroll
+				for (int u = 0; u < 4; ++u) {
+					const uint32_t i = min(i0 + u * kLnRows, total - 1);   // clamped: unconditional loads
+					pk[u] = s_keys[i]; vv[u] = s_vals[i];
+				}
+#pragma unroll
+				for (int u = 0; u < 4; ++u) st4[u] = (uint32_t)acc0[(size_t)(pk[u] >> 6) * a.accPitch + (pk[u] & 63u)];
+#pragma unroll
+				for (int u = 0; u < 4; ++u) {
+					const uint32_t i = i0 + u * kLnRows;
+					const size_t p = (size_t)first + i;
+					if (i < total && p < a.lineCap) { keys[p] = frameTag | st4[u]; vals[p] = vv[u]; }
 				}
 			}
 		}
 	}
-	if (!staged) return; // uniform
-	__syncthreads();
-	for (size_t i = threadIdx.x; i < span; i += kEmitThreads) {
-		const size_t pos = first + i;
-		if (pos < a.lineCap) { keys[pos] = s_keys[i]; vals[pos] = s_vals[i]; }
-	}
-}
-
-// Key slots [min(count, lineCap), lineCap) of every frame are zeroed (a zero key sorts last: every real key carries a strength > 0).
-constexpr int kPadThreads = 256;
-constexpr int kPadSlots = 8;
-__global__ __launch_bounds__(kPadThreads) void sht_pad_keys_kernel(uint32_t* __restrict__ keys, const int* __restrict__ counts, size_t lineCap)
-{
-	const int frame = blockIdx.y;
-	const size_t used = (size_t)max(counts[frame], 0);
-	const size_t i0 = ((size_t)blockIdx.x * kPadThreads + threadIdx.x) * kPadSlots;
-	if (i0 + kPadSlots <= used) return;
-	uint32_t* __restrict__ k = keys + (size_t)frame * lineCap;
-#pragma unroll
-	for (int j = 0; j < kPadSlots; ++j) {
-		const size_t i = i0 + j;
-		if (i >= used && i < lineCap) k[i] = 0u;
+	// 4. the last block of the frame knows the line count: publish it, zero the unused key slots (a zero key sorts last: every real key carries a strength > 0)
+	if (blk == nblk - 1) {
+		const size_t count = (size_t)first + total;
+		if (lane == 0) a.lineCounts[frame] = (int)min(count, (size_t)0x7fffffff);
+		for (size_t i = min(count, a.lineCap) + lane; i < a.lineCap; i += kLnRows) keys[i] = 0u;
 	}
 }
 
@@ -373,20 +414,17 @@ hipError_t launch_bytes_to_bits(const uint8_t* edges, int W, int H, int S, size_
 	return hipGetLastError();
 }
 
-int sht_rank_chunks(int R) { return (R + kRankThreads - 1) / kRankThreads; }
-size_t sht_nms_rows(int R) { return (size_t)((R + kNmsRows - 1) / kNmsRows) * kNmsRows; }   // rows of a flag plane (whole NMS blocks)
 int sht_nms_groups(int T) { return (T + kNmsCols - 1) / kNmsCols; }
+size_t sht_nms_rows(int R) { return (size_t)((R + kNmsRows - 1) / kNmsRows) * kNmsRows; }   // rows of a flag plane (whole NMS blocks)
+int sht_lines_blocks(int R) { return (R + kLnRows - 1) / kLnRows; }
 
-hipError_t launch_sht_nms(const ShtArgs& a, int frames, hipStream_t stream)
+hipError_t launch_sht_lines(const ShtArgs& a, int frames, hipStream_t stream)
 {
-	dim3 grid((a.R + kNmsRows - 1) / kNmsRows, (a.T + kNmsCols - 1) / kNmsCols, frames);
-	hipLaunchKernelGGL(sht_nms_kernel, grid, dim3(kNmsThreads), 0, stream, a);
-	const int chunks = (a.R + kRankThreads - 1) / kRankThreads;
-	hipLaunchKernelGGL(sht_rank_kernel, dim3(chunks, frames), dim3(kRankThreads), 0, stream, a);
-	hipLaunchKernelGGL(sht_emit_kernel, dim3((a.R + kEmitRows - 1) / kEmitRows, frames), dim3(kEmitThreads), 0, stream, a, chunks);
-	// unused key slots must sort last: zero the slots past each frame's count (a zero key sorts last: every real key carries a strength > 0)
-	dim3 pgrid((unsigned)((a.lineCap + kPadThreads * kPadSlots - 1) / (kPadThreads * kPadSlots)), frames);
-	hipLaunchKernelGGL(sht_pad_keys_kernel, pgrid, dim3(kPadThreads), 0, stream, a.lineKeys, a.lineCounts, a.lineCap);
+	dim3 ngrid((a.R + kNmsRows - 1) / kNmsRows, (a.T + kNmsCols - 1) / kNmsCols, frames);
+	hipLaunchKernelGGL(sht_nms_kernel, ngrid, dim3(kNmsThreads), 0, stream, a);
+	const int nblk = sht_lines_blocks(a.R);
+	hipLaunchKernelGGL(sht_count_kernel, dim3((unsigned)(8 * ((frames + 7) / 8) * nblk)), dim3(kLnRows), 0, stream, a);
+	hipLaunchKernelGGL(sht_lines_kernel, dim3((unsigned)(8 * ((frames + 7) / 8) * nblk)), dim3(kLnRows), 0, stream, a);
 	return hipGetLastError();
 }
 
