@@ -332,12 +332,13 @@ __global__ __launch_bounds__(kResolveThreads) void canny_resolve_kernel(ResolveA
 	uint8_t* const mine = a.dirty + (size_t)(a.round & 3) * cells + ((size_t)frame * nb + band) * nc + chunk;
 	if (a.round > 0) {
 		const uint8_t* prev = a.dirty + (size_t)((a.round - 1) & 3) * cells + (size_t)frame * nb * nc;
+		// (nine unconditional loads -- clamped cells repeat a neighbour that is read anyway -- in flight together: with a bounds test in
+		// front of each, the compiler waits for every byte before it fetches the next)
 		int any = 0;
+#pragma unroll
 		for (int db = -1; db <= 1; ++db)
-			for (int dc = -1; dc <= 1; ++dc) {
-				const int b2 = band + db, c2 = chunk + dc;
-				if (b2 >= 0 && b2 < nb && c2 >= 0 && c2 < nc) any |= prev[b2 * nc + c2];
-			}
+#pragma unroll
+			for (int dc = -1; dc <= 1; ++dc) any |= prev[min(max(band + db, 0), nb - 1) * nc + min(max(chunk + dc, 0), nc - 1)];
 		if (!any) { if (tid == 0) *mine = 0; return; } // uniform
 		// This band reached its fixed point the last time it ran: only NEW edge pixels in its halo can promote anything, and only through a
 		// candidate (U) pixel of its border that touches one of them.  Look at the border first -- 6 rows and 6 word columns instead of the whole

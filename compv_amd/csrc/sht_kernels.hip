@@ -336,17 +336,19 @@ __global__ __launch_bounds__(256) void sht_decode_kernel(const uint32_t* __restr
                                                          int T, int barrier, float thetaStep, int maxLines, int strengthBits, LineOut* __restrict__ lines, size_t outCap)
 {
 	const int frame = blockIdx.y;
-	__shared__ size_t s_off;
-	if (threadIdx.x == 0) {   // once per block, not once per thread
-		size_t o = 0;
-		for (int g = 0; g < frame; ++g) {
-			const size_t cg = (size_t)max(counts[g], 0);
-			o += cg < lineCap ? cg : lineCap;
-		}
-		s_off = o;
+	// the frame's offset: thread g adds the count of frame g (one thread walking the earlier frames' counts exposed a memory latency per
+	// frame: 10 us for the last frames of a batch of 32)
+	__shared__ unsigned long long s_part[4];
+	unsigned long long before = 0;
+	for (int g = threadIdx.x; g < frame; g += 256) {
+		const size_t cg = (size_t)max(counts[g], 0);
+		before += cg < lineCap ? cg : lineCap;
 	}
+#pragma unroll
+	for (int d = 32; d > 0; d >>= 1) before += __shfl_xor(before, d);
+	if ((threadIdx.x & 63) == 0) s_part[threadIdx.x >> 6] = before;
 	__syncthreads();
-	const size_t off = s_off;
+	const size_t off = (size_t)(s_part[0] + s_part[1] + s_part[2] + s_part[3]);
 	size_t n = (size_t)max(counts[frame], 0);
 	if (n > lineCap) n = lineCap;
 	if (maxLines > 0 && n > (size_t)maxLines) n = (size_t)maxLines;
