@@ -391,12 +391,24 @@ __global__ __launch_bounds__(kResolveThreads) void canny_resolve_kernel(ResolveA
 	}
 	if (!__syncthreads_or(haveU)) { if (tid == 0) *mine = 0; return; }  // nothing unresolved in this band
 	const uint32_t ewInv = (1u << 19) / (uint32_t)ew + 1u;   // i / ew == (i * ewInv) >> 19 for every i < 66 * 66, 3 <= ew <= 66 (verified exhaustively)
-	for (int i = tid; i < (rows + 2) * ew; i += kResolveThreads) {
-		const int r = (int)(((uint32_t)i * ewInv) >> 19), c = i - r * ew;
-		const int y = y0 - 1 + r, w = w0 - 1 + c;
-		uint32_t v = 0;
-		if (y >= 0 && y < a.H && w >= 0 && w < wb) v = gE[(size_t)y * wb + w];
-		sE[i] = v;
+	// (three words per thread and step, loaded unconditionally from clamped addresses and masked afterwards: the loads of a step are in
+	// flight together; `if (inside) v = gE[...]` made every word of the ~9 per thread wait for the one before)
+	const int nE = (rows + 2) * ew;
+	for (int i0 = tid; i0 < nE; i0 += 3 * kResolveThreads) {
+		uint32_t v[3]; bool ok[3];
+#pragma unroll
+		for (int q = 0; q < 3; ++q) {
+			const int i = min(i0 + q * kResolveThreads, nE - 1);
+			const int r = (int)(((uint32_t)i * ewInv) >> 19), c = i - r * ew;
+			const int y = y0 - 1 + r, w = w0 - 1 + c;
+			ok[q] = (y >= 0 && y < a.H && w >= 0 && w < wb);
+			v[q] = gE[(size_t)min(max(y, 0), a.H - 1) * wb + min(max(w, 0), wb - 1)];
+		}
+#pragma unroll
+		for (int q = 0; q < 3; ++q) {
+			const int i = i0 + q * kResolveThreads;
+			if (i < nE) sE[i] = ok[q] ? v[q] : 0u;
+		}
 	}
 	__syncthreads();
 	uint32_t* const col = sE + (size_t)(n > 0 ? r0 : 0) * ew + k + 1;   // LDS word of (row r0 - 1, column k); row j of the group is col[(j + 1) * ew]
