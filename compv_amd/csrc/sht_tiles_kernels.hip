@@ -81,10 +81,10 @@ __global__ __launch_bounds__(kTcThreads) void sht_compact_tiles_kernel(ShtArgs a
 		total += t;
 	}
 	if (total == 0) return; // uniform
-	if (threadIdx.x == 0) {
-		s_base = atomicAdd(&v.tileCounts[frame * v.tiles + tile], total);
-		atomicAdd(&a.edgeCounts[frame], total);
-	}
+	// (the frame's edge count is summed from the tile counts by the voting kernel: one atomicAdd per chunk on edgeCounts[frame] put all
+	// 4608 workgroups of a 32 x 4K launch on ONE cache line -- the counters of 32 frames -- and the L2 serialises the atomics of a line:
+	// 37 of this kernel's 57 us)
+	if (threadIdx.x == 0) s_base = atomicAdd(&v.tileCounts[frame * v.tiles + tile], total);
 	__syncthreads();
 	uint32_t* __restrict__ dst = a.edges + ((size_t)frame * v.tiles + tile) * v.tileCap;
 	const int first = wbase + (incl - cnt);
@@ -141,7 +141,9 @@ __global__ __launch_bounds__(kVtThreads) void sht_vote_tiles_kernel(ShtArgs a, S
 	const int tid = threadIdx.x, lane = tid & 63;
 	const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
 
-	const int n = min(v.tileCounts[unit], (int)v.tileCap);
+	const int nAll = v.tileCounts[unit];
+	if (g == 0 && threadIdx.x == 0 && nAll) atomicAdd(&a.edgeCounts[frame], nAll);   // edges of the frame (entries past a full list included)
+	const int n = min(nAll, (int)v.tileCap);
 	const int words = v.Rw * 32;
 	uint32_t* const s_any = hist + words;   // two dwords behind the histogram: lane mask of the columns that hold a count >= 256
 	if (tid < 2) s_any[tid] = 0u;
