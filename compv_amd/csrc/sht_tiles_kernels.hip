@@ -53,16 +53,22 @@ __global__ __launch_bounds__(kTcThreads) void sht_compact_tiles_kernel(ShtArgs a
 	constexpr int kPer = (kTcRows * 40 + kTcThreads - 1) / kTcThreads; // words per thread; tiles are at most 1264 = kShtMaxWindow columns wide (40 words)
 	uint32_t wv[kPer]; int wl[kPer];
 	int cnt = 0;
+	if (nwords == 0) return; // uniform
+	// The loads are unconditional (clamped addresses, masked afterwards): all kPer of a thread are in flight together.  Written as
+	// `if (i < nwords) wv[k] = bits[...]` the compiler emits branch, load, s_waitcnt per word -- ten exposed memory latencies per thread.
 #pragma unroll
 	for (int k = 0; k < kPer; ++k) {
-		const int i = threadIdx.x + k * kTcThreads;
-		wv[k] = 0u; wl[k] = 0;
-		if (i < nwords) {
-			const int r = (int)(((uint32_t)i * wprInv) >> 20), c = i - r * wpr;   // (an integer division per word cost a third of the kernel)
-			if (w0 + c < a.wb) wv[k] = bits[(size_t)(y0 + ly0 + r) * a.wb + w0 + c];
-			wl[k] = ((ly0 + r) << 16) | (c << 5);
-			cnt += __popc(wv[k]);
-		}
+		const int i = min((int)threadIdx.x + k * kTcThreads, nwords - 1);
+		const int r = (int)(((uint32_t)i * wprInv) >> 20), c = i - r * wpr;   // (an integer division per word cost a third of the kernel)
+		wv[k] = bits[(size_t)(y0 + ly0 + r) * a.wb + min(w0 + c, a.wb - 1)];
+		wl[k] = ((ly0 + r) << 16) | (c << 5);
+	}
+#pragma unroll
+	for (int k = 0; k < kPer; ++k) {
+		const int i = (int)threadIdx.x + k * kTcThreads;
+		const int c = (wl[k] & 0xffff) >> 5;
+		if (!(i < nwords && w0 + c < a.wb)) wv[k] = 0u;
+		cnt += __popc(wv[k]);
 	}
 	int incl = cnt;
 	const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
