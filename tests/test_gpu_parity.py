@@ -823,6 +823,21 @@ def test_plan_small_line_capacity_with_many_candidates(hip_ctx, oracle):
             plan.close()
 
 
+def test_houghsht_dense_local_maxima_past_the_lds_stage(hip_ctx, oracle):
+    """sht_lines_kernel stages up to 512 (key, cell) pairs of a 64-row block in the LDS and stores denser blocks directly: a 2 % random
+    edge map with threshold 1 has up to ~1600 local maxima per block (and blocks on both sides of the limit)."""
+    W, H = 512, 384
+    rng = np.random.default_rng(5)
+    e = (rng.random((H, W)) < 0.02).astype(np.uint8) * 255
+    acc_exp = oracle.sht_acc(e, 1.0)
+    exp = oracle.sht_lines_from_acc_reference_order(acc_exp, W, H, 1.0, 1)
+    per_block = np.bincount(np.array([l[3] for l in exp]) // 64)
+    assert per_block.max() > 1024 and (per_block[per_block > 0] < 512).any()
+    lines, acc = hip_ctx.houghsht(e, 1.0, 1, want_acc=True)
+    assert (acc == acc_exp).all()
+    assert _lines_tuple(lines) == _orc_tuple(exp)
+
+
 def test_plan_pipeline_async_matches_sync(hip_ctx, oracle):
     """compvhip_plan_pipeline_async / compvhip_plan_wait: two steps in flight on two buffer sets, same results as the
     synchronous call; includes a frame whose hysteresis needs more than the speculative resolve rounds (replay path)."""
