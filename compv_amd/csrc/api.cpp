@@ -889,7 +889,7 @@ int compvhip_plan_edge_dete(compvhip_plan* p, const uint8_t* d_in, int op, uint8
 }
 
 static int planShtImpl(compvhip_plan* p, const uint8_t* d_edges, int threshold, int maxLines, compvhip_line* d_lines, size_t lineCap, int32_t* d_counts,
-                       hipStream_t st, bool clearTimeline)
+                       hipStream_t st, bool clearTimeline, bool pairsOnly = false)
 {
 	compvhip_ctx* ctx = p->ctx;
 	if (threshold <= 0) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "threshold must be > 0"); // houghsht.cxx:82
@@ -914,6 +914,11 @@ static int planShtImpl(compvhip_plan* p, const uint8_t* d_edges, int threshold, 
 	{ Stamp s(p, st, "sht_vote_kernel"); HIPCHK(ctx, launch_sht_vote_tiles(a, p->vt, frames, st)); }
 	{ Stamp s(p, st, "sht_reduce_kernel"); HIPCHK(ctx, launch_sht_reduce_tiles(a, p->vt, frames, st)); }
 	{ Stamp s(p, st, "sht_lines_kernel"); HIPCHK(ctx, launch_sht_lines(a, frames, st)); }
+	// pairsOnly (the host entry point): stop at the (key, cell) pairs in emission order -- the caller orders them itself (referenceLineOrder)
+	if (pairsOnly) {
+		if (d_counts) HIPCHK(ctx, hipMemcpyAsync(d_counts, p->lineCounts, sizeof(int32_t) * frames, hipMemcpyDeviceToDevice, st));
+		return COMPVHIP_OK;
+	}
 	{
 		Stamp s(p, st, "sht_sort_lines");
 		size_t tb = p->sortTempBytes;
@@ -1339,34 +1344,24 @@ int compvhip_otsu_u8(compvhip_ctx* ctx, const uint8_t* in, size_t W, size_t H, s
 // and calling the same std::sort gives the reference's list element by element -- callers such as CompVCalibCamera (line grouping,
 // core/calib/compv_core_calib_camera.cxx:200-) depend on the order inside equal-strength groups.  The permutation only depends on
 // the strengths, so it is computed on (strength, index) pairs.
-static void referenceLineOrder(std::vector<compvhip_line>& lines, size_t T)
+static void referenceLineOrder(const std::vector<uint32_t>& keys, const std::vector<uint32_t>& cells, uint32_t strengthMask, size_t T, long long barrier, float thetaStep,
+                               std::vector<compvhip_line>& lines)
 {
-	const size_t n = lines.size();
-	if (n < 2) return;
-	std::vector<uint64_t> byCell(n);
-	for (size_t i = 0; i < n; ++i)
-		byCell[i] = ((static_cast<uint64_t>(lines[i].row) * T + static_cast<uint64_t>(lines[i].col)) << 32) | static_cast<uint64_t>(i);
-	{
-		// emission order = ascending cell (cells are unique): LSD radix sort on the cell field, 11 bits per pass (a dense 4K frame has
-		// 57 000 lines: std::sort here cost as much as the order-defining std::sort below)
-		uint64_t maxKey = 0;
-		for (uint64_t k : byCell) maxKey = std::max(maxKey, k >> 32);
-		std::vector<uint64_t> tmp(n);
-		for (int shift = 32; (maxKey >> (shift - 32)) != 0 && shift < 64; shift += 11) {
-			size_t hist[2049] = { 0 };
-			for (uint64_t k : byCell) ++hist[((k >> shift) & 2047u) + 1];
-			for (int b = 0; b < 2048; ++b) hist[b + 1] += hist[b];
-			for (uint64_t k : byCell) tmp[hist[(k >> shift) & 2047u]++] = k;
-			byCell.swap(tmp);
-		}
-	}
+	// keys / cells arrive in emission order (ascending cell): exactly the array the reference sorts
+	const size_t n = keys.size();
 	struct Item { int32_t strength; uint32_t idx; };
 	std::vector<Item> items(n);
-	for (size_t i = 0; i < n; ++i) { const uint32_t j = static_cast<uint32_t>(byCell[i] & 0xffffffffu); items[i].strength = lines[j].strength; items[i].idx = j; }
+	for (size_t i = 0; i < n; ++i) { items[i].strength = static_cast<int32_t>(keys[i] & strengthMask); items[i].idx = static_cast<uint32_t>(i); }
 	std::sort(items.begin(), items.end(), [](const Item& a, const Item& b) { return a.strength > b.strength; });
-	std::vector<compvhip_line> out(n);
-	for (size_t i = 0; i < n; ++i) out[i] = lines[items[i].idx];
-	lines.swap(out);
+	lines.resize(n);
+	for (size_t i = 0; i < n; ++i) {
+		const uint32_t cell = cells[items[i].idx];
+		const uint32_t row = cell / static_cast<uint32_t>(T), col = cell - row * static_cast<uint32_t>(T);
+		compvhip_line& l = lines[i];
+		l.rho = static_cast<float>(barrier - static_cast<long long>(row));   // houghsht.cxx:661
+		l.theta = static_cast<float>(col) * thetaStep;                       // houghsht.cxx:662 (one rounded f32 product: -ffp-contract=off)
+		l.strength = items[i].strength; l.row = static_cast<int32_t>(row); l.col = static_cast<int32_t>(col);
+	}
 }
 
 int compvhip_houghsht_u8(compvhip_ctx* ctx, const uint8_t* edges, size_t W, size_t H, size_t S, float rho, float thetaDeg, int threshold, int maxLines,
@@ -1387,13 +1382,11 @@ int compvhip_houghsht_u8(compvhip_ctx* ctx, const uint8_t* edges, size_t W, size
 	if (acc && accStride < p->T) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "accStride < theta bins");
 	HIPCHK(ctx, hipMemcpy2DAsync(ctx->dIn, p->S, edges, S, W, H, hipMemcpyHostToDevice, ctx->stream));
 	if (!ctx->dCounts) HIPCHK(ctx, dmalloc(ctx, &ctx->dCounts, 1));
-	// ALL lines of the frame come back (device order: strength, then cell), because the order the reference returns them in -- and which
-	// equal-strength lines survive maxLines -- is decided by its unstable std::sort over the whole list (referenceLineOrder).
-	size_t want = std::max<size_t>(p->lineCap, kMinLineCap); // = the device key capacity planShtImpl will use
+	// ALL candidate lines of the frame come back as (strength, cell) pairs in emission order -- the sort and the decode kernel are skipped:
+	// the order the reference returns them in, and which equal-strength lines survive maxLines, is decided by its unstable std::sort
 	int32_t count = 0;
 	for (int attempt = 0; attempt < 2; ++attempt) {
-		if (ctx->dLinesCap < want) { dfree(ctx, ctx->dLines); ctx->dLinesCap = 0; HIPCHK(ctx, dmalloc(ctx, &ctx->dLines, want)); ctx->dLinesCap = want; }
-		rc = compvhip_plan_houghsht(p, ctx->dIn, threshold, 0, ctx->dLines, want, ctx->dCounts, ctx->stream);
+		rc = planShtImpl(p, ctx->dIn, threshold, 0, nullptr, 0, ctx->dCounts, ctx->stream, true, true);
 		if (rc) return rc;
 		HIPCHK(ctx, hipMemcpyAsync(&count, ctx->dCounts, sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
 		HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -1401,11 +1394,15 @@ int compvhip_houghsht_u8(compvhip_ctx* ctx, const uint8_t* edges, size_t W, size
 		// more candidate lines than the device key buffer holds: grow it and redo the line stage
 		rc = ensureLineCap(p, static_cast<size_t>(count));
 		if (rc) return rc;
-		want = p->lineCap;
 	}
-	std::vector<compvhip_line> all(static_cast<size_t>(count));
-	if (count) HIPCHK(ctx, hipMemcpy(all.data(), ctx->dLines, all.size() * sizeof(compvhip_line), hipMemcpyDeviceToHost));
-	referenceLineOrder(all, p->T);
+	std::vector<uint32_t> hk(static_cast<size_t>(count)), hv(static_cast<size_t>(count));
+	if (count) {
+		HIPCHK(ctx, hipMemcpyAsync(hk.data(), p->keysA, hk.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+		HIPCHK(ctx, hipMemcpyAsync(hv.data(), p->valsA, hv.size() * sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
+		HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+	}
+	std::vector<compvhip_line> all;
+	referenceLineOrder(hk, hv, (1u << p->strengthBits) - 1u, p->T, static_cast<long long>(p->W + p->H), p->thetaStep, all);
 	size_t found = all.size();
 	if (maxLines > 0 && found > static_cast<size_t>(maxLines)) found = static_cast<size_t>(maxLines);
 	*n = found;
