@@ -701,7 +701,7 @@ int compvhip_plan_create(compvhip_ctx* ctx, size_t W, size_t H, size_t S, size_t
 		if (hipMemset(p->counters, 0, sizeof(int) * (p->nCounts + kMaxRounds)) != hipSuccess) { rc = COMPVHIP_E_HIP; break; }
 		if (dmalloc(ctx, &p->thrDev, frames) != hipSuccess) { rc = COMPVHIP_E_OUT_OF_MEMORY; break; }
 		if (dmalloc(ctx, &p->dirty, canny_resolve_dirty_bytes(static_cast<int>(H), p->wb, static_cast<int>(frames))) != hipSuccess) { rc = COMPVHIP_E_OUT_OF_MEMORY; break; }
-		if (dmalloc(ctx, &p->sums, frames) != hipSuccess) { rc = COMPVHIP_E_OUT_OF_MEMORY; break; }
+		if (dmalloc(ctx, &p->sums, frames * kFrameSlot) != hipSuccess) { rc = COMPVHIP_E_OUT_OF_MEMORY; break; }
 		if (hipHostMalloc(reinterpret_cast<void**>(&p->hFlags), sizeof(int) * (kAsyncDepth + 1)) != hipSuccess) { rc = COMPVHIP_E_OUT_OF_MEMORY; break; }
 	} while (0);
 	if (rc) { compvhip_plan_destroy(p); return fail(ctx, rc, "plan allocation"); }

@@ -500,14 +500,14 @@ __global__ __launch_bounds__(256) void frame_sum_kernel(const uint8_t* __restric
 		for (int x = (wq << 2) + threadIdx.x; x < W; x += blockDim.x) acc += row[x];
 	}
 	for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
-	if ((threadIdx.x & 63) == 0) atomicAdd(&sums[frame], acc);
+	if ((threadIdx.x & 63) == 0) atomicAdd(&sums[frame * kFrameSlot], acc);
 }
 
 __global__ void mean_thresholds_kernel(const unsigned int* __restrict__ sums, int W, int H, float fLow, float fHigh, int2* __restrict__ thr, int frames)
 {
 	const int f = blockIdx.x * blockDim.x + threadIdx.x;
 	if (f >= frames) return;
-	unsigned int mean = (sums[f] / (unsigned int)(W * H)) & 0xffu; // static_cast<uint8_t>
+	unsigned int mean = (sums[f * kFrameSlot] / (unsigned int)(W * H)) & 0xffu; // static_cast<uint8_t>
 	mean = mean < 1u ? 1u : mean;
 	unsigned int lo = (unsigned int)(int)__fmul_rn((float)mean, fLow) & 0xffffu;   // static_cast<uint16_t>(mean * f)
 	unsigned int hi = (unsigned int)(int)__fmul_rn((float)mean, fHigh) & 0xffffu;
@@ -569,7 +569,7 @@ hipError_t launch_canny_resolve(const ResolveArgs& a, int frames, hipStream_t st
 hipError_t launch_mean_thresholds(const uint8_t* in, int W, int H, int S, size_t frameStride, int frames, float fLow, float fHigh,
                                   unsigned int* sums, int2* thr, hipStream_t stream)
 {
-	hipError_t e = hipMemsetAsync(sums, 0, sizeof(unsigned int) * frames, stream);
+	hipError_t e = hipMemsetAsync(sums, 0, sizeof(unsigned int) * frames * kFrameSlot, stream);
 	if (e != hipSuccess) return e;
 	dim3 grid(min(H, 64), frames);
 	hipLaunchKernelGGL(frame_sum_kernel, grid, dim3(256), 0, stream, in, W, H, S, frameStride, sums);

@@ -13,6 +13,9 @@ constexpr int kCannyWaves = 4;        // waves (= 512x64 tiles, stacked vertical
 constexpr int kBandH = 64;            // rows per resolve band
 constexpr int kBandWords = 64;        // 32-px words per resolve chunk (2048 columns): 0.056 ms per step at 4K, 0.075 ms with 128
 constexpr int kResolveThreads = 512;
+// Per-frame counters that many workgroups hit with atomics (Sobel gmax, the pixel sum of the mean thresholds) sit one per 128-byte line: the
+// L2 serialises the atomics of a line, and the counters of 32 frames side by side are ONE line.
+constexpr int kFrameSlot = 32;
 constexpr int kResolveRows = kBandH * kBandWords / kResolveThreads; // rows of one word column a resolve thread owns (8)
 
 struct CannyArgs {
@@ -53,7 +56,7 @@ hipError_t launch_mean_thresholds(const uint8_t* in, int W, int H, int S, size_t
 struct EdgeDeteArgs {
 	const uint8_t* in;
 	uint8_t* out;
-	unsigned int* gmax;       // per frame
+	unsigned int* gmax;       // per frame, one counter per 128-byte line: gmax[frame * kFrameSlot]
 	size_t inFrameStride, outFrameStride;
 	int W, H, S, So;
 	int tilesX, tilesY;

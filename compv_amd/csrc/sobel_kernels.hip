@@ -49,7 +49,7 @@ __global__ __launch_bounds__(kEdgeWaves * 64) void edge_dete_kernel(EdgeDeteArgs
 	float scale = 0.f;
 	bool allZero = false;
 	if (SCALE) {
-		const unsigned int gmax = a.gmax[frame];
+		const unsigned int gmax = a.gmax[frame * kFrameSlot];
 		allZero = (gmax == 0);
 		scale = __fdiv_rn(255.f, (float)gmax);
 	}
@@ -95,7 +95,7 @@ __global__ __launch_bounds__(kEdgeWaves * 64) void edge_dete_kernel(EdgeDeteArgs
 	}
 	if (!SCALE) {
 		for (int o = 32; o > 0; o >>= 1) vmax = max(vmax, (unsigned int)__shfl_down(vmax, o));
-		if (lane == 0 && vmax) atomicMax(&a.gmax[frame], vmax);
+		if (lane == 0 && vmax) atomicMax(&a.gmax[frame * kFrameSlot], vmax);
 	}
 }
 
@@ -105,7 +105,7 @@ static hipError_t launch_op(const EdgeDeteArgs& a0, int frames, hipStream_t stre
 	EdgeDeteArgs a = a0;
 	a.blockRows = (a.tilesY + kEdgeWaves - 1) / kEdgeWaves;
 	a.groups = a.blockRows * frames;
-	hipError_t e = hipMemsetAsync(a.gmax, 0, sizeof(unsigned int) * frames, stream);
+	hipError_t e = hipMemsetAsync(a.gmax, 0, sizeof(unsigned int) * frames * kFrameSlot, stream);
 	if (e != hipSuccess) return e;
 	dim3 grid(8 * ((a.groups + 7) / 8) * a.tilesX);
 	dim3 block(kEdgeWaves * 64);
