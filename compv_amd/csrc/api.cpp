@@ -64,7 +64,6 @@ struct compvhip_ctx {
 	size_t dInBytes = 0, dOutBytes = 0;
 	uint8_t* dPacked = nullptr; size_t dPackedBytes = 0; // packed-pixel staging of compvhip_grayscale_u8
 	uint32_t* dHist = nullptr;                             // [256] histogram + 1 result word of compvhip_otsu_u8
-	compvhip_line* dLines = nullptr; size_t dLinesCap = 0;
 	int32_t* dCounts = nullptr;
 	int32_t* dAccOut = nullptr; size_t dAccOutElems = 0;
 	KhtScratch kht;                    // KHT scratch of the host entry point (compvhip_houghkht_u8)
@@ -611,7 +610,7 @@ void compvhip_ctx_destroy(compvhip_ctx* ctx)
 	(void)hipSetDevice(ctx->device);
 	if (ctx->hostPlan) compvhip_plan_destroy(ctx->hostPlan);
 	dfree(ctx, ctx->dPacked); dfree(ctx, ctx->dHist);
-	dfree(ctx, ctx->dIn); dfree(ctx, ctx->dOut); dfree(ctx, ctx->dLines); dfree(ctx, ctx->dCounts); dfree(ctx, ctx->dAccOut);
+	dfree(ctx, ctx->dIn); dfree(ctx, ctx->dOut); dfree(ctx, ctx->dCounts); dfree(ctx, ctx->dAccOut);
 	khtScratchFree(ctx, ctx->kht);
 	if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
 	delete ctx;
