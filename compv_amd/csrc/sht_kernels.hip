@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void bytes_to_bits_kernel(const uint8_t* __res
 //   sht_lines_kernel  a workgroup (one wave, lane = row) owns 64 COMPLETE accumulator rows (all theta columns), so its survivors occupy one contiguous
 //                     range of the frame's key / value arrays: the rows' survivors are counted and prefix-summed in the wave, the range's
 //                     start is the sum of the earlier blocks' survivor counts (sht_count_kernel: one wave per row block, no atomics), key = frameTag | strength and value = cell (row * T + col) are put in place in
-//                     the LDS and stored coalesced.  The last workgroup of a frame publishes the line count and zeroes the unused key slots.
+//                     the LDS and stored coalesced; every block zeroes a slice of the frame's unused key slots.
 //   sht_count_kernel  survivors per 64 rows (one wave per row block);
 //                     (Measured and dropped: a decoupled look-back chain instead of sht_count_kernel -- every block waits for atomic round
 //                     trips to the L2: 27 us of that kernel's 42; one atomicAdd per NMS thread instead of sht_count_kernel -- 184 adds on
@@ -260,16 +260,20 @@ __global__ __launch_bounds__(kLnRows) void sht_lines_kernel(ShtArgs a)
 	// wave reduction.  (A decoupled look-back chain over the blocks -- no counters, status words written by this kernel -- cost 27 us of this
 	// kernel's 42: every block waits for atomic round trips to the L2.)
 	const int* __restrict__ bc = a.blockCounts + (size_t)frame * nblk;
-	uint32_t first = 0;
-	for (int i0 = 0; i0 < blk; i0 += 4 * kLnRows) {
+	uint32_t first = 0, count = 0;   // survivors of the earlier row blocks / of the whole frame
+	for (int i0 = 0; i0 < nblk; i0 += 4 * kLnRows) {
 		uint32_t v[4];
 #pragma unroll
 		for (int u = 0; u < 4; ++u) v[u] = (uint32_t)bc[min(i0 + u * kLnRows + lane, nblk - 1)];   // clamped: unconditional loads
 #pragma unroll
-		for (int u = 0; u < 4; ++u) first += (i0 + u * kLnRows + lane < blk) ? v[u] : 0u;
+		for (int u = 0; u < 4; ++u) {
+			const int i = i0 + u * kLnRows + lane;
+			first += (i < blk) ? v[u] : 0u;
+			count += (i < nblk) ? v[u] : 0u;
+		}
 	}
 #pragma unroll
-	for (int o = 32; o > 0; o >>= 1) first += __shfl_xor(first, o);
+	for (int o = 32; o > 0; o >>= 1) { first += __shfl_xor(first, o); count += __shfl_xor(count, o); }
 	uint32_t* __restrict__ keys = a.lineKeys + (size_t)frame * a.lineCap;
 	uint32_t* __restrict__ vals = a.lineVals + (size_t)frame * a.lineCap;
 	// 3. the survivors in (row, column) order: key = frameTag | strength, value = cell (row * T + col), put in place in the LDS and stored
@@ -323,11 +327,12 @@ __global__ __launch_bounds__(kLnRows) void sht_lines_kernel(ShtArgs a)
 			}
 		}
 	}
-	// 4. the last block of the frame knows the line count: publish it, zero the unused key slots (a zero key sorts last: every real key carries a strength > 0)
-	if (blk == nblk - 1) {
-		const size_t count = (size_t)first + total;
-		if (lane == 0) a.lineCounts[frame] = (int)min(count, (size_t)0x7fffffff);
-		for (size_t i = min(count, a.lineCap) + lane; i < a.lineCap; i += kLnRows) keys[i] = 0u;
+	// 4. the line count, and this block's slice of the unused key slots (a zero key sorts last: every real key carries a strength > 0).
+	// (Left to the frame's last block alone, the zeroing is 24 us on the critical path of a frame with few lines.)
+	if (blk == 0 && lane == 0) a.lineCounts[frame] = (int)min(count, 0x7fffffffu);
+	if ((size_t)count < a.lineCap) {
+		const size_t pad = a.lineCap - count, per = (pad + (size_t)nblk - 1) / (size_t)nblk;
+		for (size_t i = (size_t)blk * per + lane; i < min((size_t)(blk + 1) * per, pad); i += kLnRows) keys[(size_t)count + i] = 0u;
 	}
 }
 
