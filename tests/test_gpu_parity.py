@@ -361,6 +361,32 @@ def test_plan_pipeline_batch_matches_oracle(hip_ctx, oracle):
         assert _lines_tuple(got) == _orc_tuple(exp)
 
 
+def test_plan_pipeline_nine_frames_and_fine_theta(hip_ctx, oracle):
+    """The kernels placed XCD-aware (voting, count, lines) deal frames to the 8 XCDs in groups of eight: 9 frames = one full group and a
+    group with a single frame.  And a theta step of 0.25 degrees (T = 720: 90 groups of 8 columns) makes the line kernels walk the flag
+    planes in three chunks of 32 column groups."""
+    from compv_amd import capi
+    W, H, n = 200, 150, 9
+    frames = np.stack([synth_frame(W, H, 777 + f) for f in range(n)])
+    edges, lines_raw, counts, accs = _plan_run(hip_ctx, frames, 59.0, 119.0, 25, 4096)
+    for f in range(n):
+        rc, e = oracle.canny(frames[f], 59.0, 119.0)
+        assert (edges[f] == e).all(), f
+        acc = oracle.sht_acc(e, 1.0)
+        assert (accs[f] == acc).all(), f
+        exp = oracle.sht_lines_from_acc(acc, W, H, 1.0, 25)
+        assert counts[f] == len(exp)
+        got = np.frombuffer(lines_raw[f].tobytes(), dtype=capi.LINE_DTYPE)[:len(exp)]
+        assert _lines_tuple(got) == _orc_tuple(exp)
+    rc, e = oracle.canny(frames[0], 59.0, 119.0)
+    acc_exp = oracle.sht_acc(e, 0.25)
+    assert acc_exp.shape[1] == 720
+    lines, acc = hip_ctx.houghsht(e, 0.25, 12, want_acc=True)
+    assert (acc == acc_exp).all()
+    assert _lines_tuple(lines) == _orc_tuple(oracle.sht_lines_from_acc_reference_order(acc_exp, W, H, 0.25, 12))
+    assert len(lines) > 100
+
+
 def test_plan_houghsht_foreign_edge_maps_with_empty_and_full_frames(hip_ctx, oracle):
     """compvhip_plan_houghsht on caller-provided edge maps (any non-zero byte is an edge, houghsht.cxx:159-165): a batch that mixes
     an EMPTY frame (no tile has an edge), a frame with every pixel set (the densest possible tile lists) and sparse frames -- the
