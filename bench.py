@@ -216,8 +216,8 @@ def committed_counters(W, H, F):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=16)
-    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=64, help="timed steps per repetition (64 x 0.7 ms: the two-lane pipeline is in steady state for all but its first and last step)")
+    ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--frames-per-gpu", type=int, default=32)   # BASELINE config 4: 256 frames over 8 GPUs
     ap.add_argument("--batches", type=int, default=8, help="distinct resident batches the steps rotate over (8 x 32 = config 4's 256 frames)")
     ap.add_argument("--width", type=int, default=3840)
