@@ -27,13 +27,14 @@
 // 240 = 15 half-words) but own no pixels.  Every input byte is fetched once per tile (+ 4/64 row halo, + 16/240 column halo).
 // 4 pixels per lane: <= 64 VGPRs and 4.6 KB of LDS per wave put 8 waves on every SIMD (one wave issues an instruction only every
 // ~8.7 cycles whatever its type, so the issue rate of a SIMD is resident waves / 8.7 until a pipe saturates).
-#include "stencil.hpp"
-#include "kernels.hpp"
+#include "../../compv_amd/csrc/stencil.hpp"
+#include "../../compv_amd/csrc/kernels.hpp"
 
 #include <cstdlib>
 #include <type_traits>
 
-namespace compvhip {
+namespace compvhip_lab_ns {
+using namespace compvhip;
 
 namespace {
 
@@ -46,8 +47,14 @@ constexpr int kAux = 4 * kRowB;              // aux ring, 2 rows: row r lives in
 constexpr int kList = kAux + 2 * kRowB;      // candidate list of a row pair: <= 480 u16 entries
 constexpr int kNib = kList + 1024;           // result nibbles, 4 rows x 64 bytes: byte l of a row = lane l's four pixels, U flags (weak, not strong) in bits 0..3, E flags (strong) in 4..7
 constexpr int kNibRowB = 64;
-constexpr int kLdsBytes = kNib + 4 * kNibRowB + 64;   // 4416 B per wave (the flush reads up to 8 bytes past the last row)
+#ifdef LAB_PAIRS
+constexpr int kCarry = kNib + 4 * kNibRowB + 64;   // [tile row][plane] u16: the low half of the mask dword an even tile shares with the odd tile to its right
+constexpr int kLdsBytes = kCarry + 128;
+#else
+constexpr int kLdsBytes = kNib + 4 * kNibRowB + 64;
+#endif   // 4416 B per wave (the flush reads up to 8 bytes past the last row)
 
+constexpr uint32_t kBiasD = 0x01000100u;     // +256 per half: horizontal difference R - L
 constexpr uint32_t kBias1k = 0x04000400u;    // +1024 per half: gx, gy
 constexpr uint32_t kBias2k = 0x08000800u;    // +2048 per half: g' = g + 2048 (and "2 * bias" of the absolute value)
 
@@ -70,10 +77,6 @@ __device__ __forceinline__ uint32_t twice(uint32_t x)
 	asm("v_add_u32 %0, %1, %1" : "=v"(d) : "v"(x));
 	return d;
 }
-// three-operand forms (one instruction each; the constants ride in SGPRs -- VOP3 takes no literal on gfx9)
-__device__ __forceinline__ uint32_t lshl1_add(uint32_t a, uint32_t b) { uint32_t d; asm("v_lshl_add_u32 %0, %1, 1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }   // 2a + b
-__device__ __forceinline__ uint32_t xad(uint32_t a, uint32_t sk, uint32_t c) { uint32_t d; asm("v_xad_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(sk), "v"(c)); return d; }   // (a ^ k) + c
-__device__ __forceinline__ uint32_t add3(uint32_t a, uint32_t b, uint32_t sk) { uint32_t d; asm("v_add3_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(sk)); return d; }
 // nibble -> four bytes {0, 0xff}
 __device__ __forceinline__ uint32_t nibble_bytes(uint32_t nib)
 {
@@ -83,6 +86,28 @@ __device__ __forceinline__ uint32_t nibble_bytes(uint32_t nib)
 	return hi - b;
 }
 
+
+// ---- single-instruction wrappers (the compiler turns mask arithmetic back into v_cmp + v_cndmask otherwise) ----
+#define VOP2(NAME, OP) __device__ __forceinline__ uint32_t NAME(uint32_t a, uint32_t b) { uint32_t d; asm(OP " %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }
+VOP2(vadd, "v_add_u32")
+VOP2(vsub, "v_sub_u32")        // a - b
+VOP2(vand, "v_and_b32")
+VOP2(vor, "v_or_b32")
+VOP2(vmax16, "v_max_u16")
+VOP2(vmul24, "v_mul_u32_u24")
+__device__ __forceinline__ uint32_t vshl(uint32_t x, uint32_t n) { uint32_t d; asm("v_lshlrev_b32 %0, %1, %2" : "=v"(d) : "v"(n), "v"(x)); return d; }
+template <int N> __device__ __forceinline__ uint32_t vlshr(uint32_t x) { uint32_t d; asm("v_lshrrev_b32 %0, %1, %2" : "=v"(d) : "n"(N), "v"(x)); return d; }
+template <int N> __device__ __forceinline__ uint32_t vashr(uint32_t x) { uint32_t d; asm("v_ashrrev_i32 %0, %1, %2" : "=v"(d) : "n"(N), "v"(x)); return d; }
+template <uint32_t K> __device__ __forceinline__ uint32_t vandk(uint32_t x) { uint32_t d; asm("v_and_b32 %0, %1, %2" : "=v"(d) : "n"(K), "v"(x)); return d; }
+template <uint32_t K> __device__ __forceinline__ uint32_t vaddk(uint32_t x) { uint32_t d; asm("v_add_u32 %0, %1, %2" : "=v"(d) : "n"(K), "v"(x)); return d; }
+template <uint32_t K> __device__ __forceinline__ uint32_t vsubk(uint32_t x) { uint32_t d; asm("v_sub_u32 %0, %1, %2" : "=v"(d) : "n"(K), "v"(x)); return d; }   // K - x
+__device__ __forceinline__ uint32_t vnot(uint32_t x) { uint32_t d; asm("v_not_b32 %0, %1" : "=v"(d) : "v"(x)); return d; }
+
+__device__ __forceinline__ uint32_t lshl1_add(uint32_t a, uint32_t b) { uint32_t d; asm("v_lshl_add_u32 %0, %1, 1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; }   // 2a + b
+__device__ __forceinline__ uint32_t lshl1_add_s(uint32_t a, uint32_t sb) { uint32_t d; asm("v_lshl_add_u32 %0, %1, 1, %2" : "=v"(d) : "v"(a), "s"(sb)); return d; }
+__device__ __forceinline__ uint32_t xad(uint32_t a, uint32_t sk, uint32_t c) { uint32_t d; asm("v_xad_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(sk), "v"(c)); return d; }   // (a ^ k) + c
+__device__ __forceinline__ uint32_t add3(uint32_t a, uint32_t b, uint32_t sk) { uint32_t d; asm("v_add3_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(sk)); return d; }
+
 } // namespace
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -90,15 +115,45 @@ template <bool GAP, int WAVES, int kSwRows>
 __global__ __launch_bounds__(WAVES * 64, 8) void canny_swar_tile_kernel(CannyArgs a)
 {
 	// the g rings of all waves first (2048-byte aligned), then the rest of each wave's block
+#ifdef LAB_PAIRS2
+	// + the two halves of the mask dword the pair's tiles share: [tile row][plane] u16, low halves (even tile) then high halves (odd tile)
+	__shared__ __attribute__((aligned(2048))) uint8_t lds_all[WAVES * kLdsBytes + 256];
+#else
 	__shared__ __attribute__((aligned(2048))) uint8_t lds_all[WAVES * kLdsBytes];
+#endif
 
 	const int lane = threadIdx.x & 63;
 	const int wave = WAVES == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+#ifdef LAB_PAIRS
+	int pairX, group;
+	const int pairsX = (a.tilesX + 1) >> 1;
+	if (!xcd_tile_map(blockIdx.x, pairsX, a.groups, pairX, group)) return;
+	const int frame = group / a.blockRows;
+	const int tileY = (group - frame * a.blockRows) * WAVES + wave;
+	if (tileY >= a.tilesY) return; // whole wave
+#pragma nounroll
+	for (int tp = 0; tp < 2; ++tp) {
+	const int tileX = 2 * pairX + tp;
+	if (tileX >= a.tilesX) break;
+	const bool hasPartner = (tileX + 1 < a.tilesX);
+#elif defined(LAB_PAIRS2)
+	// a workgroup = two horizontally adjacent tiles (480 columns = 15 mask dwords): the dword they share leaves as ONE store after both are done
+	static_assert(WAVES == 2, "pairs");
+	int pairX, group;
+	if (!xcd_tile_map(blockIdx.x, (a.tilesX + 1) >> 1, a.groups, pairX, group)) return;
+	const int frame = group / a.blockRows;
+	const int tileY = group - frame * a.blockRows;
+	const int tileX = 2 * pairX + wave;
+	if (tileX >= a.tilesX) return; // whole wave (an ended wave no longer takes part in the barrier below)
+	const bool hasPartner = (2 * pairX + 1 < a.tilesX);
+	uint16_t* const carry = reinterpret_cast<uint16_t*>(lds_all + WAVES * kLdsBytes);
+#else
 	int tileX, group;
 	if (!xcd_tile_map(blockIdx.x, a.tilesX, a.groups, tileX, group)) return;
 	const int frame = group / a.blockRows;
 	const int tileY = (group - frame * a.blockRows) * WAVES + wave;
 	if (tileY >= a.tilesY) return; // whole wave
+#endif
 
 	uint8_t* const ring = lds_all + wave * (4 * kRowB);                               // g' ring
 	uint8_t* const rest = lds_all + WAVES * (4 * kRowB) + wave * (kLdsBytes - 4 * kRowB) - kAux; // rest[kAux ..] = aux, list, masks
@@ -150,31 +205,174 @@ __global__ __launch_bounds__(WAVES * 64, 8) void canny_swar_tile_kernel(CannyArg
 	const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(in), 0, (int)((size_t)H * S), 0x00020000);
 	auto load = [&](int y, uint32_t& m, uint32_t& l, uint32_t& r) {
 		const int so = min(max(y, 0), H - 1) * S;
+#if defined(LAB_NO_LOADS)
+		m = (uint32_t)so * 2654435761u + xm; l = m >> 3; r = m << 5;
+#elif defined(LAB_ONE_LOAD)
+		m = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)xm, so, 0);
+		l = m >> 3; r = m << 5;
+#else
 		m = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)xm, so, 0);
 		l = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)xl, so, 0);
 		r = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)xr, so, 0);
+#endif
 	};
 
 	// rolling state: two pixels per register, pairs k = (x0 + 2k, x0 + 2k + 1)
-	uint32_t P[2] = { 0, 0 };              // d[y-2] + 2 d[y-1]   (bias 765)
-	uint32_t dprev[2] = { 0, 0 };          // d[y-1]              (bias 255)
+	uint32_t P[2] = { 0, 0 };              // d[y-2] + 2 d[y-1]   (bias 768)
+	uint32_t dprev[2] = { 0, 0 };          // d[y-1]              (bias 256)
 	uint32_t hy[2][2] = { { 0, 0 }, { 0, 0 } }; // horizontal smooth of rows y-1 / y-2 (ring)
 
 	// per-lane constants of the sparse stage
 	const uint32_t lane8 = (uint32_t)lane * 8u;            // byte offset of the lane's 4 u16 inside a ring row
-	const bool fullRow = (tileX * kSwCols + kSwCols <= a.So); // every 16-byte group of the tile's edge bytes lies inside the output row
 	auto zero_nibbles = [&]() { *reinterpret_cast<uint32_t*>(rest + kNib + lane * 4) = 0u; };   // 4 rows x 64 B
 	zero_nibbles();
 	uint32_t listCount = 0;                // entries in the candidate list (wave-uniform)
-
+#if defined(LAB_DENSE2)
 	uint32_t k255 = 0x00ff00ffu, k4 = 0x00040004u, k3ff = 0x03ff03ffu, k1 = 0x00010001u;
 	asm volatile("" : "+s"(k255), "+s"(k4), "+s"(k3ff), "+s"(k1));
+#endif
+#ifdef LAB_NMS2
+	uint32_t tanQ = 27145u, tHighV = (uint32_t)tHighQ;
+	asm volatile("" : "+v"(tanQ), "+v"(tHighV));
+#endif
 
-	// input rows are fetched TWO steps ahead (two register sets that alternate: the row loop is unrolled by four).  With one row in flight per
-	// wave the kernel ran 12 % slower once its stores shared the memory pipeline with the loads (tools/canny_lab, round 4)
+#ifdef LAB_PF2
 	uint32_t nb[2][3];
 	load(y0 - 2, nb[0][0], nb[0][1], nb[0][2]);
 	load(y0 - 1, nb[1][0], nb[1][1], nb[1][2]);
+#else
+	uint32_t nm, nl, nr;
+	load(y0 - 2, nm, nl, nr);
+#endif
+
+	// rows rr0 .. rr0 + 3 of the tile are classified: masks and edge bytes leave in their final global layout, the nibble rows are cleared
+	const bool fullRow = (tileX * kSwCols + kSwCols <= a.So);
+	auto flush = [&](int rr0) {
+		__builtin_amdgcn_wave_barrier();
+		const uint32_t* const nibw = reinterpret_cast<const uint32_t*>(rest + kNib);
+		{
+			// masks: lanes 0..31 the U rows (weak & ~strong), 32..63 the E rows (strong), whole row segments per store instruction.  Global
+			// dword d0 + dl = the pixels of lanes [8 dl + 2, 8 dl + 10) (even tiles) or [8 dl - 2, 8 dl + 6) (odd): 8 result bytes that start
+			// in the middle of a dword (the bytes of a neighbouring tile's columns, or of the next row, end in a half-word that is not stored)
+			const int mi = lane >> 5, q = (lane >> 3) & 3, dl = lane & 7;
+#ifdef LAB_TILE_MASKS
+			{
+				const uint32_t* rn2 = nibw + q * 16 + 2 * dl;
+				const uint32_t nsh2 = (uint32_t)mi * 4u;
+				uint32_t th2[2];
+#pragma unroll
+				for (int hh = 0; hh < 2; ++hh) {
+					uint32_t t = (rn2[hh] >> nsh2) & 0x0f0f0f0fu;
+					t = (t | (t >> 4)) & 0x00ff00ffu;
+					th2[hh] = (t | (t >> 8)) & 0x0000ffffu;
+				}
+				const uint32_t v2 = th2[0] | (th2[1] << 16);
+				// [tile][plane][row][8 dwords]: the four rows of a flush are one 128-byte line per plane
+				const size_t ti = ((size_t)frame * a.tilesY + tileY) * a.tilesX + tileX;
+#ifdef LAB_PAD_ROWMAJOR
+				uint32_t* dst2 = (mi ? ebase : ubase) + (size_t)(y0 + rr0 + q) * a.wb + tileX * 8 + dl;   // row-major, 256 bits per tile
+#else
+				uint32_t* dst2 = (mi ? a.ebits : a.ubits) + (ti * kSwRows + (rr0 + q)) * 8 + dl;
+#endif
+				if (y0 + rr0 + q < H) *dst2 = v2;
+			}
+			if (a.ksize == 77) {
+#endif
+			const uint32_t* rn = nibw + q * 16 + 2 * dl - odd;
+			const uint32_t d0w = rn[0], d1w = rn[1], d2w = rn[2];
+			const uint32_t nsh = (uint32_t)mi * 4u;                          // U: low nibbles, E: high nibbles
+			uint32_t th[2];
+#pragma unroll
+			for (int hh = 0; hh < 2; ++hh) {
+				const uint32_t by = hh ? __builtin_amdgcn_alignbit(d2w, d1w, 16) : __builtin_amdgcn_alignbit(d1w, d0w, 16);  // 4 lanes = 16 pixels
+				uint32_t t = (by >> nsh) & 0x0f0f0f0fu;
+				t = (t | (t >> 4)) & 0x00ff00ffu;
+				th[hh] = (t | (t >> 8)) & 0x0000ffffu;
+			}
+			const uint32_t v = th[0] | (th[1] << 16);
+			const int row = y0 + rr0 + q, gd = d0 + dl;
+#ifdef LAB_GUARD_MASKS
+			if (row < H && gd < a.wb && a.ksize == 77) {
+#else
+			if (row < H && gd < a.wb) {
+#endif
+				uint32_t* dst = (mi ? ebase : ubase) + (size_t)row * a.wb + gd;
+#if defined(LAB_PAIRS)
+				{
+					const bool sharedLo = (!odd && dl == 7), sharedHi = (odd && dl == 0);
+					uint16_t* const cw = reinterpret_cast<uint16_t*>(rest + kCarry) + ((rr0 + q) * 2 + mi);
+					if (sharedLo) *cw = (uint16_t)v;
+					uint32_t vv = sharedLo ? (v & 0xffffu) : v;
+					if (sharedHi) vv = (v & 0xffff0000u) | *cw;
+					if (!(sharedLo && hasPartner)) *dst = vv;
+				}
+#elif defined(LAB_PAIRS2)
+				{
+					const bool sharedLo = (!odd && dl == 7), sharedHi = (odd && dl == 0);
+					if (sharedLo) carry[(rr0 + q) * 2 + mi] = (uint16_t)v;
+					else if (sharedHi) carry[64 + (rr0 + q) * 2 + mi] = (uint16_t)(v >> 16);
+					else *dst = v;
+				}
+#elif defined(LAB_ATOMIC_SHARED)
+				{
+					// the dword two tiles share: each clears and sets ITS half with two L2 atomics (any interleaving of the two tiles is correct)
+					if (!odd && dl == 7) { atomicAnd(dst, 0xffff0000u); atomicOr(dst, v & 0x0000ffffu); }
+					else if (odd && dl == 0) { atomicAnd(dst, 0x0000ffffu); atomicOr(dst, v & 0xffff0000u); }
+					else *dst = v;
+				}
+#elif defined(LAB_NO_SHORTS)
+				if (!(!odd && dl == 7) && !(odd && dl == 0)) *dst = v;
+#elif defined(LAB_ALL_SHORTS)
+				if (!(odd && dl == 0)) reinterpret_cast<uint16_t*>(dst)[0] = (uint16_t)v;
+				if (!(!odd && dl == 7)) reinterpret_cast<uint16_t*>(dst)[1] = (uint16_t)(v >> 16);
+#else
+				if (!odd && dl == 7) reinterpret_cast<uint16_t*>(dst)[0] = (uint16_t)v;             // low half-word: the next tile owns the high one
+				else if (odd && dl == 0) reinterpret_cast<uint16_t*>(dst)[1] = (uint16_t)(v >> 16);  // high half-word: the previous tile owns the low one
+				else *dst = v;
+#endif
+			}
+#ifdef LAB_TILE_MASKS
+			}
+#endif
+		}
+		{
+			// edge bytes of the strong pixels (the resolve rounds add the promoted ones): lane = (row q, 16-pixel group gi = lanes 2 + 4 gi .. 5 + 4 gi):
+			// one 16-byte store
+			const int q = lane >> 4, gi = lane & 15;
+			const uint32_t* rn = nibw + q * 16 + gi;
+			const uint32_t by = __builtin_amdgcn_alignbit(rn[1], rn[0], 16);
+			const int row = y0 + rr0 + q;
+			const int x = tileX * kSwCols + gi * 16;
+#ifdef LAB_GUARD_BYTES
+			if (gi < 15 && row < H && x + 8 <= a.So && a.ksize == 77) {
+#else
+			if (gi < 15 && row < H && x + 8 <= a.So) {
+#endif
+				uint8_t* dst = obase + (size_t)row * a.So + x;
+				const uint32_t b0 = nibble_bytes((by >> 4) & 0xfu), b1 = nibble_bytes((by >> 12) & 0xfu);
+#ifdef LAB_CLEAN_X4
+				if (fullRow) {
+					const uint32_t b2 = nibble_bytes((by >> 20) & 0xfu), b3 = nibble_bytes(by >> 28);
+					typedef uint32_t v4u __attribute__((ext_vector_type(4)));
+					const v4u bv = { b0, b1, b2, b3 };
+					#ifdef LAB_NT_BYTES
+					asm volatile("global_store_dwordx4 %0, %1, off nt" :: "v"(dst), "v"(bv) : "memory");
+#else
+					asm volatile("global_store_dwordx4 %0, %1, off" :: "v"(dst), "v"(bv) : "memory");
+#endif
+				}
+				else
+#endif
+				if (x + 16 <= a.So) {
+					const uint32_t b2 = nibble_bytes((by >> 20) & 0xfu), b3 = nibble_bytes(by >> 28);
+					*reinterpret_cast<uint4*>(dst) = make_uint4(b0, b1, b2, b3);
+				}
+				else *reinterpret_cast<uint2*>(dst) = make_uint2(b0, b1); // So % 8 == 0: an 8-column tail
+			}
+		}
+		__builtin_amdgcn_wave_barrier();
+		zero_nibbles();
+	};
 
 	// One row step: push input row yin = y0 - 2 + it  ->  gradient row yc = yin - 1 = y0 + (it - 3)  ->  ring slot (it - 3) & 3.
 	// After the steps with odd it >= 5 the rows 2j, 2j + 1 (j = (it - 5) / 2) of the tile have all three g rows of their neighbourhood
@@ -185,8 +383,18 @@ __global__ __launch_bounds__(WAVES * 64, 8) void canny_swar_tile_kernel(CannyArg
 		constexpr int sNew = (PH + 1) & 3;                    // ring slot of the gradient row produced now
 		constexpr int aNew = (PH + 1) & 1;                    // its aux slot = its row parity
 		const int yin = y0 - 2 + it;
+#if defined(LAB_EARLY_FLUSH) && !defined(LAB_NO_FLUSH)
+		// the stores of the previous four rows are issued BEFORE this step's loads: vmcnt counts in order, so the first wait on a load that was
+		// issued after a store also waits for that store's acknowledgement -- a whole step lies between these stores and that wait
+		if constexpr (PH == 0) { if (it >= 8) flush(it - 8); }
+#endif
+#ifdef LAB_PF2
 		const uint32_t m = nb[PH & 1][0], l = nb[PH & 1][1], r = nb[PH & 1][2];
-		load(yin + 2, nb[PH & 1][0], nb[PH & 1][1], nb[PH & 1][2]); // prefetch
+		load(yin + 2, nb[PH & 1][0], nb[PH & 1][1], nb[PH & 1][2]); // prefetch, two rows ahead
+#else
+		const uint32_t m = nm, l = nl, r = nr;
+		load(yin + 1, nm, nl, nr); // prefetch
+#endif
 
 		// ---- dense stage: packed pairs straight from the raw dwords (one v_perm each) ----
 		uint32_t A[2], L[3];
@@ -197,23 +405,42 @@ __global__ __launch_bounds__(WAVES * 64, 8) void canny_swar_tile_kernel(CannyArg
 		L[2] = __builtin_amdgcn_perm(r, m, 0x0c040c03u);      // (p3, p4)
 		uint32_t gq[2], aux[2];
 		uint32_t (&hyTop)[2] = hy[PH & 1]; // hy of row yin-2; overwritten with hy of row yin
+#ifdef LAB_DENSE2
 #pragma unroll
 		for (int k = 0; k < 2; ++k) {
 			const uint32_t Lk = L[k], Rk = L[k + 1], Ck = A[k];
 			const uint32_t hyN = lshl1_add(Ck, Lk + Rk);               // I[x-1] + 2 I[x] + I[x+1]           (<= 1020)
 			const uint32_t d = xad(Lk, k255, Rk);                      // I[x+1] - I[x-1] + 255    ((L ^ 0xff) = 255 - L per half)
-			const uint32_t gxb = add3(P[k], d, k4);                    // gx + 1024                (P carries 3 x 255)
+			const uint32_t gxb = add3(P[k], d, k4);                    // gx + 1024   (P carries 3 x 255)
 			P[k] = lshl1_add(d, dprev[k]);
 			dprev[k] = d;
-			const uint32_t gyb = xad(hyTop[k], k3ff, hyN);             // gy + 1023                ((t ^ 0x3ff) = 1023 - t: t <= 1020)
+			const uint32_t gyb = xad(hyTop[k], k3ff, hyN);             // gy + 1023   ((t ^ 0x3ff) = 1023 - t: t <= 1020)
 			hyTop[k] = hyN;
 			const uint32_t mx = pk_max_u16(gxb, kBias2k - gxb);        // |gx| + 1024
 			const uint32_t my = pk_max_u16(gyb, 0x07fe07feu - gyb);    // |gy| + 1023
 			gq[k] = add3(mx, my, k1);                                  // g + 2048
 			// bit 10 of gxb ^ gyb = sign(gx) != sign(gy), except that gy = 0 reads as negative: a pixel with gy = 0 is in the horizontal class
-			// (or has g = 0) and the sign only selects between the two diagonals
+			// (or has g = 0), the sign only selects between the two diagonals
+			aux[k] = bfi(kBias1k, gxb ^ gyb, mx);
+		}
+#else
+#pragma unroll
+		for (int k = 0; k < 2; ++k) {
+			const uint32_t Lk = L[k], Rk = L[k + 1], Ck = A[k];
+			const uint32_t s = Lk + Rk;
+			const uint32_t hyN = s + twice(Ck);                        // I[x-1] + 2 I[x] + I[x+1]           (<= 1020)
+			const uint32_t d = (Rk | kBiasD) - Lk;                     // I[x+1] - I[x-1] + 256
+			const uint32_t gxb = P[k] + d;                             // gx + 1024
+			P[k] = dprev[k] + twice(d);
+			dprev[k] = d;
+			const uint32_t gyb = (hyN | kBias1k) - hyTop[k];           // gy + 1024
+			hyTop[k] = hyN;
+			const uint32_t mx = pk_max_u16(gxb, kBias2k - gxb);        // |gx| + 1024
+			const uint32_t my = pk_max_u16(gyb, kBias2k - gyb);        // |gy| + 1024
+			gq[k] = mx + my;                                           // g + 2048
 			aux[k] = bfi(kBias1k, gxb ^ gyb, mx);                      // bits 0..9 |gx|, bit 10 = ((gx ^ gy) < 0)
 		}
+#endif
 		const int yc = yin - 1;
 		if (borderTile) { // one wave-uniform test per row; interior tiles skip all of it (the empty asm keeps the compiler from turning the branch into selects)
 			asm volatile("" : "+v"(gq[0]), "+v"(gq[1]));
@@ -221,7 +448,11 @@ __global__ __launch_bounds__(WAVES * 64, 8) void canny_swar_tile_kernel(CannyArg
 #pragma unroll
 			for (int k = 0; k < 2; ++k) gq[k] = bfi(okm[k] & rowm, gq[k], kBias2k);
 		}
+#ifdef LAB_NO_LDSW
+		if (a.ksize == 77) obase[lane + it] = (uint8_t)(gq[0] + gq[1] + aux[0] + aux[1]);
+#else
 		*reinterpret_cast<uint2*>(ring + sNew * kRowB + lane8) = make_uint2(gq[0], gq[1]);
+#endif
 
 		// ---- sparse stage: NMS + classification of the row pair (2j, 2j + 1) on its candidates ----
 		if (NMS) {
@@ -230,6 +461,38 @@ __global__ __launch_bounds__(WAVES * 64, 8) void canny_swar_tile_kernel(CannyArg
 			__builtin_amdgcn_wave_barrier();
 			const int total = (int)listCount;
 			const uint8_t* const list = rest + kList;
+#if defined(LAB_NO_NMS)
+#elif defined(LAB_NMS2)
+#pragma nounroll
+			for (int base = 0; base < total; base += 64) {
+				const int jx = base + lane;
+				if (jx < total) {
+					const uint32_t e = *reinterpret_cast<const uint16_t*>(list + 2 * jx);
+					const uint32_t gc = *reinterpret_cast<const uint16_t*>(ring + sA * kRowB + e);
+					const uint32_t au = *reinterpret_cast<const uint16_t*>(rest + kAux + e);
+					const uint32_t cAbs = vaddk<sA * kRowB>(e);
+					const uint32_t ax = vandk<0x3ffu>(au);
+					const uint32_t aym = vsub(gc, ax);                       // |gy| + 2048
+					const uint32_t q1 = vlshr<16>(vmul24(ax, tanQ));         // floor(27145 |gx| / 65536): k1 <=> |gy| <= q1 (|gx| > 0; no candidate has |gx| = |gy| = 0)
+					const uint32_t w1 = vsub(aym, q1);                       // k1 <=> w1 <= 2048
+					const uint32_t nm1 = vashr<31>(vsubk<2048u>(w1));        // all ones: not k1
+					const uint32_t w2 = vsub(w1, vadd(ax, ax));              // k2 <=> w2 <= 2048  (158217 = 27145 + 2^17)
+					const uint32_t m2 = vashr<31>(vaddk<0xfffff7ffu>(w2));   // all ones: k2   (w2 - 2049 < 0)
+					const uint32_t s4 = vand(vandk<4u>(vlshr<8>(au)), nm1);  // 4: diagonal with (gx ^ gy) < 0
+					const uint32_t dd = vand(vsubk<2u>(s4), m2);             // +2 / -2 columns on top of the row step, 0 for the vertical class
+					const uint32_t delta = vadd(vandk<512u>(nm1), dd);       // 2 | 510 | 514 | 512: the neighbours are centre -+ delta
+					const uint32_t n1a = vandk<0x7ffu>(vsub(cAbs, delta)), n2a = vandk<0x7ffu>(vadd(cAbs, delta));
+					const uint32_t n1 = *reinterpret_cast<const uint16_t*>(ring + n1a), n2 = *reinterpret_cast<const uint16_t*>(ring + n2a);
+					const uint32_t mx = vmax16(n1, n2);
+					const uint32_t wk = vlshr<31>(vnot(vsub(gc, mx)));       // 1: not suppressed (gc >= both)
+					const uint32_t b4 = vandk<4u>(vlshr<29>(vsub(tHighV, gc)));  // 4: strong
+					const uint32_t sh = vadd(vor(vandk<3u>(vlshr<1>(e)), vandk<24u>(e)), b4);
+					const uint32_t val = vshl(wk, sh);
+					const uint32_t addr = vandk<0xfcu>(vlshr<3>(cAbs));
+					atomicOr(reinterpret_cast<uint32_t*>(rest + kNib + addr), val);
+				}
+			}
+#else
 #pragma nounroll
 			for (int base = 0; base < total; base += 64) {
 				const int jx = base + lane;
@@ -274,74 +537,22 @@ __global__ __launch_bounds__(WAVES * 64, 8) void canny_swar_tile_kernel(CannyArg
 					}
 				}
 			}
+#endif
 			listCount = 0;
-			if constexpr (PH == 3) {
-				// rows 4m .. 4m + 3 of the tile are classified: masks and edge bytes leave in their final global layout
-				const int rr0 = it - 7;                          // tile row of nibble row 0
-				__builtin_amdgcn_wave_barrier();
-				const uint32_t* const nibw = reinterpret_cast<const uint32_t*>(rest + kNib);
-				{
-					// masks: lanes 0..31 the U rows (weak & ~strong), 32..63 the E rows (strong), whole row segments per store instruction.  Global
-					// dword d0 + dl = the pixels of lanes [8 dl + 2, 8 dl + 10) (even tiles) or [8 dl - 2, 8 dl + 6) (odd): 8 result bytes that start
-					// in the middle of a dword (the bytes of a neighbouring tile's columns, or of the next row, end in a half-word that is not stored)
-					const int mi = lane >> 5, q = (lane >> 3) & 3, dl = lane & 7;
-					const uint32_t* rn = nibw + q * 16 + 2 * dl - odd;
-					const uint32_t d0w = rn[0], d1w = rn[1], d2w = rn[2];
-					const uint32_t nsh = (uint32_t)mi * 4u;                          // U: low nibbles, E: high nibbles
-					uint32_t th[2];
-#pragma unroll
-					for (int hh = 0; hh < 2; ++hh) {
-						const uint32_t by = hh ? __builtin_amdgcn_alignbit(d2w, d1w, 16) : __builtin_amdgcn_alignbit(d1w, d0w, 16);  // 4 lanes = 16 pixels
-						uint32_t t = (by >> nsh) & 0x0f0f0f0fu;
-						t = (t | (t >> 4)) & 0x00ff00ffu;
-						th[hh] = (t | (t >> 8)) & 0x0000ffffu;
-					}
-					const uint32_t v = th[0] | (th[1] << 16);
-					const int row = y0 + rr0 + q, gd = d0 + dl;
-					if (row < H && gd < a.wb) {
-						uint32_t* dst = (mi ? ebase : ubase) + (size_t)row * a.wb + gd;
-						if (!odd && dl == 7) reinterpret_cast<uint16_t*>(dst)[0] = (uint16_t)v;             // low half-word: the next tile owns the high one
-						else if (odd && dl == 0) reinterpret_cast<uint16_t*>(dst)[1] = (uint16_t)(v >> 16);  // high half-word: the previous tile owns the low one
-						else *dst = v;
-					}
-				}
-				{
-					// edge bytes of the strong pixels (the resolve rounds add the promoted ones): lane = (row q, 16-pixel group gi = lanes 2 + 4 gi .. 5 + 4 gi):
-					// one 16-byte store
-					const int q = lane >> 4, gi = lane & 15;
-					const uint32_t* rn = nibw + q * 16 + gi;
-					const uint32_t by = __builtin_amdgcn_alignbit(rn[1], rn[0], 16);
-					const int row = y0 + rr0 + q;
-					const int x = tileX * kSwCols + gi * 16;
-					if (gi < 15 && row < H && x + 8 <= a.So) {
-						uint8_t* dst = obase + (size_t)row * a.So + x;
-						const uint32_t b0 = nibble_bytes((by >> 4) & 0xfu), b1 = nibble_bytes((by >> 12) & 0xfu);
-						if (fullRow) {
-							// (spelled out: with the two tails below in one if / else the compiler merges their common part and emits a 12-byte store plus a
-							// 4-byte store at 16-byte stride -- twice the write requests, every one of them partial: 0.193 -> 0.177 ms per launch)
-							const uint32_t b2 = nibble_bytes((by >> 20) & 0xfu), b3 = nibble_bytes(by >> 28);
-							typedef uint32_t v4u __attribute__((ext_vector_type(4)));
-							const v4u bv = { b0, b1, b2, b3 };
-							asm volatile("global_store_dwordx4 %0, %1, off" :: "v"(dst), "v"(bv) : "memory");
-						}
-						else if (x + 16 <= a.So) {
-							const uint32_t b2 = nibble_bytes((by >> 20) & 0xfu), b3 = nibble_bytes(by >> 28);
-							*reinterpret_cast<uint4*>(dst) = make_uint4(b0, b1, b2, b3);
-						}
-						else *reinterpret_cast<uint2*>(dst) = make_uint2(b0, b1); // So % 8 == 0: an 8-column tail
-					}
-				}
-				__builtin_amdgcn_wave_barrier();
-				zero_nibbles();
-			}
+#if !defined(LAB_NO_FLUSH) && !defined(LAB_EARLY_FLUSH)
+			if constexpr (PH == 3) flush(it - 7);
+#endif
 			__builtin_amdgcn_wave_barrier();
 		}
 
 		// aux of the new row (its slot held the aux of row 2j until the NMS above was done with it)
+#ifndef LAB_NO_LDSW
 		*reinterpret_cast<uint2*>(rest + kAux + aNew * kRowB + lane8) = make_uint2(aux[0], aux[1]);
+#endif
 
 		// ---- candidates of the new row join the list: entry = (row parity << 9) | byte offset inside a ring row, position = scalar
 		// popcount of the earlier slots (rides in as the mbcnt base) + mbcnt of the slot's own mask; the store is exec-masked ----
+#ifndef LAB_NO_LIST
 		if (it >= 3 && it < kSwRows + 3) {   // gradient rows y0 .. y0 + kSwRows - 1 only (uniform)
 			uint8_t* const listw = rest + kList;
 			uint32_t cnt = listCount;
@@ -351,14 +562,22 @@ __global__ __launch_bounds__(WAVES * 64, 8) void canny_swar_tile_kernel(CannyArg
 				const uint32_t gp = (p & 1) ? (gk >> 16) : (gk & 0xffffu);
 				const bool c = gp > thrV;
 				const uint64_t mk = __ballot(c);
+#ifdef LAB_LIST2
+				if (c) {
+					const uint32_t rk = __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, 0u));
+					*reinterpret_cast<uint16_t*>(listw + lshl1_add_s(rk, __builtin_amdgcn_readfirstlane(cnt * 2u))) = (uint16_t)((aNew << 9) | (lane * 8 + 2 * p));
+				}
+#else
 				if (c) {
 					const uint32_t rk = __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, cnt));
 					*reinterpret_cast<uint16_t*>(listw + twice(rk)) = (uint16_t)((aNew << 9) | (lane * 8 + 2 * p));
 				}
+#endif
 				cnt += (uint32_t)__popcll(mk);
 			}
 			listCount = __builtin_amdgcn_readfirstlane(cnt);
 		}
+#endif
 	};
 
 	{
@@ -374,7 +593,23 @@ __global__ __launch_bounds__(WAVES * 64, 8) void canny_swar_tile_kernel(CannyArg
 			step(std::integral_constant<int, 2>{}, F{}, it + 2);
 			step(std::integral_constant<int, 3>{}, T{}, it + 3);
 		}
+#if defined(LAB_EARLY_FLUSH) && !defined(LAB_NO_FLUSH)
+		flush(kSwRows - 4);
+#endif
 	}
+#ifdef LAB_PAIRS
+	__builtin_amdgcn_wave_barrier();
+	}
+#endif
+#ifdef LAB_PAIRS2
+	__syncthreads();
+	if (wave == (hasPartner ? 1 : 0)) {
+		const int row = y0 + (lane >> 1), mi = lane & 1;
+		const uint32_t v = (uint32_t)carry[lane] | (hasPartner ? (uint32_t)carry[64 + lane] << 16 : 0u);
+		const int gd = ((15 * (2 * pairX)) >> 1) + 7;
+		if (row < H && gd < a.wb) ((mi ? ebase : ubase) + (size_t)row * a.wb)[gd] = v;
+	}
+#endif
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -386,7 +621,15 @@ static hipError_t launch_swar(const CannyArgs& a0, int frames, bool gap, hipStre
 	a.tilesY = (a.H + kRows - 1) / kRows;
 	a.blockRows = (a.tilesY + kWaves - 1) / kWaves;
 	a.groups = a.blockRows * frames;
+#if defined(LAB_PAIRS2)
+	a.blockRows = a.tilesY;
+	a.groups = a.blockRows * frames;
+	dim3 grid(8 * ((a.groups + 7) / 8) * ((a.tilesX + 1) / 2));
+#elif defined(LAB_PAIRS)
+	dim3 grid(8 * ((a.groups + 7) / 8) * ((a.tilesX + 1) / 2));
+#else
 	dim3 grid(8 * ((a.groups + 7) / 8) * a.tilesX);
+#endif
 	dim3 block(kWaves * 64);
 	if (gap) hipLaunchKernelGGL((canny_swar_tile_kernel<true, kWaves, kRows>), grid, block, 0, stream, a);
 	else hipLaunchKernelGGL((canny_swar_tile_kernel<false, kWaves, kRows>), grid, block, 0, stream, a);
@@ -399,7 +642,11 @@ hipError_t launch_canny_tiles_swar(const CannyArgs& a0, int frames, bool gap, hi
 	// frames.  Measured per 32 x 4K launch (same run): 128 rows 0.232 ms, 64 rows 0.202 ms, 32 rows 0.192 ms, 16 / 24 rows the same as 32 within 1 % -- the
 	// 4-row halo costs 12.5 % more gradient rows than at 64 rows, but twice as many, shorter waves balance the SIMDs better at the end of
 	// the launch (a tile's time follows its candidate count).
+#ifdef LAB_PAIRS2
+	return launch_swar<2, 32>(a0, frames, gap, stream);
+#else
 	return launch_swar<1, 32>(a0, frames, gap, stream);
+#endif
 }
 
-} // namespace compvhip
+} // namespace compvhip_lab_ns
