@@ -88,16 +88,51 @@ class FrameSynth:
 # ------------------------------------------------------------------------------------------------------------------------------------
 # CPU baseline
 # ------------------------------------------------------------------------------------------------------------------------------------
-def _ref_worker(args):
-    """One process of the frame-parallel baseline: its own CompV instance with `threads` workers, its own frames."""
-    threads, first_seed, n, W, H = args
-    from oracle_bindings import RefShim, synth_frame
-    ref = RefShim(threads)
-    frames = np.stack([synth_frame(W, H, first_seed + f) for f in range(n)])
-    ref.bench_pipeline(frames[:1], T_LOW, T_HIGH, THETA_DEG, SHT_THRESHOLD)   # warm the pool and the scratch buffers
-    t0 = time.time()
-    ms, e, l = ref.bench_pipeline(frames, T_LOW, T_HIGH, THETA_DEG, SHT_THRESHOLD)
-    return t0, time.time(), n
+def _ref_worker(threads, first_seed, n, repeats, W, H, barrier, queue):
+    """One process of the frame-parallel baseline: its own CompV instance with `threads` workers, its own frames.  Import, library start-up and
+    frame synthesis happen BEFORE the cross-process barrier; the clock runs over `repeats` passes over the worker's n frames only."""
+    try:
+        from oracle_bindings import RefShim, synth_frame
+        ref = RefShim(threads)
+        frames = np.stack([synth_frame(W, H, first_seed + f) for f in range(n)])
+        ref.bench_pipeline(frames[:1], T_LOW, T_HIGH, THETA_DEG, SHT_THRESHOLD)   # warm the pool and the scratch buffers
+        barrier.wait()
+        t0 = time.time()
+        for _ in range(repeats):
+            ref.bench_pipeline(frames, T_LOW, T_HIGH, THETA_DEG, SHT_THRESHOLD)
+        queue.put((t0, time.time(), n * repeats))
+    except Exception as e:  # a worker that dies must not leave the others at the barrier for ever
+        try:
+            barrier.abort()
+        except Exception:
+            pass
+        queue.put(("error", repr(e), 0))
+
+
+def frame_parallel_baseline(W, H, threads_per_proc, ms_per_frame_guess, cores, work_s=2.5):
+    """P processes x T threads over independent frames, all started together (barrier) and each with >= work_s seconds of frames."""
+    import multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    tt = max(1, threads_per_proc)
+    procs = max(1, min(cores // tt, 32))
+    n = 4
+    repeats = max(2, int(work_s * 1000.0 / max(ms_per_frame_guess * 1.5, 1e-3) / n + 0.5))
+    barrier = ctx.Barrier(procs)
+    queue = ctx.Queue()
+    ps = [ctx.Process(target=_ref_worker, args=(tt, 20000 + 100 * i, n, repeats, W, H, barrier, queue)) for i in range(procs)]
+    for pr in ps:
+        pr.start()
+    res = [queue.get(timeout=600) for _ in ps]
+    for pr in ps:
+        pr.join(timeout=60)
+    bad = [r for r in res if r[0] == "error"]
+    if bad:
+        raise RuntimeError("frame-parallel worker failed: %s" % bad[0][1])
+    span = max(r[1] for r in res) - min(r[0] for r in res)
+    frames = sum(r[2] for r in res)
+    return {"value": round(frames * W * H / span / 1e6, 2), "unit": "Mpixels/s", "processes": procs, "threads_per_process": tt, "cores": procs * tt,
+            "frames": frames, "span_s": round(span, 3), "start_skew_s": round(max(r[0] for r in res) - min(r[0] for r in res), 4),
+            "note": "all workers released by one cross-process barrier after start-up; throughput = frames / (last finish - first start)"}
 
 
 def cpu_baseline(W, H, budget_s=20.0):
@@ -129,18 +164,10 @@ def cpu_baseline(W, H, budget_s=20.0):
                "sample": "%d frames %dx%d, CompV AVX2 intrinsics path (COMPV_ASM=0), %d threads (best of sweep), Canny(59,119)+SHT(1deg,100)" % (n, W, H, ref.threads),
                "ms_per_frame": round(ms / n, 3), "ms_per_frame_by_threads": sweep}
         # frame-parallel: CompV's row-band pool stops scaling at ~8 threads, independent frames do not -- P processes x T threads
-        # ("all host cores via row-band / frame-parallel threads").  Throughput = frames / (last finish - first start).
+        # ("all host cores via row-band / frame-parallel threads")
         try:
-            import multiprocessing as mp
             tt = max(1, min(best, 8))
-            procs = max(1, min(cores // tt, 32))
-            per = max(1, int(0.5 * budget_s * 1000.0 / max(sweep[best] * (best / tt if best > tt else 1.0), 1e-3) / 2))
-            per = min(per, 8)
-            with mp.get_context("spawn").Pool(procs) as pool:
-                res = pool.map(_ref_worker, [(tt, 20000 + 100 * i, per, W, H) for i in range(procs)])
-            span = max(r[1] for r in res) - min(r[0] for r in res)
-            out["frame_parallel"] = {"value": round(procs * per * W * H / span / 1e6, 2), "unit": "Mpixels/s", "processes": procs,
-                                     "threads_per_process": tt, "cores": procs * tt, "frames": procs * per}
+            out["frame_parallel"] = frame_parallel_baseline(W, H, tt, sweep[best] * (best / tt if best > tt else 1.0), cores)
         except Exception as e:  # reporting only
             out["frame_parallel"] = {"error": str(e)}
         return out
@@ -213,10 +240,100 @@ def committed_counters(W, H, F):
         return None, "no committed PMC pass (%s)" % e
 
 
+def check_batch(torch, q, seeds, golden, W, H, line_cap, dev):
+    """One lane's edge maps / line lists / counts of a whole batch against the reference-derived fixture (real CompV: edge-map MD5, edge count,
+    line count, strength sum, order-independent line-set hash).  Returns (frames checked, edge pixels, lines); raises on the first mismatch."""
+    F = len(seeds)
+    counts = q["counts"].cpu().numpy()
+    if int(counts.max()) > line_cap:
+        raise RuntimeError("a frame produced %d lines, more than the line capacity %d: its line set would be an arbitrary subset" % (int(counts.max()), line_cap))
+    n_e = (q["edges"] != 0).sum(dim=(1, 2)).cpu().numpy()
+    if golden is None:
+        return 0, int(n_e.sum()), int(counts.sum())
+    ln = q["lines"].to(torch.int64)
+    idx = torch.arange(line_cap, device=dev)[None, :]
+    valid = idx < q["counts"].to(torch.int64)[:, None]
+    st = torch.where(valid, ln[:, :, 2], torch.zeros_like(ln[:, :, 2]))
+    hv = ((W + H) - ln[:, :, 3] + 32768) * 1000003 + ln[:, :, 4] * 7919 + ln[:, :, 2] * 31337
+    hv = torch.where(valid, hv, torch.zeros_like(hv)).sum(dim=1).cpu().numpy()
+    sums = st.sum(dim=1).cpu().numpy()
+    edges_host = q["edges"].cpu().numpy()
+    for f in range(F):
+        g = golden[seeds[f]]
+        got = {"canny_md5": hashlib.md5(edges_host[f].tobytes()).hexdigest(), "edges": int(n_e[f]), "lines": int(counts[f]),
+               "sum_strength": int(sums[f]), "line_hash": "%016x" % (int(hv[f]) & M64)}
+        exp = {k: g[k] for k in got}
+        if got != exp:
+            raise RuntimeError("frame seed %d (frame %d of its batch) differs from the CompV reference: got %r, expected %r" % (seeds[f], f, got, exp))
+    return F, int(n_e.sum()), int(counts.sum())
+
+
+def extra_config(torch, capi, sharding, ctx, dev, W, H, F, NB, steps, warmup, reps, fixture):
+    """The same pipeline at another frame size (north_star: throughput on 1080p as well as 4K), same two-lane asynchronous mode, every frame of the
+    rotating batches checked against its own reference-derived fixture after the timed region."""
+    synth = FrameSynth(torch, dev, W, H)
+    seeds = [[sharding.frame_seed(b * F + f) for f in range(F)] for b in range(NB)]
+    blocks = [synth.batch(sd) for sd in seeds]
+    del synth
+    line_cap = 1 << 15
+    lanes = [{"plan": capi.Plan(ctx, W, H, W, F, THETA_DEG), "edges": torch.empty_like(blocks[0]),
+              "lines": torch.zeros((F, line_cap, 5), dtype=torch.int32, device=dev), "counts": torch.zeros(F, dtype=torch.int32, device=dev),
+              "stream": torch.cuda.Stream(device=dev)} for _ in range(2)]
+    try:
+        def go(q, b):
+            return q["plan"].pipeline_async(blocks[b].data_ptr(), T_LOW, T_HIGH, SHT_THRESHOLD, 0, q["edges"].data_ptr(), q["lines"].data_ptr(), line_cap,
+                                            q["counts"].data_ptr(), q["stream"].cuda_stream)
+        k = [0]
+
+        def run(n):
+            pend = []
+            for _ in range(n):
+                q = lanes[k[0] % 2]
+                pend.append((q, go(q, k[0] % NB)))
+                k[0] += 1
+                if len(pend) > 4:
+                    q0, t0 = pend.pop(0)
+                    q0["plan"].wait(t0)
+            for q0, t0 in pend:
+                q0["plan"].wait(t0)
+        run(warmup)
+        torch.cuda.synchronize()
+        el = []
+        for _ in range(max(1, reps)):
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            run(steps)
+            torch.cuda.synchronize()
+            el.append(time.perf_counter() - t0)
+        e = sorted(el)[len(el) // 2]
+        golden = None
+        if fixture and os.path.exists(fixture):
+            g = json.load(open(fixture))
+            assert (g["W"], g["H"], g["tLow"], g["tHigh"], g["threshold"]) == (W, H, T_LOW, T_HIGH, SHT_THRESHOLD)
+            golden = {x["seed"]: x for x in g["frames"]}
+        checked = 0
+        for b0 in range(0, NB, 2):
+            todo = [(lanes[i], b0 + i) for i in range(2) if b0 + i < NB]
+            tickets = [(q, go(q, b)) for q, b in todo]
+            for q, t in tickets:
+                q["plan"].wait(t)
+            torch.cuda.synchronize()
+            for q, b in todo:
+                checked += check_batch(torch, q, seeds[b], golden, W, H, line_cap, dev)[0]
+        return {"workload": "batched %dx%d uint8 frames, same pipeline and parameters; %d distinct frames as %d batches of %d" % (W, H, NB * F, NB, F),
+                "value": round(F * W * H * steps / e / 1e6, 1), "unit": "Mpixels/s", "ms_per_step": round(e / steps * 1e3, 4), "steps": steps, "reps": len(el),
+                "frames_per_step": F,
+                "verified": ({"frames_checked": checked, "against": os.path.relpath(fixture, ROOT) + " (real CompV, tests/golden/make_golden_batch.py fhd)"}
+                             if golden is not None else "no fixture")}
+    finally:
+        for q in lanes:
+            q["plan"].close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=64, help="timed steps per repetition (64 x 0.7 ms: the two-lane pipeline is in steady state for all but its first and last step)")
+    ap.add_argument("--steps", type=int, default=512, help="timed steps per repetition (512 x 0.66 ms x 3 repetitions: a second of timed GPU work)")
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--frames-per-gpu", type=int, default=32)   # BASELINE config 4: 256 frames over 8 GPUs
     ap.add_argument("--batches", type=int, default=8, help="distinct resident batches the steps rotate over (8 x 32 = config 4's 256 frames)")
@@ -226,7 +343,7 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the host_api / kht objects")
     ap.add_argument("--no-verify", action="store_true", help="experiment only: skip the golden check of all frames (the JSON line says so)")
     ap.add_argument("--no-kernel-events", action="store_true", help="experiment: no per-kernel HIP events in the timed steps")
-    ap.add_argument("--reps", type=int, default=5, help="repetitions of the timed K-step loop; the MEDIAN repetition is reported")
+    ap.add_argument("--reps", type=int, default=3, help="repetitions of the timed K-step loop; the MEDIAN repetition is reported")
     ap.add_argument("--inflight", type=int, default=2,
                     help="batches in flight: N plans (own buffers) on N HIP streams take the steps in turn, so the latency-bound kernels of one "
                          "batch (key sort, decode, hysteresis rounds) run under the wide kernels of the other; 1 = one stream, kernels never overlap")
@@ -324,6 +441,11 @@ def main():
         pend = []
         for _ in range(k):
             q = lanes[step_no[0] % len(lanes)]
+            if args.scatter:
+                # ONE step in flight per lane: a step overwrites the lane's receive buffer and its result arrays, which must stay untouched until
+                # the previous step on that lane has been waited for (a replayed step re-reads its input; the gather reads its results)
+                while len(pend) >= len(lanes):
+                    finish(*pend.pop(0))
             pend.append((q, enqueue(q, step_no[0])))
             step_no[0] += 1
             if len(pend) > max(1, min(args.depth, 3)) * len(lanes):   # the library keeps at most 4 steps of a plan in flight
@@ -387,9 +509,10 @@ def main():
     for q in lanes:
         q["plan"].set_timing(0)
     breakdown = {}
+    iso_steps = min(args.steps, 64)
     if rank == 0 and not args.no_kernel_events:
         plan.set_timing(1)
-        for k in range(args.steps):
+        for k in range(iso_steps):
             one_sync_step(lanes[0], k % NB)
             collect(breakdown, [plan])
     plan.set_timing(0)
@@ -406,7 +529,6 @@ def main():
         golden = json.load(open(gpath))
         assert (golden["W"], golden["H"], golden["tLow"], golden["tHigh"], golden["threshold"]) == (W, H, T_LOW, T_HIGH, SHT_THRESHOLD)
         golden = {g["seed"]: g for g in golden["frames"]}
-    barrier_rows = W + H
     total_edges = 0
     total_lines = 0
     lines_frame0 = None
@@ -423,32 +545,12 @@ def main():
                 q["plan"].wait(t)
         torch.cuda.synchronize()
         for q, b in todo:
-            counts = q["counts"].cpu().numpy()
-            if int(counts.max()) > line_cap:
-                raise RuntimeError("a frame produced %d lines, more than the line capacity %d: its line set would be an arbitrary subset" % (int(counts.max()), line_cap))
-            n_e = (q["edges"] != 0).sum(dim=(1, 2)).cpu().numpy()
-            total_edges += int(n_e.sum())
-            total_lines += int(counts.sum())
+            c, ne, nl = check_batch(torch, q, block_seeds[b], golden, W, H, line_cap, dev)
+            checked += c
+            total_edges += ne
+            total_lines += nl
             if b == 0:
-                lines_frame0 = int(counts[0])
-            if golden is None:
-                continue
-            ln = q["lines"].to(torch.int64)
-            idx = torch.arange(line_cap, device=dev)[None, :]
-            valid = idx < q["counts"].to(torch.int64)[:, None]
-            st = torch.where(valid, ln[:, :, 2], torch.zeros_like(ln[:, :, 2]))
-            hv = (barrier_rows - ln[:, :, 3] + 32768) * 1000003 + ln[:, :, 4] * 7919 + ln[:, :, 2] * 31337
-            hv = torch.where(valid, hv, torch.zeros_like(hv)).sum(dim=1).cpu().numpy()
-            sums = st.sum(dim=1).cpu().numpy()
-            edges_host = q["edges"].cpu().numpy()
-            for f in range(F):
-                g = golden[block_seeds[b][f]]
-                got = {"canny_md5": hashlib.md5(edges_host[f].tobytes()).hexdigest(), "edges": int(n_e[f]), "lines": int(counts[f]),
-                       "sum_strength": int(sums[f]), "line_hash": "%016x" % (int(hv[f]) & M64)}
-                exp = {k: g[k] for k in got}
-                if got != exp:
-                    raise RuntimeError("frame seed %d (batch %d, frame %d) differs from the CompV reference: got %r, expected %r" % (block_seeds[b][f], b, f, got, exp))
-                checked += 1
+                lines_frame0 = int(q["counts"][0].item())
     if golden is None and len(lanes) > 1 and not args.no_verify:
         # no fixture: at least the lanes must agree on one common batch
         for q in lanes:
@@ -546,6 +648,16 @@ def main():
             vf = valu_floor("canny_tile_kernel", rc["ms_per_launch"])
             if vf:
                 rc["valu_issue"] = vf
+        def stage_roof(names, nbytes, what):
+            ms = sum(v[0] for k, v in breakdown.items() if k in names) / max(iso_steps, 1)
+            if ms <= 0:
+                return None
+            ach = nbytes / (ms * 1e-3) / 1e9
+            return {"stage": what, "kernels": sorted(k for k in breakdown if k in names), "bound": "hbm", "ms_per_step": round(ms, 4), "algorithmic_bytes": int(nbytes),
+                    "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(ach / HBM_PEAK_GBS, 4),
+                    "timing": "sum of the stage's launches in the single-stream instrumented pass (HIP events), one batch per step"}
+        canny_stage = {"canny_tile_kernel", "canny_resolve_kernel", "canny_mean_thresholds", "otsu_kernels"}
+        sht_stage = {k for k in breakdown if k.startswith("sht_")}
         out = {
             "metric": "Mpixels/s Sobel->Canny->HoughSHT on 4K uint8",
             "value": round(value, 1), "unit": "Mpixels/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -567,9 +679,12 @@ def main():
             "verified": ({"frames_checked": checked, "against": "tests/golden/golden_batch.json (real CompV: edge-map MD5, edge count, line count, strength sum, line-set hash)",
                           "mode": "two lanes in flight, asynchronous steps" if overlapped else "one lane"} if golden is not None else verify_note),
             "roofline": roofline, "roofline_canny": rc,
+            # the same algorithmic bytes priced against the whole STAGE (every launch of it), not one kernel
+            "roofline_stage_canny": stage_roof(canny_stage, alg["canny_tile_kernel"], "Sobel -> NMS -> hysteresis (tile kernel + resolve rounds), 1 B/px read"),
+            "roofline_stage_sht": stage_roof(sht_stage, alg["sht_vote_kernel"], "edge compaction -> voting -> reduce -> NMS / lines -> sort -> decode, W*H + R*T*4 bytes per frame"),
             # every kernel of a step, from the instrumented pass AFTER the timed steps (same process, same buffers)
-            "kernels_ms_per_step": {k: round(v[0] / args.steps, 4) for k, v in sorted(breakdown.items())},
-            "kernels_ms_per_step_source": "second pass of %d steps, one batch at a time on one stream, HIP events around every launch (not in the timed region)" % args.steps,
+            "kernels_ms_per_step": {k: round(v[0] / iso_steps, 4) for k, v in sorted(breakdown.items())},
+            "kernels_ms_per_step_source": "second pass of %d steps, one batch at a time on one stream, HIP events around every launch (not in the timed region)" % iso_steps,
             "edge_pixels_per_batch": total_edges // NB,
             "lines_frame0": lines_frame0,
             "lines_per_batch": total_lines // NB,
@@ -584,6 +699,12 @@ def main():
                 out["kht"] = kht_figure(capi, ctx, torch, lanes[0], blocks, W, H, F)
             except Exception as e:
                 out["kht"] = {"error": str(e)}
+        if world == 1 and not args.no_extras and (W, H) == (3840, 2160):
+            try:
+                out["configs_extra"] = {"fhd_1920x1080": extra_config(torch, capi, sharding, ctx, dev, 1920, 1080, 32, 2, max(64, args.steps // 2), args.warmup,
+                                                                        args.reps, os.path.join(ROOT, "tests", "golden", "golden_batch_fhd.json"))}
+            except Exception as e:
+                out["configs_extra"] = {"error": str(e)}
         if world == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline(W, H)
@@ -613,7 +734,29 @@ def kht_figure(capi, ctx, torch, lane, blocks, W, H, F):
         dts.append(time.perf_counter() - t0)
     dt = sorted(dts)[len(dts) // 2]
     stages = q["plan"].houghkht_stage_ms()
+    cpu = None
+    try:
+        from oracle_bindings import RefShim, have_refshim
+        if have_refshim():
+            # CompV's own KHT (tests/image/houghkht.cxx loops process() on one object the same way) on this batch's first edge maps, at its best thread count
+            maps = q["edges"][:4].cpu().numpy().copy()
+            sweep = {}
+            ref = None
+            for t in (1, 8, -1):
+                if ref is None:
+                    ref = RefShim(t)
+                else:
+                    ref.reinit(t)
+                ref.bench_kht(maps[:1], 1.0, THETA_DEG, 1)
+                ms, nl = ref.bench_kht(maps, 1.0, THETA_DEG, 1)
+                sweep[ref.threads] = round(ms / len(maps), 3)
+            best = min(sweep, key=sweep.get)
+            cpu = {"ms_per_frame": sweep[best], "cores": best, "kind": "reference", "ms_per_frame_by_threads": sweep, "lines_4_frames": int(nl),
+                   "sample": "%d of the batch's %dx%d edge maps, CompVHoughKht::process (AVX2 / SSE intrinsics path, COMPV_ASM=0), best of the thread sweep" % (len(maps), W, H)}
+    except Exception as e:  # reporting only
+        cpu = {"error": str(e)}
     return {"ms_per_frame": round(dt * 1e3 / F, 3), "ms_per_frame_calls": [round(d * 1e3 / F, 3) for d in dts], "frames": F, "lines_frame0": int(len(res[0][0])),
+            "cpu_baseline": cpu,
             "host_threads": stages.get("threads"),
             "host_share": stages.get("host_share"), "stages_ms_per_frame": stages.get("stages"),
             "note": "compvhip_plan_houghkht on the device edge maps of one batch: one download, host linking on a thread pool pipelined with the GPU stages (subdivision, statistics, voting, peaks) of the previous frames"}

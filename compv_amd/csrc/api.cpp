@@ -124,7 +124,9 @@ struct compvhip_plan {
 	std::vector<KhtScratch*> khtWorkers;
 	double khtStageMs[6] = {}; double khtWallMs = 0.0; int khtThreads = 0;
 	// asynchronous steps (compvhip_plan_pipeline_async / compvhip_plan_wait)
-	struct AsyncStep { bool used = false; hipEvent_t done = nullptr; hipStream_t stream = nullptr; StepParams sp; } steps[kAsyncDepth];
+	// seq: enqueue order; replay: an EARLIER step of the plan was replayed after this one ran -- its outputs may have been overwritten
+	struct AsyncStep { bool used = false; bool replay = false; uint64_t seq = 0; hipEvent_t done = nullptr; hipStream_t stream = nullptr; StepParams sp; } steps[kAsyncDepth];
+	uint64_t stepSeq = 0;
 	// timing
 	int timing = 0; // 0 off, 1 every kernel, 2 canny_tile + sht_vote, 3 sht_vote only, 4 canny_tile only
 	std::vector<hipEvent_t> eventPool;
@@ -958,6 +960,7 @@ static int checkStep(compvhip_plan* p, const StepParams& sp)
 static int enqueueStep(compvhip_plan* p, const StepParams& sp, hipStream_t st, bool clearTimeline)
 {
 	compvhip_ctx* ctx = p->ctx;
+	HIPCHK(ctx, hipSetDevice(ctx->device));   // before the scratch allocation below: the caller's current device may be another GPU
 	const uint8_t* luma = sp.d_in;
 	if (sp.pixfmt != COMPVHIP_FMT_Y) {
 		// samples/hough_lines/main.cxx:102: CompVImage::convertGrayscale in front of everything else
@@ -966,7 +969,6 @@ static int enqueueStep(compvhip_plan* p, const StepParams& sp, hipStream_t st, b
 			if (!p->grayTmp) HIPCHK(ctx, dmalloc(ctx, &p->grayTmp, p->S * p->H * p->frames));
 			gray = p->grayTmp;
 		}
-		HIPCHK(ctx, hipSetDevice(ctx->device));
 		if (p->timing && clearTimeline) timelineClear(p);
 		clearTimeline = false;
 		GrayArgs a;
@@ -982,12 +984,14 @@ static int enqueueStep(compvhip_plan* p, const StepParams& sp, hipStream_t st, b
 	return COMPVHIP_OK;
 }
 
+static int toCartesianImpl(compvhip_plan* p, const compvhip_line* d_lines, const int32_t* d_counts, size_t lineCap, int maxLines, float* d_cart, void* stream);
+
 static int enqueueStepTail(compvhip_plan* p, const StepParams& sp, hipStream_t st)
 {
 	int rc = planShtImpl(p, nullptr, sp.threshold, sp.maxLines, sp.d_lines, sp.lineCap, sp.d_counts, st, false);
 	if (rc) return rc;
 	if (sp.d_cart) {
-		rc = compvhip_plan_to_cartesian(p, sp.d_lines, sp.d_counts, sp.lineCap, sp.d_cart, st);
+		rc = toCartesianImpl(p, sp.d_lines, sp.d_counts, sp.lineCap, sp.maxLines, sp.d_cart, st);   // d_counts = the UNCUT counts; only min(count, lineCap, maxLines) slots were decoded
 		if (rc) return rc;
 	}
 	return COMPVHIP_OK;
@@ -1043,7 +1047,7 @@ static int runStepAsync(compvhip_plan* p, const StepParams& sp, hipStream_t st, 
 	if (rc) return rc;
 	HIPCHK(ctx, hipMemcpyAsync(p->hFlags + 1 + slot, p->flags + (p->roundsUsed - 1), sizeof(int), hipMemcpyDeviceToHost, st));
 	HIPCHK(ctx, hipEventRecord(stp.done, st));
-	stp.used = true; stp.stream = st; stp.sp = sp;
+	stp.used = true; stp.replay = false; stp.seq = ++p->stepSeq; stp.stream = st; stp.sp = sp;
 	*ticket = slot;
 	return COMPVHIP_OK;
 }
@@ -1100,14 +1104,25 @@ int compvhip_plan_wait(compvhip_plan* p, int ticket)
 	HIPCHK(ctx, hipSetDevice(ctx->device));
 	HIPCHK(ctx, hipEventSynchronize(stp.done));
 	stp.used = false;
-	if (p->hFlags[1 + ticket] == 0) return COMPVHIP_OK; // the speculative rounds reached the fixed point (the usual case)
+	if (p->hFlags[1 + ticket] == 0 && !stp.replay) return COMPVHIP_OK; // the speculative rounds reached the fixed point (the usual case)
 	// Rare: the hysteresis of this step needed more rounds than were enqueued, and a later step may already have reused the
-	// plan's masks.  Let the stream drain and run the step again, synchronously, from its (unmodified) input.
+	// plan's masks.  Let the stream drain and run the step again, synchronously, from its (unmodified) input.  The replay writes this
+	// step's output buffers AFTER the later steps of the plan ran: if they share those buffers (a caller that only consumes the newest
+	// result), their results are gone -- every step enqueued after this one is therefore replayed as well when it is waited for, in order.
 	HIPCHK(ctx, hipStreamSynchronize(stp.stream));
+	for (int i = 0; i < kAsyncDepth; ++i)
+		if (p->steps[i].used && p->steps[i].seq > stp.seq) p->steps[i].replay = true;
+	stp.replay = false;
 	return runStepSync(p, stp.sp, stp.stream);
 }
 
 int compvhip_plan_to_cartesian(compvhip_plan* p, const compvhip_line* d_lines, const int32_t* d_counts, size_t lineCap, float* d_cart, void* stream)
+{
+	return toCartesianImpl(p, d_lines, d_counts, lineCap, 0, d_cart, stream);
+}
+
+// maxLines > 0: d_counts holds the uncut line counts of a step that decoded only the first maxLines lines of every frame
+static int toCartesianImpl(compvhip_plan* p, const compvhip_line* d_lines, const int32_t* d_counts, size_t lineCap, int maxLines, float* d_cart, void* stream)
 {
 	if (!p) return COMPVHIP_E_INVALID_PARAMETER;
 	compvhip_ctx* ctx = p->ctx;
@@ -1117,7 +1132,8 @@ int compvhip_plan_to_cartesian(compvhip_plan* p, const compvhip_line* d_lines, c
 	if (rc) return rc;
 	const float widthF = static_cast<float>(p->W), heightF = static_cast<float>(p->H);
 	const float r = std::sqrt((widthF * widthF) + (heightF * heightF)); // houghsht.cxx:570
-	HIPCHK(ctx, launch_sht_cartesian(d_lines, d_counts, lineCap, static_cast<int>(p->frames), p->cosT, p->invSinT, widthF, r, d_cart, static_cast<hipStream_t>(stream)));
+	HIPCHK(ctx, launch_sht_cartesian(d_lines, d_counts, lineCap, maxLines, static_cast<int>(p->frames), static_cast<int>(p->T), p->cosT, p->invSinT, widthF, r, d_cart,
+	                                 static_cast<hipStream_t>(stream)));
 	return COMPVHIP_OK;
 }
 

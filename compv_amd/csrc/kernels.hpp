@@ -149,8 +149,9 @@ int sht_nms_groups(int T);
 size_t sht_nms_rows(int R);
 int sht_lines_blocks(int R);
 // acc [T][pitch] -> reference layout [R][stride]
-hipError_t launch_sht_cartesian(const void* lines /*compvhip_line*/, const int* counts, size_t lineCap, int frames, const float* cosT, const float* invSinT,
-                                float widthF, float r, float* out /*[frames][lineCap][4]*/, hipStream_t stream);
+// maxLines > 0: only the first min(count, lineCap, maxLines) lines of a frame are converted (what sht_decode_kernel wrote)
+hipError_t launch_sht_cartesian(const void* lines /*compvhip_line*/, const int* counts, size_t lineCap, int maxLines, int frames, int T, const float* cosT,
+                                const float* invSinT, float widthF, float r, float* out /*[frames][lineCap][4]*/, hipStream_t stream);
 hipError_t launch_sht_acc_transpose(const uint16_t* accT, int R, int T, int accPitch, int32_t* out, size_t outStride, hipStream_t stream);
 // one stable descending radix sort over the (key, value) slots of all frames; temp == nullptr queries tempBytes
 hipError_t sht_sort_pairs(void* temp, size_t& tempBytes, const uint32_t* keysIn, uint32_t* keysOut, const uint32_t* valsIn, uint32_t* valsOut, size_t lineCap,

@@ -376,8 +376,8 @@ __global__ __launch_bounds__(256) void sht_decode_kernel(const uint32_t* __restr
 // CompVHoughSht::toCartesian (houghsht.cxx:566-589) on the device line arrays.  cos(theta) and 1/sin(theta) come from HOST
 // tables indexed by the line's theta column (libm cosf/sinf, as the reference; device trig would not be bit-identical);
 // the kernel only multiplies and subtracts, with single correctly-rounded operations.
-__global__ __launch_bounds__(256) void sht_cartesian_kernel(const LineOut* __restrict__ lines, const int* __restrict__ counts, size_t lineCap, const float* __restrict__ cosT,
-                                                            const float* __restrict__ invSinT, float widthF, float r, float4* __restrict__ out)
+__global__ __launch_bounds__(256) void sht_cartesian_kernel(const LineOut* __restrict__ lines, const int* __restrict__ counts, size_t lineCap, int maxLines, int T,
+                                                            const float* __restrict__ cosT, const float* __restrict__ invSinT, float widthF, float r, float4* __restrict__ out)
 {
 	// rho - W*a must stay a rounded product followed by a rounded subtraction, as on the CPU: the library is built with
 	// -ffp-contract=off (the __f*_rn intrinsics are plain operators that a later FMA contraction would still fuse)
@@ -385,10 +385,12 @@ __global__ __launch_bounds__(256) void sht_cartesian_kernel(const LineOut* __res
 	const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
 	size_t n = (size_t)max(counts[frame], 0);
 	if (n > lineCap) n = lineCap;
+	if (maxLines > 0 && n > (size_t)maxLines) n = (size_t)maxLines;   // counts[] holds the uncut line count: the decode stage wrote min(count, lineCap, maxLines) slots
 	if (i >= n) return;
 	const LineOut l = lines[(size_t)frame * lineCap + i];
 	float4 o;
 	if (l.theta == 0.f) o = make_float4(l.rho, r, l.rho, -r); // perfect vertical line
+	else if (l.col < 0 || l.col >= T) o = make_float4(0.f, 0.f, 0.f, 0.f);   // not a line of this plan (foreign / uninitialised slot): no table entry to read
 	else {
 		const float a = cosT[l.col], b = invSinT[l.col];
 		o = make_float4(0.f, __fmul_rn(l.rho, b), widthF, __fmul_rn(__fsub_rn(l.rho, __fmul_rn(widthF, a)), b));
@@ -459,12 +461,13 @@ hipError_t launch_sht_decode(const uint32_t* keys, const uint32_t* vals, const i
 	return hipGetLastError();
 }
 
-hipError_t launch_sht_cartesian(const void* lines, const int* counts, size_t lineCap, int frames, const float* cosT, const float* invSinT, float widthF,
-                                float r, float* out, hipStream_t stream)
+hipError_t launch_sht_cartesian(const void* lines, const int* counts, size_t lineCap, int maxLines, int frames, int T, const float* cosT, const float* invSinT,
+                                float widthF, float r, float* out, hipStream_t stream)
 {
 	if (!lineCap) return hipSuccess;
-	dim3 grid((unsigned)((lineCap + 255) / 256), frames);
-	hipLaunchKernelGGL(sht_cartesian_kernel, grid, dim3(256), 0, stream, reinterpret_cast<const LineOut*>(lines), counts, lineCap, cosT, invSinT, widthF, r,
+	const size_t span = (maxLines > 0 && (size_t)maxLines < lineCap) ? (size_t)maxLines : lineCap;
+	dim3 grid((unsigned)((span + 255) / 256), frames);
+	hipLaunchKernelGGL(sht_cartesian_kernel, grid, dim3(256), 0, stream, reinterpret_cast<const LineOut*>(lines), counts, lineCap, maxLines, T, cosT, invSinT, widthF, r,
 	                   reinterpret_cast<float4*>(out));
 	return hipGetLastError();
 }

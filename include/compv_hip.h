@@ -248,7 +248,12 @@ COMPVHIP_API int compvhip_plan_pipeline(compvhip_plan* plan, const uint8_t* d_in
  * its hysteresis needed more resolve rounds than were enqueued speculatively, drains the stream and runs the step again
  * synchronously -- so d_in must stay unmodified, and distinct from d_edges, until the step was waited for.  Up to 4 steps may be
  * in flight (further calls return COMPVHIP_E_INVALID_STATE); steps of one plan must use one stream.  Typical use:
- * t1 = async(batch k+1); wait(t0) -- the GPU never idles between steps. */
+ * t1 = async(batch k+1); wait(t0) -- the GPU never idles between steps.
+ * Output buffers and the replay: a replayed step writes its d_edges / d_lines / d_counts again, AFTER later steps of the plan have run.  Steps in
+ * flight may share output buffers (a caller that only consumes the newest result): every step enqueued after a replayed one is then replayed too
+ * when it is waited for, in enqueue order, so after compvhip_plan_wait(t) the buffers of step t always hold step t's results.  Wait for the tickets
+ * of a plan in the order they were issued.  Results of step t are only guaranteed to still be there until the next step that shares its buffers
+ * starts -- give steps their own buffers to read them later. */
 COMPVHIP_API int compvhip_plan_pipeline_async(compvhip_plan* plan, const uint8_t* d_in, float tLow, float tHigh,
                                               int threshold, int maxLines, uint8_t* d_edges,
                                               compvhip_line* d_lines, size_t lineCap, int32_t* d_counts, void* stream, int* ticket);

@@ -235,6 +235,28 @@ double refshim_bench_pipeline(const uint8_t* in, size_t W, size_t H, size_t S, s
 	return t1 - t0;
 }
 
+// Per-call wall time of CompVHoughKht::process on `frames` edge maps laid out back to back (frame stride S*H), one Hough object reused
+// across the frames as tests/image/houghkht.cxx loops process().  Returns total wall ms.
+double refshim_bench_kht(const uint8_t* edges, size_t W, size_t H, size_t S, size_t frames, float rho, float thetaDeg, size_t threshold, long long* nLines)
+{
+	CompVHoughPtr kht;
+	if (COMPV_ERROR_CODE_IS_NOK(CompVHough::newObj(&kht, COMPV_HOUGHKHT_ID, rho, thetaDeg, threshold))) return -1;
+	std::vector<CompVMatPtr> maps(frames);
+	for (size_t f = 0; f < frames; ++f) {
+		if (COMPV_ERROR_CODE_IS_NOK(toMat(edges + f * S * H, W, H, S, &maps[f]))) return -1;
+	}
+	CompVHoughLineVector lines;
+	long long l = 0;
+	const double t0 = nowMs();
+	for (size_t f = 0; f < frames; ++f) {
+		if (COMPV_ERROR_CODE_IS_NOK(kht->process(maps[f], lines))) return -1;
+		l += (long long)lines.size();
+	}
+	const double t1 = nowMs();
+	if (nLines) *nLines = l;
+	return t1 - t0;
+}
+
 // CompVImage::convertGrayscale (samples/hough_lines/main.cxx:102). fmt: index into the table below (the numbering of
 // include/compv_hip.h, compvhip_pixfmt). in: H rows of S samples (S*bpp bytes per row). out: H rows of W bytes at stride So.
 int refshim_grayscale(const uint8_t* in, int fmt, size_t W, size_t H, size_t S, uint8_t* out, size_t So)

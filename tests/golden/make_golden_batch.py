@@ -2,7 +2,8 @@
 Canny(59,119) -> SHT(rho 1, theta 1 deg, threshold 100)), produced by the REAL CompV library (oracle/_ref, AVX2 intrinsics path,
 one thread: the multi-threaded gradient of the reference races).  Run in the build container only:
 
-    python tests/golden/make_golden_batch.py            (about a minute)
+    python tests/golden/make_golden_batch.py            (about a minute)  -> golden_batch.json
+    python tests/golden/make_golden_batch.py fhd        (1920 x 1080, 64 frames: bench.py's configs_extra)  -> golden_batch_fhd.json
 
 Per frame: MD5 of the edge map (rows of W bytes), number of edge pixels, number of lines, sum of their strengths and an
 order-independent 64-bit hash of the line set (the reference leaves the order of equal-strength lines to an unstable sort):
@@ -20,8 +21,9 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(HERE))
 from oracle_bindings import RefShim, md5_rows, synth_frame  # noqa: E402
 
-W, H = 3840, 2160
-FIRST_SEED, FRAMES = 12345, 256
+FHD = len(sys.argv) > 1 and sys.argv[1] == "fhd"
+W, H = (1920, 1080) if FHD else (3840, 2160)
+FIRST_SEED, FRAMES = 12345, (64 if FHD else 256)
 T_LOW, T_HIGH, THETA_DEG, THRESHOLD = 59.0, 119.0, 1.0, 100
 M64 = (1 << 64) - 1
 
@@ -56,7 +58,7 @@ def main():
         print(f, frames[-1], flush=True)
     out = {"W": W, "H": H, "tLow": T_LOW, "tHigh": T_HIGH, "theta_deg": THETA_DEG, "threshold": THRESHOLD, "first_seed": FIRST_SEED,
            "source": "CompV (oracle/_ref, AVX2 intrinsics, 1 thread)", "frames": frames}
-    with open(os.path.join(HERE, "golden_batch.json"), "w") as fh:
+    with open(os.path.join(HERE, "golden_batch_fhd.json" if FHD else "golden_batch.json"), "w") as fh:
         json.dump(out, fh, indent=0, sort_keys=True)
 
 

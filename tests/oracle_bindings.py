@@ -484,6 +484,16 @@ class RefShim:
         r = self.lib.refshim_convlt1_16s16s16s(_p(img), W, H, img.strides[0] // 2, _p(vt), _p(hz), len(vt), _p(out))
         return r, out[:, :W]
 
+    def bench_kht(self, edge_maps, rho=1.0, theta_deg=1.0, threshold=1):
+        """wall ms of CompVHoughKht::process over the (n, H, W) edge maps, and the number of lines found"""
+        n, H, W = edge_maps.shape
+        sz = C.c_size_t
+        self.lib.refshim_bench_kht.argtypes = [C.c_void_p, sz, sz, sz, sz, C.c_float, C.c_float, sz, C.c_void_p]
+        self.lib.refshim_bench_kht.restype = C.c_double
+        l = C.c_longlong(0)
+        ms = self.lib.refshim_bench_kht(_p(edge_maps), W, H, W, n, rho, theta_deg, threshold, C.byref(l))
+        return ms, l.value
+
     def bench_pipeline(self, frames, fLow, fHigh, theta_deg, threshold, stages=3):
         n, H, W = frames.shape
         e = C.c_longlong(0); l = C.c_longlong(0)

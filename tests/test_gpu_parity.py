@@ -919,6 +919,46 @@ def test_plan_pipeline_async_matches_sync(hip_ctx, oracle):
         plan.close()
 
 
+def test_async_replay_with_shared_output_buffers(hip_ctx, oracle):
+    """compvhip_plan_wait's replay rule (include/compv_hip.h): steps in flight may SHARE their output buffers; when an earlier step is replayed
+    (its hysteresis needed more rounds than were enqueued), the later steps are replayed too when they are waited for, so after wait(t) the
+    buffers hold step t's results.  Step 0 = the serpentine frame that forces the replay, step 1 = an ordinary frame; both write ONE buffer set."""
+    import torch
+    from compv_amd import capi
+    W, H, n, cap = 1104, 700, 1, 4096
+    serp = np.full((H, W), 100, np.uint8)
+    for k, yy in enumerate(range(20, H - 20, 12)):
+        serp[yy:yy + 3, 15:W - 15] = 112
+        xs = W - 30 if (k % 2 == 0) else 15
+        serp[yy:yy + 15, xs:xs + 3] = 112
+    serp[18:26, 10:20] = 255
+    frames = [serp[None].copy(), synth_frame(W, H, 9)[None].copy()]
+    params = [(10.0, 200.0), (59.0, 119.0)]
+    dev = torch.device("cuda:0")
+    plan = capi.Plan(hip_ctx, W, H, W, n, 1.0)
+    st = torch.cuda.Stream(device=dev)
+    try:
+        d_in = [torch.from_numpy(f).to(dev) for f in frames]
+        d_e = torch.empty((n, H, W), dtype=torch.uint8, device=dev)
+        d_l = torch.zeros((n, cap, 5), dtype=torch.int32, device=dev)
+        d_c = torch.zeros(n, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        tickets = [plan.pipeline_async(d_in[k].data_ptr(), params[k][0], params[k][1], 40, 0, d_e.data_ptr(), d_l.data_ptr(), cap, d_c.data_ptr(), st.cuda_stream)
+                   for k in range(2)]
+        for k, t in enumerate(tickets):
+            plan.wait(t)                                          # wait(0) replays step 0 AFTER step 1 ran; wait(1) must bring step 1's results back
+            st.synchronize()
+            rc, e = oracle.canny(frames[k][0], *params[k])
+            assert rc == 0
+            assert (d_e.cpu().numpy()[0] == e).all(), ("step", k)
+            exp = oracle.sht(e, 1.0, 40)
+            assert int(d_c.cpu().numpy()[0]) == len(exp), ("step", k)
+            raw = d_l.cpu().numpy().view(np.uint8).reshape(n, cap, 20)
+            assert _lines_tuple(np.frombuffer(raw[0].tobytes(), dtype=capi.LINE_DTYPE)[:min(len(exp), cap)]) == _orc_tuple(exp[:cap]), ("step", k)
+    finally:
+        plan.close()
+
+
 def test_two_plans_in_flight_on_two_streams(hip_ctx, oracle):
     """bench.py's default step mode: two plans, each with its own buffers and HIP stream, take asynchronous steps in turn so that kernels
     of different batches overlap on the GPU.  Different inputs per plan, several steps each; every plan's LAST result is compared with

@@ -161,6 +161,25 @@ def test_sample_loop_as_one_enqueue(hip_ctx, oracle):
                 assert [(int(l["row"]), int(l["col"]), int(l["strength"])) for l in got] == [(l[3], l[4], l[2]) for l in exp]
                 ce = oracle.sht_to_cartesian(W, H, [(float(np.float32(l[0])), float(np.float32(l[1]))) for l in exp])
                 assert (cart[f][:len(exp)].view(np.uint32) == ce.view(np.uint32)).all(), (asynchronous, f)
+        # the sample's line cut (HOUGH_MAXLINES = 20, samples/hough_lines/main.cxx) with the Cartesian output: d_counts keeps the UNCUT count, only
+        # the first 20 slots of d_lines are decoded -- toCartesian must stop there too (slots past the cut hold whatever the buffer held)
+        d_lines = torch.full((F, cap, 5), 0x7f7f7f7f, dtype=torch.int32, device=dev)
+        d_cart = torch.full((F, cap, 4), float("nan"), dtype=torch.float32, device=dev)
+        d_counts.zero_()
+        plan.pipeline_ex(d_rgb.data_ptr(), 0.5, 1.0, 60, 20, d_edges.data_ptr(), d_lines.data_ptr(), cap, d_counts.data_ptr(),
+                         threshold_type=capi.THRESHOLD_OTSU, pixfmt=capi.FMT_RGB24, d_cart=d_cart.data_ptr())
+        torch.cuda.synchronize()
+        counts = d_counts.cpu().numpy(); cart = d_cart.cpu().numpy()
+        raw = d_lines.cpu().numpy().view(np.uint8).reshape(F, cap, 20)
+        for f in range(F):
+            exp = lines_exp[f]
+            assert counts[f] == len(exp) > 20
+            got = np.frombuffer(raw[f].tobytes(), dtype=capi.LINE_DTYPE)[:20]
+            # the cut keeps the 20 strongest; lines of equal strength at the cut are an arbitrary choice of the reference's unstable sort: compare strengths
+            assert [int(l["strength"]) for l in got] == [l[2] for l in exp[:20]]
+            ce = oracle.sht_to_cartesian(W, H, [(float(l["rho"]), float(l["theta"])) for l in got])
+            assert (cart[f][:20].view(np.uint32) == ce.view(np.uint32)).all(), f
+            assert np.isnan(cart[f][20:]).all(), f                  # nothing converted past the cut
         # kernel size 5 + PERCENT_OF_MEAN thresholds on the luma planes, no optional outputs (the plan keeps its own scratch)
         d_y = torch.from_numpy(np.stack(grays)).to(dev)
         d_edges = torch.zeros_like(d_y); d_lines.zero_(); d_counts.zero_()

@@ -14,8 +14,8 @@ BIN = os.path.join(ROOT, "integration", "_build", "headless_samples")
 @pytest.mark.gpu
 @pytest.mark.parametrize("W,H,frames", [(641, 480, 1), (1280, 720, 2), (1920, 1080, 1)])
 def test_real_compv_with_hip_factories(W, H, frames):
-    if not os.path.exists(BIN):
-        pytest.skip("integration/_build/headless_samples not built (needs a CompV checkout)")
+    # on a GPU box the prebuilt drop-in binary must be there: a missing one is a failure of the build / snapshot, not a reason to skip
+    assert os.path.exists(BIN), "integration/_build/headless_samples is missing: run __graft_entry__.build() where the CompV checkout is (integration/build.sh)"
     r = subprocess.run([BIN, str(W), str(H), str(frames)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
     assert "DROP-IN PARITY OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
     assert r.returncode == 0
@@ -42,28 +42,46 @@ def test_bench_under_torchrun_nccl_single_rank(tmp_path):
     assert res["lines_last_step_all_ranks"] is not None and res["lines_frame0"] > 0
 
 
-@pytest.mark.gpu
-def test_bench_two_ranks_on_one_gpu_with_the_rccl_data_path(tmp_path):
-    """N > 1 logic driving the HIP path on hardware, with the one GPU a test box has: two ranks (two processes, two HIP contexts) share
-    cuda:0, torch.distributed backend nccl (= RCCL) carries bench.py --scatter's data path -- rank 0 owns every step's batch and sends
-    rank 1 its block (grouped send/recv), line counts and the strongest lines are all-gathered -- plus the barrier / MAX brackets.
-    Where the RCCL build refuses two ranks on one device ("Duplicate GPU detected") the same two-rank run is repeated with the gloo backend
-    (host-staged payload): two processes and two HIP contexts still drive the HIP path under the N > 1 logic."""
+def _two_rank_scatter_run(backend, port):
     import json
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29618",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.join(root, "bench.py"), "--gpus", "2", "--shared-gpu", "--scatter", "--steps", "4", "--warmup", "2", "--reps", "2", "--frames-per-gpu", "2",
-           "--batches", "4", "--width", "1280", "--height", "720", "--no-cpu-baseline", "--no-extras"]
+           "--batches", "4", "--width", "1280", "--height", "720", "--no-cpu-baseline", "--no-extras", "--dist-backend", backend]
     r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    res = None
+    if r.returncode == 0:
+        res = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    return r, res
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_gpu_with_the_rccl_data_path(tmp_path):
+    """N > 1 logic driving the HIP path on hardware, with the one GPU a test box has: two ranks (two processes, two HIP contexts) share
+    cuda:0, torch.distributed backend nccl (= RCCL) carries bench.py --scatter's data path -- rank 0 owns every step's batch and sends
+    rank 1 its block (grouped send/recv), line counts and the strongest lines are all-gathered -- plus the barrier / MAX brackets.
+    The backend that carried the payload is asserted and printed.  An RCCL build that refuses two ranks on ONE device ("Duplicate GPU
+    detected") cannot run this on a one-GPU box: that is reported as an xfail naming the reason, never silently replaced by another backend
+    (the gloo run is its own test below)."""
+    r, res = _two_rank_scatter_run("nccl", 29618)
     if r.returncode != 0 and ("Duplicate GPU detected" in r.stderr or "invalid usage" in r.stderr):
-        # RCCL builds that refuse two ranks on one device: the same two-rank run with the gloo backend still drives two HIP contexts
-        cmd_g = cmd + ["--dist-backend", "gloo"]
-        r = subprocess.run(cmd_g, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+        pytest.xfail("this RCCL build refuses two ranks on one device (Duplicate GPU detected): the RCCL scatter needs two GPUs")
     assert r.returncode == 0, r.stderr[-3000:]
-    line = [l for l in r.stdout.splitlines() if l.startswith("{")][-1]
-    res = json.loads(line)
-    assert res["n_gpus"] == 2 and res["value"] > 0 and "scattered from rank 0" in res["config"]["parallelism"]
+    print("two-rank scatter / gather carried by torch.distributed backend:", res["dist_backend"])
+    assert res["dist_backend"] == "nccl"
+    assert res["n_gpus"] == 2 and res["value"] > 0 and "scattered from rank 0 over nccl" in res["config"]["parallelism"]
+    assert res["lines_last_step_all_ranks"] is not None and res["lines_frame0"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_on_one_gpu_gloo_host_staged(tmp_path):
+    """The same two-rank run with the gloo backend (payload staged through the host): two processes and two HIP contexts drive the HIP path
+    under the N > 1 logic whatever the RCCL build allows on one device."""
+    r, res = _two_rank_scatter_run("gloo", 29619)
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert res["dist_backend"] == "gloo"
+    assert res["n_gpus"] == 2 and res["value"] > 0 and "scattered from rank 0 over gloo" in res["config"]["parallelism"]
     assert res["lines_last_step_all_ranks"] is not None and res["lines_frame0"] > 0
