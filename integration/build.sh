@@ -7,6 +7,13 @@ HERE="$(cd "$(dirname "$0")" && pwd)"
 ROOT="$(dirname "$HERE")"
 REF="${COMPV_ROOT:-/root/reference}"
 OUT="$HERE/_build"
+mkdir -p "$OUT"
+# the C++ multi-GPU batch driver: C ABI + RCCL only, no CompV checkout needed
+ROCM="${ROCM_PATH:-/opt/rocm}"
+g++ -std=c++14 -O2 -w -D__HIP_PLATFORM_AMD__ -I"$ROCM/include" -o "$OUT/multi_gpu_batch" "$HERE/multi_gpu_batch.cxx" \
+  -L"$ROOT/compv_amd/lib" -lcompv_hip -L"$ROCM/lib" -lamdhip64 -lrccl \
+  -Wl,-rpath,'$ORIGIN/../../compv_amd/lib' -Wl,-rpath,"$ROCM/lib" -lpthread
+echo "integration/build.sh: OK -> $OUT/multi_gpu_batch"
 if [ ! -d "$REF/base/include" ] || [ ! -f "$ROOT/oracle/_ref/libcompv_ref.so" ]; then
   echo "integration/build.sh: no CompV checkout / library -> skipping"; exit 0
 fi

@@ -85,3 +85,23 @@ def test_bench_two_ranks_on_one_gpu_gloo_host_staged(tmp_path):
     assert res["dist_backend"] == "gloo"
     assert res["n_gpus"] == 2 and res["value"] > 0 and "scattered from rank 0 over gloo" in res["config"]["parallelism"]
     assert res["lines_last_step_all_ranks"] is not None and res["lines_frame0"] > 0
+
+
+MGB = os.path.join(ROOT, "integration", "_build", "multi_gpu_batch")
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("mode", [["--devices", "1"], ["--virtual", "2"]])
+def test_cxx_multi_gpu_batch_driver(mode):
+    """integration/multi_gpu_batch.cxx: ONE C++ process, one compvhip context + plan + stream per device, batch born on device 0 and split with a
+    grouped ncclSend / ncclRecv (RCCL directly), per-frame line counts all-gathered; every frame checked against tests/golden/golden_batch.json.
+    A test box has one GPU: `--devices 1` runs the RCCL code path (communicator, group calls, all-gather) with one rank, `--virtual 2` runs two
+    ranks (two contexts, plans, streams) on that GPU with device copies as transport."""
+    import json
+    assert os.path.exists(MGB), "integration/_build/multi_gpu_batch is missing: run integration/build.sh"
+    r = subprocess.run([MGB, "--frames-per-device", "3", "--steps", "2"] + mode, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0 and "MULTI-GPU BATCH OK" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+    res = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    ranks = 2 if mode[0] == "--virtual" else 1
+    assert res["ranks"] == ranks and res["frames_checked"] == 3 * ranks and res["Mpixels_per_s"] > 0
+    assert ("rccl" in res["transport"]) == (mode[0] == "--devices")
