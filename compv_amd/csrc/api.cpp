@@ -48,7 +48,10 @@ struct KhtScratch {
 	uint32_t* counts32 = nullptr;
 	KhtSpan* scratch = nullptr;
 	KhtSubdivFrame* stack = nullptr;
-	uint8_t* hostEdges = nullptr; size_t hostEdgesBytes = 0;   // pinned: one frame's edge map downloaded from the device (plan workers)
+	uint32_t* dBits = nullptr; size_t dBitsWords = 0;          // plan workers: the frame's edge map as bit-mask rows (bytes_to_bits_kernel), device
+	uint32_t* hostBits = nullptr; size_t hostBitsWords = 0;    // ... and its pinned host copy: 1/8 of the edge map's bytes cross PCIe
+	KhtBitPlane plane;                                         // the linker's working copy (zero border, destroyed by the walk)
+	std::vector<KhtPoint> linked;                              // points of the strings, string after string
 	double stageMs[6] = {};   // link, subdivide (GPU), statistics (GPU), prune + Gmin, vote + peaks (GPU), sort + sweep: last frame (ctx) / sums (plan worker)
 	std::string err;
 };
@@ -169,7 +172,8 @@ void khtScratchFree(compvhip_ctx* ctx, KhtScratch& k)
 	dfree(ctx, k.counts); dfree(ctx, k.params); dfree(ctx, k.cells); dfree(ctx, k.cellCount);
 	dfree(ctx, k.pts); dfree(ctx, k.spans); dfree(ctx, k.kernelsDev);
 	dfree(ctx, k.strings); dfree(ctx, k.counts32); dfree(ctx, k.scratch); dfree(ctx, k.stack);
-	if (k.hostEdges) { (void)hipHostFree(k.hostEdges); k.hostEdges = nullptr; k.hostEdgesBytes = 0; }
+	dfree(ctx, k.dBits); k.dBitsWords = 0;
+	if (k.hostBits) { (void)hipHostFree(k.hostBits); k.hostBits = nullptr; k.hostBitsWords = 0; }
 	if (k.ownStream && k.stream) { (void)hipStreamDestroy(k.stream); k.stream = nullptr; }
 }
 
@@ -1440,33 +1444,22 @@ int compvhip_houghsht_u8(compvhip_ctx* ctx, const uint8_t* edges, size_t W, size
 // several of these at the same time on worker threads, so nothing below touches ctx->err or any other shared state (ctx->live is atomic).
 #define KCHK(K, call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { (K).err = std::string(#call) + ": " + hipGetErrorString(e__); return COMPVHIP_E_HIP; } } while (0)
 
-// host linking, then cluster subdivision (kht_subdivide_kernel) and per-cluster statistics (kht_stats_kernel) on the GPU; kernels in cluster order
-static int khtBuildKernels(compvhip_ctx* ctx, KhtScratch& K, const uint8_t* edges, size_t W, size_t H, size_t S, double clusterMinDeviation, size_t clusterMinSize,
-                           std::vector<KhtKernel>& kernels, double& hmax, uint8_t* scratchEdges = nullptr)
+// host linking (on K.plane, which it destroys), then cluster subdivision (kht_subdivide_kernel) and per-cluster statistics (kht_stats_kernel) on the GPU; kernels in cluster order
+static int khtBuildKernels(compvhip_ctx* ctx, KhtScratch& K, size_t W, size_t H, double clusterMinDeviation, size_t clusterMinSize,
+                           std::vector<KhtKernel>& kernels, double& hmax)
 {
 	using clk = std::chrono::steady_clock;
 	auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
 	kernels.clear(); hmax = 0.0;
 	const auto t0 = clk::now();
-	// the linker destroys the edges it visits (:323-336): it works on a clone -- or in place when the caller hands over a private copy
-	// (scratchEdges: the pinned frame buffer of a plan worker, dense rows)
-	std::vector<uint8_t> work;
-	uint8_t* e = scratchEdges;
-	if (!e) {
-		work.resize(W * H);
-		for (size_t j = 0; j < H; ++j) memcpy(&work[j * W], edges + j * S, W);
-		e = work.data();
-	}
-	std::vector<KhtPos> poss; std::vector<KhtRange> strings;
-	khtLink(e, W, H, W, clusterMinSize, poss, strings);
+	std::vector<KhtPoint>& pts = K.linked; std::vector<KhtRange> strings;
+	khtLink(K.plane, clusterMinSize, pts, strings);
 	const auto t1 = clk::now();
 	K.stageMs[0] += ms(t0, t1);
 	if (strings.empty()) return COMPVHIP_OK;
-	if (poss.size() > 0x7fffffffull) { K.err = "too many edge pixels"; return COMPVHIP_E_INVALID_PARAMETER; }
+	if (pts.size() > 0x7fffffffull) { K.err = "too many edge pixels"; return COMPVHIP_E_INVALID_PARAMETER; }
 
 	// device: cluster subdivision (one wave per string), per-cluster statistics (one thread per cluster)
-	std::vector<KhtPoint> pts(poss.size());
-	for (size_t i = 0; i < poss.size(); ++i) { pts[i].x = poss[i].x; pts[i].y = poss[i].y; }
 	std::vector<KhtStringDesc> descs(strings.size());
 	size_t slots = 0;
 	for (size_t i = 0; i < strings.size(); ++i) {
@@ -1519,15 +1512,16 @@ static int khtBuildKernels(compvhip_ctx* ctx, KhtScratch& K, const uint8_t* edge
 }
 
 // one frame, host edge map -> lines in the reference's order (the body of CompVHoughKht::process, houghkht.cxx:208-447)
-static int khtFrame(compvhip_ctx* ctx, KhtScratch& K, const uint8_t* edges, size_t W, size_t H, size_t S, const KhtAxes& ax, int threshold, int maxLines,
-                    double clusterMinDeviation, size_t clusterMinSize, double kernelMinHeight, std::vector<KhtLine>& out, double* gs, uint8_t* scratchEdges = nullptr)
+// (the frame's edge map is K.plane: packed by the caller, destroyed by the linker)
+static int khtFrame(compvhip_ctx* ctx, KhtScratch& K, size_t W, size_t H, const KhtAxes& ax, int threshold, int maxLines,
+                    double clusterMinDeviation, size_t clusterMinSize, double kernelMinHeight, std::vector<KhtLine>& out, double* gs)
 {
 	using clk = std::chrono::steady_clock;
 	auto msSince = [](clk::time_point a) { return std::chrono::duration<double, std::milli>(clk::now() - a).count(); };
 	out.clear();
 	std::vector<KhtKernel> kernels;
 	double hmax = 0.0;
-	const int rck = khtBuildKernels(ctx, K, edges, W, H, S, clusterMinDeviation, clusterMinSize, kernels, hmax, scratchEdges);
+	const int rck = khtBuildKernels(ctx, K, W, H, clusterMinDeviation, clusterMinSize, kernels, hmax);
 	if (rck) return rck;
 	if (kernels.empty()) return COMPVHIP_OK;
 	auto t3 = clk::now();
@@ -1601,7 +1595,12 @@ int compvhip_houghkht_kernels_u8(compvhip_ctx* ctx, const uint8_t* edges, size_t
 	std::vector<KhtKernel> kernels; double hm = 0.0;
 	ctx->kht.stream = ctx->stream;
 	memset(ctx->kht.stageMs, 0, sizeof(ctx->kht.stageMs));
-	const int rc = khtBuildKernels(ctx, ctx->kht, edges, W, H, S, clusterMinDeviation, clusterMinSize, kernels, hm);
+	{
+		const auto tp = std::chrono::steady_clock::now();
+		khtPackBytes(edges, W, H, S, ctx->kht.plane);
+		ctx->kht.stageMs[0] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tp).count();
+	}
+	const int rc = khtBuildKernels(ctx, ctx->kht, W, H, clusterMinDeviation, clusterMinSize, kernels, hm);
 	if (rc) return fail(ctx, rc, ctx->kht.err.c_str());
 	*n = kernels.size();
 	if (hmax) *hmax = hm;
@@ -1633,7 +1632,12 @@ int compvhip_houghkht_u8(compvhip_ctx* ctx, const uint8_t* edges, size_t W, size
 	ctx->kht.stream = ctx->stream;
 	memset(ctx->kht.stageMs, 0, sizeof(ctx->kht.stageMs));
 	std::vector<KhtLine> out;
-	rc = khtFrame(ctx, ctx->kht, edges, W, H, S, ax, threshold, maxLines, clusterMinDeviation, clusterMinSize, kernelMinHeight, out, gs);
+	{
+		const auto tp = std::chrono::steady_clock::now();
+		khtPackBytes(edges, W, H, S, ctx->kht.plane);   // host bytes -> the linker's bit plane (the linker never touches the caller's map)
+		ctx->kht.stageMs[0] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tp).count();
+	}
+	rc = khtFrame(ctx, ctx->kht, W, H, ax, threshold, maxLines, clusterMinDeviation, clusterMinSize, kernelMinHeight, out, gs);
 	if (rc) return fail(ctx, rc, ctx->kht.err.c_str());
 	*n = out.size();
 	khtCopyLines(out, lines, cap);
@@ -1661,20 +1665,29 @@ int compvhip_plan_houghkht(compvhip_plan* p, const uint8_t* d_edges, float rho, 
 	if (!hw) hw = 4;
 	size_t T = hostThreads > 0 ? static_cast<size_t>(hostThreads) : std::min<size_t>(32, std::max<size_t>(1, hw / 2));   // measured at 4K x 32 frames: 8 / 16 / 32 workers 1.25 / 0.77 / 0.55 ms per frame
 	T = std::min(T, F);
+	// The producer of d_edges may still be running on the caller's stream; the workers use private streams: drain the device first (the call is
+	// synchronous and takes milliseconds -- the drain is not what bounds it)
+	HIPCHK(ctx, hipDeviceSynchronize());
+	const size_t wpr = (W + 31) / 32;   // mask words per row
 	while (p->khtWorkers.size() < T) {
 		KhtScratch* k = new (std::nothrow) KhtScratch();
 		if (!k) return fail(ctx, COMPVHIP_E_OUT_OF_MEMORY, "KHT worker");
-		p->khtWorkers.push_back(k);
-		if (hipStreamCreateWithFlags(&k->stream, hipStreamNonBlocking) != hipSuccess) return fail(ctx, COMPVHIP_E_HIP, "KHT worker stream");
+		if (hipStreamCreateWithFlags(&k->stream, hipStreamNonBlocking) != hipSuccess) { delete k; return fail(ctx, COMPVHIP_E_HIP, "KHT worker stream"); }
 		k->ownStream = true;
+		p->khtWorkers.push_back(k);   // only a worker that has its stream joins the pool
 	}
 	for (size_t t = 0; t < T; ++t) {
 		KhtScratch& K = *p->khtWorkers[t];
-		if (K.hostEdgesBytes < W * H) {
-			if (K.hostEdges) (void)hipHostFree(K.hostEdges);
-			K.hostEdges = nullptr; K.hostEdgesBytes = 0;
-			if (hipHostMalloc(reinterpret_cast<void**>(&K.hostEdges), W * H) != hipSuccess) return fail(ctx, COMPVHIP_E_OUT_OF_MEMORY, "pinned frame buffer");
-			K.hostEdgesBytes = W * H;
+		if (K.hostBitsWords < wpr * H) {
+			if (K.hostBits) (void)hipHostFree(K.hostBits);
+			K.hostBits = nullptr; K.hostBitsWords = 0;
+			if (hipHostMalloc(reinterpret_cast<void**>(&K.hostBits), wpr * H * sizeof(uint32_t)) != hipSuccess) return fail(ctx, COMPVHIP_E_OUT_OF_MEMORY, "pinned frame buffer");
+			K.hostBitsWords = wpr * H;
+		}
+		if (K.dBitsWords < wpr * H) {
+			dfree(ctx, K.dBits); K.dBitsWords = 0;
+			if (dmalloc(ctx, &K.dBits, wpr * H) != hipSuccess) return fail(ctx, COMPVHIP_E_OUT_OF_MEMORY, "device bit plane");
+			K.dBitsWords = wpr * H;
 		}
 		memset(K.stageMs, 0, sizeof(K.stageMs));
 		K.err.clear();
@@ -1685,38 +1698,62 @@ int compvhip_plan_houghkht(compvhip_plan* p, const uint8_t* d_edges, float rho, 
 	std::vector<double> dlMs(T, 0.0);
 	std::atomic<int> overflow{0};
 	const auto wall0 = std::chrono::steady_clock::now();
+	std::vector<size_t> failedFrame(T, static_cast<size_t>(-1));
 	auto work = [&](size_t t) {
 		KhtScratch& K = *p->khtWorkers[t];
-		if (hipSetDevice(ctx->device) != hipSuccess) { codes[t] = COMPVHIP_E_HIP; K.err = "hipSetDevice"; return; }
-		std::vector<KhtLine> out;
-		for (;;) {
-			const size_t f = next.fetch_add(1);
-			if (f >= F) break;
-			const auto d0 = std::chrono::steady_clock::now();
-			hipError_t e = hipMemcpy2DAsync(K.hostEdges, W, d_edges + f * S * H, S, W, H, hipMemcpyDeviceToHost, K.stream);
-			if (e == hipSuccess) e = hipStreamSynchronize(K.stream);
-			if (e != hipSuccess) { codes[t] = COMPVHIP_E_HIP; K.err = std::string("frame download: ") + hipGetErrorString(e); return; }
-			dlMs[t] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - d0).count();
-			const int r = khtFrame(ctx, K, K.hostEdges, W, H, W, ax, threshold, maxLines, clusterMinDeviation, clusterMinSize, kernelMinHeight, out, gs ? gs + f : nullptr,
-			                       K.hostEdges);   // the worker's private download: linked in place
-			if (r) { codes[t] = r; return; }
-			counts[f] = out.size();
-			if (lines) khtCopyLines(out, lines + f * cap, cap);
-			if (out.size() > cap) overflow.store(1);
+		size_t f = static_cast<size_t>(-1);
+		try {
+			if (hipSetDevice(ctx->device) != hipSuccess) { codes[t] = COMPVHIP_E_HIP; K.err = "hipSetDevice"; return; }
+			std::vector<KhtLine> out;
+			for (;;) {
+				f = next.fetch_add(1);
+				if (f >= F) break;
+				const auto d0 = std::chrono::steady_clock::now();
+				// the frame's edge map leaves the device as bit-mask rows: 1/8 of the bytes over PCIe, and the linker works on bits anyway
+				hipError_t e = launch_bytes_to_bits(d_edges + f * S * H, static_cast<int>(W), static_cast<int>(H), static_cast<int>(S), S * H, K.dBits, static_cast<int>(wpr),
+				                                    wpr * H, 1, K.stream);
+				if (e == hipSuccess) e = hipMemcpyAsync(K.hostBits, K.dBits, wpr * H * sizeof(uint32_t), hipMemcpyDeviceToHost, K.stream);
+				if (e == hipSuccess) e = hipStreamSynchronize(K.stream);
+				if (e != hipSuccess) { codes[t] = COMPVHIP_E_HIP; failedFrame[t] = f; K.err = std::string("frame download: ") + hipGetErrorString(e); return; }
+				khtPlaneFromWords(K.hostBits, wpr, W, H, K.plane);
+				dlMs[t] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - d0).count();
+				const int r = khtFrame(ctx, K, W, H, ax, threshold, maxLines, clusterMinDeviation, clusterMinSize, kernelMinHeight, out, gs ? gs + f : nullptr);
+				if (r) { codes[t] = r; failedFrame[t] = f; return; }
+				counts[f] = out.size();
+				if (lines) khtCopyLines(out, lines + f * cap, cap);
+				if (out.size() > cap) overflow.store(1);
+			}
+		}
+		catch (const std::exception& ex) {   // nothing may leave an extern "C" entry point (or a std::thread) as an exception
+			codes[t] = COMPVHIP_E_OUT_OF_MEMORY; failedFrame[t] = f; K.err = std::string("exception in a KHT worker: ") + ex.what();
+		}
+		catch (...) {
+			codes[t] = COMPVHIP_E_OUT_OF_MEMORY; failedFrame[t] = f; K.err = "exception in a KHT worker";
 		}
 	};
 	if (T == 1) work(0);
 	else {
 		std::vector<std::thread> pool;
-		for (size_t t = 1; t < T; ++t) pool.emplace_back(work, t);
+		size_t started = 1;
+		try {
+			for (size_t t = 1; t < T; ++t, ++started) pool.emplace_back(work, t);
+		}
+		catch (...) {
+			// the system refused another thread: the workers that did start share the frames among themselves
+		}
 		work(0);
 		for (auto& th : pool) th.join();
+		(void)started;
 	}
 	p->khtWallMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
 	p->khtThreads = static_cast<int>(T);
 	memset(p->khtStageMs, 0, sizeof(p->khtStageMs));
 	for (size_t t = 0; t < T; ++t) for (int k = 0; k < 6; ++k) p->khtStageMs[k] += p->khtWorkers[t]->stageMs[k];
-	for (size_t t = 0; t < T; ++t) if (codes[t]) return fail(ctx, codes[t], p->khtWorkers[t]->err.c_str());
+	for (size_t t = 0; t < T; ++t)
+		if (codes[t]) {
+			const std::string msg = "frame " + (failedFrame[t] == static_cast<size_t>(-1) ? std::string("?") : std::to_string(failedFrame[t])) + ": " + p->khtWorkers[t]->err;
+			return fail(ctx, codes[t], msg.c_str());
+		}
 	if (overflow.load()) return fail(ctx, COMPVHIP_E_OUT_OF_BOUND, "line buffer too small");
 	return COMPVHIP_OK;
 }

@@ -10,7 +10,6 @@
 namespace compvhip {
 
 struct KhtAxes { double dRho, dThetaRad, dThetaDeg, r; size_t rhoN, T, W, H; };
-struct KhtPos { int y, x; double cy, cx; };                 // CompVHoughKhtPos (houghkht.h:31-38)
 struct KhtRange { size_t begin, end; };                     // CompVHoughKhtString / Cluster
 struct KhtKernel { double rho, theta, h, sigmaThetaSquare, sigmaRhoSquare, m2, sigmaRhoTimesTheta; }; // CompVHoughKhtKernel (:52-62)
 struct KhtLine { float rho, theta; int32_t strength, rhoIndex, thetaIndex; };
@@ -22,7 +21,17 @@ struct KhtCell { uint32_t order; uint32_t rhoIndex; uint32_t thetaIndex; int32_t
 
 bool khtAxes(size_t W, size_t H, float rho, float thetaDeg, KhtAxes& ax);
 void khtFillAxes(const KhtAxes& ax, std::vector<double>& rho, std::vector<double>& theta);
-void khtLink(uint8_t* edges, size_t W, size_t H, size_t S, size_t minSize, std::vector<KhtPos>& poss, std::vector<KhtRange>& strings);
+struct KhtPoint { int32_t x, y; };
+// the edge map of one frame, one bit per pixel, with a zero border: row y (-1 <= y <= H) starts at row(y); pixel x is bit x + 8 of the row
+struct KhtBitPlane {
+	std::vector<uint8_t> buf; size_t pitch = 0, W = 0, H = 0;
+	void reset(size_t W, size_t H);
+	uint8_t* row(int y) { return buf.data() + static_cast<size_t>(y + 1) * pitch; }
+};
+void khtPackBytes(const uint8_t* edges, size_t W, size_t H, size_t S, KhtBitPlane& plane);
+void khtPlaneFromWords(const uint32_t* words, size_t wordsPerRow, size_t W, size_t H, KhtBitPlane& plane);
+// Appendix A: strings of linked pixels, in the reference's order; destroys the plane
+void khtLink(KhtBitPlane& plane, size_t minSize, std::vector<KhtPoint>& pts, std::vector<KhtRange>& strings);
 void khtFinishKernels(std::vector<KhtKernel>& kernels, double& hmax);
 double khtPruneAndScale(std::vector<KhtKernel>& kernels, double hmax, double minHeight);
 void khtVoteParams(const KhtAxes& ax, const std::vector<KhtKernel>& kernels, std::vector<KhtVoteParams>& params);
@@ -39,7 +48,6 @@ struct KhtGpuArgs {
 	KhtCell* cells; int* cellCount; int cellCap;
 };
 // Algorithm 2, per-cluster statistics (kht_stats_kernel): one thread per cluster, float64, the reference's operation order
-struct KhtPoint { int32_t x, y; };
 struct KhtSpan { uint32_t begin, end; };
 struct KhtStatsArgs {
 	const KhtPoint* pts; const KhtSpan* clusters; int n;
