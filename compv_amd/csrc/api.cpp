@@ -1490,7 +1490,7 @@ static int khtBuildKernels(compvhip_ctx* ctx, KhtScratch& K, size_t W, size_t H,
 	uint32_t tot[2] = { 0, 0 };
 	KCHK(K, hipMemcpyAsync(tot, sv.total, sizeof(tot), hipMemcpyDeviceToHost, st));
 	KCHK(K, hipStreamSynchronize(st));
-	if (tot[1]) { K.err = "cluster subdivision ran out of recursion slots"; return COMPVHIP_E_INVALID_STATE; } // never for clusterMinSize >= 2 (khtSubdivSlots bounds the depth)
+	if (tot[1]) { K.err = "cluster subdivision ran out of recursion slots"; return COMPVHIP_E_INVALID_STATE; } // cannot happen: clusterMinSize >= 2 is enforced and khtSubdivSlots bounds the depth for it
 	const uint32_t nClusters = tot[0];
 	const auto t2 = clk::now();
 	K.stageMs[1] += ms(t1, t2);
@@ -1572,6 +1572,9 @@ static int khtCheckParams(compvhip_ctx* ctx, size_t W, size_t H, float rho, floa
 {
 	if (!(rho > 0.f) || rho > 1.f || !(thetaDeg > 0.f) || threshold <= 0) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "rho in (0,1], theta > 0, threshold > 0"); // :146-163,491
 	if (!clusterMinSize || !(kernelMinHeight >= 0.0)) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "invalid KHT knob"); // :169-186 (the deviation is unchecked there)
+	// Defined deviation: the reference's set() accepts a cluster size of 1 and its clusters_subdivision then recurses without bound on the first
+	// collinear string (max_index stays at start_index, both "halves" hold >= 1 point: houghkht.cxx:795-821) -- a stack overflow, not a result.
+	if (clusterMinSize < 2) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "clusterMinSize must be >= 2 (the reference's recursion does not terminate for 1)");
 	if (!W || !H || W > 32767 || H > 32767) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "image size out of range");
 	if (!khtAxes(W, H, rho, thetaDeg, ax)) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "degenerate KHT parameter space");
 	return COMPVHIP_OK;
@@ -1590,7 +1593,7 @@ int compvhip_houghkht_kernels_u8(compvhip_ctx* ctx, const uint8_t* edges, size_t
                                  double* kernels7, size_t cap, size_t* n, double* hmax)
 {
 	if (!ctx) return COMPVHIP_E_INVALID_PARAMETER;
-	if (!edges || !n || (cap && !kernels7) || S < W || !W || !H || !clusterMinSize) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "null/invalid argument");
+	if (!edges || !n || (cap && !kernels7) || S < W || !W || !H || clusterMinSize < 2) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "null/invalid argument (clusterMinSize >= 2)");
 	if (W > 32767 || H > 32767) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "image size out of range");
 	std::vector<KhtKernel> kernels; double hm = 0.0;
 	ctx->kht.stream = ctx->stream;

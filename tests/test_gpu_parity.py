@@ -569,6 +569,12 @@ def test_houghkht_empty_and_errors(hip_ctx):
     with pytest.raises(capi.CompvHipError) as ex:
         hip_ctx.houghkht(e, rho=1.5)                           # rho must be in (0,1] (houghkht.cxx:491)
     assert ex.value.code == capi.E_INVALID_PARAMETER
+    # defined deviation: clusterMinSize = 1 sends the reference's clusters_subdivision into an unbounded recursion (houghkht.cxx:795-821: a stack
+    # overflow, which the C restatement reproduces); the HIP path refuses the value instead
+    for fn in (lambda: hip_ctx.houghkht(e, min_size=1), lambda: hip_ctx.houghkht_kernels(e, 2.0, 1)):
+        with pytest.raises(capi.CompvHipError) as ex:
+            fn()
+        assert ex.value.code == capi.E_INVALID_PARAMETER
 
 
 def test_plan_to_cartesian_on_device(hip_ctx, oracle):

@@ -47,7 +47,7 @@ constexpr int kAux = 4 * kRowB;              // aux ring, 2 rows: row r lives in
 constexpr int kList = kAux + 2 * kRowB;      // candidate list of a row pair: <= 480 u16 entries
 constexpr int kNib = kList + 1024;           // result nibbles, 4 rows x 64 bytes: byte l of a row = lane l's four pixels, U flags (weak, not strong) in bits 0..3, E flags (strong) in 4..7
 constexpr int kNibRowB = 64;
-#ifdef LAB_PAIRS
+#if defined(LAB_PAIRS) || defined(LAB_SHORTS_AT_END)
 constexpr int kCarry = kNib + 4 * kNibRowB + 64;   // [tile row][plane] u16: the low half of the mask dword an even tile shares with the odd tile to its right
 constexpr int kLdsBytes = kCarry + 128;
 #else
@@ -107,6 +107,13 @@ __device__ __forceinline__ uint32_t lshl1_add(uint32_t a, uint32_t b) { uint32_t
 __device__ __forceinline__ uint32_t lshl1_add_s(uint32_t a, uint32_t sb) { uint32_t d; asm("v_lshl_add_u32 %0, %1, 1, %2" : "=v"(d) : "v"(a), "s"(sb)); return d; }
 __device__ __forceinline__ uint32_t xad(uint32_t a, uint32_t sk, uint32_t c) { uint32_t d; asm("v_xad_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(sk), "v"(c)); return d; }   // (a ^ k) + c
 __device__ __forceinline__ uint32_t add3(uint32_t a, uint32_t b, uint32_t sk) { uint32_t d; asm("v_add3_u32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(sk)); return d; }
+
+#ifdef LAB_DIET
+__device__ __forceinline__ uint32_t perm_s(uint32_t hi, uint32_t lo, uint32_t ssel) { uint32_t d; asm("v_perm_b32 %0, %1, %2, %3" : "=v"(d) : "v"(hi), "v"(lo), "s"(ssel)); return d; }
+__device__ __forceinline__ uint32_t perm0_s(uint32_t lo, uint32_t ssel) { uint32_t d; asm("v_perm_b32 %0, 0, %1, %2" : "=v"(d) : "v"(lo), "s"(ssel)); return d; }
+__device__ __forceinline__ uint32_t bfi_s(uint32_t smask, uint32_t a, uint32_t b) { uint32_t d; asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(d) : "s"(smask), "v"(a), "v"(b)); return d; }
+__device__ __forceinline__ uint32_t bfi_vs(uint32_t mask, uint32_t a, uint32_t sb) { uint32_t d; asm("v_bfi_b32 %0, %1, %2, %3" : "=v"(d) : "v"(mask), "v"(a), "s"(sb)); return d; }
+#endif
 
 } // namespace
 
@@ -172,6 +179,7 @@ __global__ __launch_bounds__(WAVES * 64, 8) void canny_swar_tile_kernel(CannyArg
 	// g is forced to 0 (g' = 2048) outside columns [1, W-2]: zero OUTPUT border of the convolution (compv_math_convlt.h:181-209)
 	const bool edgeTile = (xbase < 1) || (xbase + 256 > W - 1);
 	uint32_t okm[2] = { 0xffffffffu, 0xffffffffu };
+#ifndef LAB_DIET
 	if (edgeTile) {
 #pragma unroll
 		for (int k = 0; k < 2; ++k) {
@@ -179,6 +187,8 @@ __global__ __launch_bounds__(WAVES * 64, 8) void canny_swar_tile_kernel(CannyArg
 			okm[k] = ((xa >= 1 && xa <= W - 2) ? 0x0000ffffu : 0u) | ((xb >= 1 && xb <= W - 2) ? 0xffff0000u : 0u);
 		}
 	}
+#endif
+	(void)okm;
 	// lanes 0, 1, 62, 63 own no pixels (column halo): their candidate threshold is out of reach
 	const bool owner = (lane >= 2 && lane <= 61);
 	uint32_t thrV = owner ? (uint32_t)tLowQ : 0xffffu;
@@ -227,6 +237,10 @@ __global__ __launch_bounds__(WAVES * 64, 8) void canny_swar_tile_kernel(CannyArg
 	auto zero_nibbles = [&]() { *reinterpret_cast<uint32_t*>(rest + kNib + lane * 4) = 0u; };   // 4 rows x 64 B
 	zero_nibbles();
 	uint32_t listCount = 0;                // entries in the candidate list (wave-uniform)
+#ifdef LAB_DIET
+	uint32_t selA0 = 0x0c010c00u, selA1 = 0x0c030c02u, selLR = 0x0c040c03u, selL1 = 0x0c020c01u, sBias1k = kBias1k, sBias2k = kBias2k;
+	asm volatile("" : "+s"(selA0), "+s"(selA1), "+s"(selLR), "+s"(selL1), "+s"(sBias1k), "+s"(sBias2k));
+#endif
 #if defined(LAB_DENSE2)
 	uint32_t k255 = 0x00ff00ffu, k4 = 0x00040004u, k3ff = 0x03ff03ffu, k1 = 0x00010001u;
 	asm volatile("" : "+s"(k255), "+s"(k4), "+s"(k3ff), "+s"(k1));
@@ -320,6 +334,13 @@ __global__ __launch_bounds__(WAVES * 64, 8) void canny_swar_tile_kernel(CannyArg
 					else if (odd && dl == 0) { atomicAnd(dst, 0x0000ffffu); atomicOr(dst, v & 0xffff0000u); }
 					else *dst = v;
 				}
+#elif defined(LAB_SHORTS_AT_END)
+				{
+					// the half of the dword this tile shares with its neighbour: collected in the LDS, stored once per tile (below)
+					const bool shared = odd ? (dl == 0) : (dl == 7);
+					if (shared) reinterpret_cast<uint16_t*>(rest + kCarry)[(rr0 + q) * 2 + mi] = odd ? (uint16_t)(v >> 16) : (uint16_t)v;
+					else *dst = v;
+				}
 #elif defined(LAB_NO_SHORTS)
 				if (!(!odd && dl == 7) && !(odd && dl == 0)) *dst = v;
 #elif defined(LAB_ALL_SHORTS)
@@ -398,11 +419,15 @@ __global__ __launch_bounds__(WAVES * 64, 8) void canny_swar_tile_kernel(CannyArg
 
 		// ---- dense stage: packed pairs straight from the raw dwords (one v_perm each) ----
 		uint32_t A[2], L[3];
+#ifdef LAB_DIET
+		A[0] = perm0_s(m, selA0); A[1] = perm0_s(m, selA1); L[0] = perm_s(m, l, selLR); L[1] = perm0_s(m, selL1); L[2] = perm_s(r, m, selLR);
+#else
 		A[0] = __builtin_amdgcn_perm(0u, m, 0x0c010c00u);     // (p0, p1)
 		A[1] = __builtin_amdgcn_perm(0u, m, 0x0c030c02u);     // (p2, p3)
 		L[0] = __builtin_amdgcn_perm(m, l, 0x0c040c03u);      // (p-1, p0)
 		L[1] = __builtin_amdgcn_perm(0u, m, 0x0c020c01u);     // (p1, p2)
 		L[2] = __builtin_amdgcn_perm(r, m, 0x0c040c03u);      // (p3, p4)
+#endif
 		uint32_t gq[2], aux[2];
 		uint32_t (&hyTop)[2] = hy[PH & 1]; // hy of row yin-2; overwritten with hy of row yin
 #ifdef LAB_DENSE2
@@ -421,7 +446,11 @@ __global__ __launch_bounds__(WAVES * 64, 8) void canny_swar_tile_kernel(CannyArg
 			gq[k] = add3(mx, my, k1);                                  // g + 2048
 			// bit 10 of gxb ^ gyb = sign(gx) != sign(gy), except that gy = 0 reads as negative: a pixel with gy = 0 is in the horizontal class
 			// (or has g = 0), the sign only selects between the two diagonals
+#ifdef LAB_DIET
+			aux[k] = bfi_s(sBias1k, gxb ^ gyb, mx);
+#else
 			aux[k] = bfi(kBias1k, gxb ^ gyb, mx);
+#endif
 		}
 #else
 #pragma unroll
@@ -446,7 +475,15 @@ __global__ __launch_bounds__(WAVES * 64, 8) void canny_swar_tile_kernel(CannyArg
 			asm volatile("" : "+v"(gq[0]), "+v"(gq[1]));
 			const uint32_t rowm = (yc >= 1 && yc <= H - 2) ? 0xffffffffu : 0u; // image border rows (and rows past the image): g = 0
 #pragma unroll
+#ifdef LAB_DIET
+			for (int k = 0; k < 2; ++k) {
+				const int xa = x0 + 2 * k, xb = xa + 1;   // rebuilt here (border tiles only): two registers less in every tile
+				const uint32_t ok = ((xa >= 1 && xa <= W - 2) ? 0x0000ffffu : 0u) | ((xb >= 1 && xb <= W - 2) ? 0xffff0000u : 0u);
+				gq[k] = bfi_vs(ok & rowm, gq[k], sBias2k);
+			}
+#else
 			for (int k = 0; k < 2; ++k) gq[k] = bfi(okm[k] & rowm, gq[k], kBias2k);
+#endif
 		}
 #ifdef LAB_NO_LDSW
 		if (a.ksize == 77) obase[lane + it] = (uint8_t)(gq[0] + gq[1] + aux[0] + aux[1]);
@@ -599,6 +636,15 @@ __global__ __launch_bounds__(WAVES * 64, 8) void canny_swar_tile_kernel(CannyArg
 	}
 #ifdef LAB_PAIRS
 	__builtin_amdgcn_wave_barrier();
+	}
+#endif
+#ifdef LAB_SHORTS_AT_END
+	{
+		__builtin_amdgcn_wave_barrier();
+		const int row = y0 + (lane >> 1), mi = lane & 1;
+		const int gd = d0 + (odd ? 0 : 7);
+		if (row < H && gd < a.wb)
+			reinterpret_cast<uint16_t*>((mi ? ebase : ubase) + (size_t)row * a.wb + gd)[odd] = reinterpret_cast<const uint16_t*>(rest + kCarry)[lane];
 	}
 #endif
 #ifdef LAB_PAIRS2
