@@ -88,9 +88,9 @@ class FrameSynth:
 # ------------------------------------------------------------------------------------------------------------------------------------
 # CPU baseline
 # ------------------------------------------------------------------------------------------------------------------------------------
-def _ref_worker(threads, first_seed, n, repeats, W, H, barrier, queue):
+def _ref_worker(threads, first_seed, n, work_s, W, H, barrier, queue):
     """One process of the frame-parallel baseline: its own CompV instance with `threads` workers, its own frames.  Import, library start-up and
-    frame synthesis happen BEFORE the cross-process barrier; the clock runs over `repeats` passes over the worker's n frames only."""
+    frame synthesis happen BEFORE the cross-process barrier; the clock runs over passes over the worker's n frames until work_s seconds are up."""
     try:
         from oracle_bindings import RefShim, synth_frame
         ref = RefShim(threads)
@@ -98,9 +98,11 @@ def _ref_worker(threads, first_seed, n, repeats, W, H, barrier, queue):
         ref.bench_pipeline(frames[:1], T_LOW, T_HIGH, THETA_DEG, SHT_THRESHOLD)   # warm the pool and the scratch buffers
         barrier.wait()
         t0 = time.time()
-        for _ in range(repeats):
-            ref.bench_pipeline(frames, T_LOW, T_HIGH, THETA_DEG, SHT_THRESHOLD)
-        queue.put((t0, time.time(), n * repeats))
+        done = 0
+        while time.time() - t0 < work_s:
+            ref.bench_pipeline(frames[done % n:done % n + 1], T_LOW, T_HIGH, THETA_DEG, SHT_THRESHOLD)
+            done += 1
+        queue.put((t0, time.time(), done))
     except Exception as e:  # a worker that dies must not leave the others at the barrier for ever
         try:
             barrier.abort()
@@ -109,17 +111,16 @@ def _ref_worker(threads, first_seed, n, repeats, W, H, barrier, queue):
         queue.put(("error", repr(e), 0))
 
 
-def frame_parallel_baseline(W, H, threads_per_proc, ms_per_frame_guess, cores, work_s=2.5):
-    """P processes x T threads over independent frames, all started together (barrier) and each with >= work_s seconds of frames."""
+def frame_parallel_baseline(W, H, threads_per_proc, cores, work_s=4.0):
+    """P processes x T threads over independent frames, all released together (barrier); every worker processes frames for work_s seconds."""
     import multiprocessing as mp
     ctx = mp.get_context("spawn")
     tt = max(1, threads_per_proc)
     procs = max(1, min(cores // tt, 32))
     n = 4
-    repeats = max(2, int(work_s * 1000.0 / max(ms_per_frame_guess * 1.5, 1e-3) / n + 0.5))
     barrier = ctx.Barrier(procs)
     queue = ctx.Queue()
-    ps = [ctx.Process(target=_ref_worker, args=(tt, 20000 + 100 * i, n, repeats, W, H, barrier, queue)) for i in range(procs)]
+    ps = [ctx.Process(target=_ref_worker, args=(tt, 20000 + 100 * i, n, work_s, W, H, barrier, queue)) for i in range(procs)]
     for pr in ps:
         pr.start()
     res = [queue.get(timeout=600) for _ in ps]
@@ -132,7 +133,7 @@ def frame_parallel_baseline(W, H, threads_per_proc, ms_per_frame_guess, cores, w
     frames = sum(r[2] for r in res)
     return {"value": round(frames * W * H / span / 1e6, 2), "unit": "Mpixels/s", "processes": procs, "threads_per_process": tt, "cores": procs * tt,
             "frames": frames, "span_s": round(span, 3), "start_skew_s": round(max(r[0] for r in res) - min(r[0] for r in res), 4),
-            "note": "all workers released by one cross-process barrier after start-up; throughput = frames / (last finish - first start)"}
+            "note": "all workers released by one cross-process barrier after start-up, each processes frames for %.0f s; throughput = frames / (last finish - first start)" % work_s}
 
 
 def cpu_baseline(W, H, budget_s=20.0):
@@ -167,7 +168,7 @@ def cpu_baseline(W, H, budget_s=20.0):
         # ("all host cores via row-band / frame-parallel threads")
         try:
             tt = max(1, min(best, 8))
-            out["frame_parallel"] = frame_parallel_baseline(W, H, tt, sweep[best] * (best / tt if best > tt else 1.0), cores)
+            out["frame_parallel"] = frame_parallel_baseline(W, H, tt, cores)
         except Exception as e:  # reporting only
             out["frame_parallel"] = {"error": str(e)}
         return out

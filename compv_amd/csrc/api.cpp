@@ -52,6 +52,8 @@ struct KhtScratch {
 	uint32_t* hostBits = nullptr; size_t hostBitsWords = 0;    // ... and its pinned host copy: 1/8 of the edge map's bytes cross PCIe
 	KhtBitPlane plane;                                         // the linker's working copy (zero border, destroyed by the walk)
 	std::vector<KhtPoint> linked;                              // points of the strings, string after string
+	KhtPeaksWork peaks;                                        // sort records, visited map, axes of the peak stage
+	std::vector<KhtCell> cellsHost;                            // the vote cells of the frame, downloaded
 	double stageMs[6] = {};   // link, subdivide (GPU), statistics (GPU), prune + Gmin, vote + peaks (GPU), sort + sweep: last frame (ctx) / sums (plan worker)
 	std::string err;
 };
@@ -1555,7 +1557,8 @@ static int khtFrame(compvhip_ctx* ctx, KhtScratch& K, size_t W, size_t H, const 
 	int cellCount = 0;
 	KCHK(K, hipMemcpyAsync(&cellCount, K.cellCount, sizeof(int), hipMemcpyDeviceToHost, st));
 	KCHK(K, hipStreamSynchronize(st));
-	std::vector<KhtCell> cells(static_cast<size_t>(std::min<int>(cellCount, static_cast<int>(cellCap))));
+	std::vector<KhtCell>& cells = K.cellsHost;
+	cells.resize(static_cast<size_t>(std::min<int>(cellCount, static_cast<int>(cellCap))));
 	if (!cells.empty()) {
 		KCHK(K, hipMemcpyAsync(cells.data(), K.cells, cells.size() * sizeof(KhtCell), hipMemcpyDeviceToHost, st));
 		KCHK(K, hipStreamSynchronize(st));
@@ -1563,7 +1566,7 @@ static int khtFrame(compvhip_ctx* ctx, KhtScratch& K, size_t W, size_t H, const 
 	K.stageMs[4] += msSince(t3);
 	t3 = clk::now();
 	// host: sort + sweep (order dependent, :1195-1247)
-	khtPeaks(ax, cells, maxLines, out);
+	khtPeaks(ax, cells, maxLines, out, K.peaks);
 	K.stageMs[5] += msSince(t3);
 	return COMPVHIP_OK;
 }

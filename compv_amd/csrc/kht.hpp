@@ -35,7 +35,13 @@ void khtLink(KhtBitPlane& plane, size_t minSize, std::vector<KhtPoint>& pts, std
 void khtFinishKernels(std::vector<KhtKernel>& kernels, double& hmax);
 double khtPruneAndScale(std::vector<KhtKernel>& kernels, double hmax, double minHeight);
 void khtVoteParams(const KhtAxes& ax, const std::vector<KhtKernel>& kernels, std::vector<KhtVoteParams>& params);
-void khtPeaks(const KhtAxes& ax, std::vector<KhtCell>& cells, int maxLines, std::vector<KhtLine>& lines);
+// buffers of the peak stage that survive from frame to frame (one per KhtScratch)
+struct KhtPeaksWork {
+	struct Rec { int32_t count; uint32_t pos; };
+	std::vector<KhtCell> tmp; std::vector<Rec> recs; std::vector<uint8_t> visited; std::vector<double> rho, theta;
+	size_t axW = 0, axH = 0; double axRho = 0.0, axTheta = 0.0;
+};
+void khtPeaks(const KhtAxes& ax, std::vector<KhtCell>& cells, int maxLines, std::vector<KhtLine>& lines, KhtPeaksWork& work);
 
 // GPU stages
 struct KhtGpuArgs {

@@ -315,15 +315,15 @@ void khtVoteParams(const KhtAxes& ax, const std::vector<KhtKernel>& kernels, std
 // Section 3.4 (:1195-1247): std::sort on the count alone -- unstable but deterministic for one libstdc++ and one input
 // order, which is why the cells are first put into the reference's emission order (theta-major; within a theta row the SIMD
 // scan, then the scalar remainder) -- then the sweep with the visited map.
-void khtPeaks(const KhtAxes& ax, std::vector<KhtCell>& cells, int maxLines, std::vector<KhtLine>& lines)
+void khtPeaks(const KhtAxes& ax, std::vector<KhtCell>& cells, int maxLines, std::vector<KhtLine>& lines, KhtPeaksWork& wk)
 {
 	lines.clear();
 	// (1) the reference's emission order: `order` is a unique key below 2^32 -- LSD radix sort, 11 bits per pass, only the passes the largest key needs
 	{
 		uint32_t maxKey = 0;
 		for (const KhtCell& c : cells) maxKey = std::max(maxKey, c.order);
-		std::vector<KhtCell> tmp(cells.size());
-		KhtCell* src = cells.data(); KhtCell* dst = tmp.data();
+		wk.tmp.resize(cells.size());
+		KhtCell* src = cells.data(); KhtCell* dst = wk.tmp.data();
 		for (int shift = 0; shift < 32 && (maxKey >> shift) != 0; shift += 11) {
 			uint32_t hist[2048] = { 0 };
 			for (size_t i = 0; i < cells.size(); ++i) ++hist[(src[i].order >> shift) & 2047u];
@@ -336,15 +336,21 @@ void khtPeaks(const KhtAxes& ax, std::vector<KhtCell>& cells, int maxLines, std:
 	}
 	// (2) the reference's std::sort on the count alone (:1195-1205): unstable, but a function of the sequence of counts only -- the permutation is
 	// found on 8-byte (count, position) records (same comparisons, same moves as on the cells themselves, half the bytes) and applied afterwards
-	struct Rec { int32_t count; uint32_t pos; };
-	std::vector<Rec> recs(cells.size());
+	std::vector<KhtPeaksWork::Rec>& recs = wk.recs;
+	recs.resize(cells.size());
 	for (size_t i = 0; i < cells.size(); ++i) { recs[i].count = cells[i].count; recs[i].pos = static_cast<uint32_t>(i); }
-	std::sort(recs.begin(), recs.end(), [](const Rec& a, const Rec& b) { return a.count > b.count; });
-	std::vector<double> rho, theta;
-	khtFillAxes(ax, rho, theta);
+	std::sort(recs.begin(), recs.end(), [](const KhtPeaksWork::Rec& a, const KhtPeaksWork::Rec& b) { return a.count > b.count; });
+	// the axes and the visited map live in the caller's workspace: a worker thread of the batch entry point would otherwise map and unmap a megabyte per
+	// frame (32 threads doing that at once spent more time in the kernel's address-space lock than in the sweep)
+	if (wk.axW != ax.W || wk.axH != ax.H || wk.axRho != ax.dRho || wk.axTheta != ax.dThetaDeg || wk.rho.size() != ax.rhoN) {
+		khtFillAxes(ax, wk.rho, wk.theta);
+		wk.axW = ax.W; wk.axH = ax.H; wk.axRho = ax.dRho; wk.axTheta = ax.dThetaDeg;
+	}
+	const std::vector<double>& rho = wk.rho; const std::vector<double>& theta = wk.theta;
 	const size_t vs = ax.rhoN + 2;
-	std::vector<uint8_t> visited((ax.T + 2) * vs, 0);
-	for (const Rec& rec : recs) {
+	if (wk.visited.size() != (ax.T + 2) * vs) wk.visited.assign((ax.T + 2) * vs, 0);
+	std::vector<uint8_t>& visited = wk.visited;   // all zero on entry; the cells marked below are cleared again on the way out
+	for (const KhtPeaksWork::Rec& rec : recs) {
 		const KhtCell& c = cells[rec.pos];
 		uint8_t* p = visited.data() + static_cast<size_t>(c.thetaIndex) * vs + c.rhoIndex;
 		const uint8_t *t = p - vs, *b = p + vs;
@@ -359,6 +365,7 @@ void khtPeaks(const KhtAxes& ax, std::vector<KhtCell>& cells, int maxLines, std:
 		}
 		*p = 0xff;
 	}
+	for (const KhtCell& c : cells) visited[static_cast<size_t>(c.thetaIndex) * vs + c.rhoIndex] = 0;
 	if (maxLines > 0 && lines.size() > static_cast<size_t>(maxLines)) lines.resize(static_cast<size_t>(maxLines));
 }
 
