@@ -250,7 +250,13 @@ __global__ __launch_bounds__(WAVES * 64, 8) void canny_swar_tile_kernel(CannyArg
 	asm volatile("" : "+v"(tanQ), "+v"(tHighV));
 #endif
 
-#ifdef LAB_PF2
+#if defined(LAB_PF4)
+	uint32_t nb[4][3];
+	load(y0 - 2, nb[0][0], nb[0][1], nb[0][2]);
+	load(y0 - 1, nb[1][0], nb[1][1], nb[1][2]);
+	load(y0, nb[2][0], nb[2][1], nb[2][2]);
+	load(y0 + 1, nb[3][0], nb[3][1], nb[3][2]);
+#elif defined(LAB_PF2)
 	uint32_t nb[2][3];
 	load(y0 - 2, nb[0][0], nb[0][1], nb[0][2]);
 	load(y0 - 1, nb[1][0], nb[1][1], nb[1][2]);
@@ -409,7 +415,10 @@ __global__ __launch_bounds__(WAVES * 64, 8) void canny_swar_tile_kernel(CannyArg
 		// issued after a store also waits for that store's acknowledgement -- a whole step lies between these stores and that wait
 		if constexpr (PH == 0) { if (it >= 8) flush(it - 8); }
 #endif
-#ifdef LAB_PF2
+#if defined(LAB_PF4)
+		const uint32_t m = nb[PH][0], l = nb[PH][1], r = nb[PH][2];
+		load(yin + 4, nb[PH][0], nb[PH][1], nb[PH][2]); // prefetch, four rows ahead
+#elif defined(LAB_PF2)
 		const uint32_t m = nb[PH & 1][0], l = nb[PH & 1][1], r = nb[PH & 1][2];
 		load(yin + 2, nb[PH & 1][0], nb[PH & 1][1], nb[PH & 1][2]); // prefetch, two rows ahead
 #else
