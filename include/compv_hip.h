@@ -279,10 +279,13 @@ COMPVHIP_API int compvhip_plan_pipeline_ex(compvhip_plan* plan, const uint8_t* d
 
 /* CompVHoughKht::process (compvhip_houghkht_u8 semantics, same knobs) on the plan's `frames` DEVICE edge maps d_edges = [frames][H][S]
  * ({0, non-zero} bytes, e.g. the edge maps a compvhip_plan_canny / _pipeline call produced); results in HOST memory: lines[f * cap ..] /
- * counts[f] / gs[f] (gs optional; gs[f] is left untouched for a frame without surviving kernels, like the reference's m_dGS).  Synchronous.
- * The edge-linking stage is a sequential chain walk per frame and runs on the host; frames are independent, so hostThreads workers
- * (0 = min(32, hardware threads / 2)) each take frames in turn with their own HIP stream: frame download, linking, and the GPU stages of
- * one frame overlap with those of the other workers'.  COMPVHIP_E_OUT_OF_BOUND when a frame has more than cap lines (counts[f] tells).
+ * counts[f] / gs[f] (gs optional; gs[f] is left untouched for a frame without surviving kernels, like the reference's m_dGS).  Synchronous,
+ * and it drains the device first (hipDeviceSynchronize): whatever stream produced d_edges has finished before a worker reads them.
+ * The edge-linking stage is a sequential chain walk per frame and runs on the host (on a bit plane: the edge maps leave the device as bit masks);
+ * frames are independent, so hostThreads workers (0 = min(32, hardware threads / 2)) each take frames in turn with their own HIP stream: frame
+ * download, linking, and the GPU stages of one frame overlap with those of the other workers'.  COMPVHIP_E_OUT_OF_BOUND when a frame has more
+ * than cap lines (counts[f] tells); on any other failure the error text names the frame.  clusterMinSize must be >= 2 (for 1 the reference's
+ * cluster subdivision does not terminate: a defined deviation, also of compvhip_houghkht_u8 / compvhip_houghkht_kernels_u8).
  * compvhip_plan_houghkht_stage_ms: the six stage clocks of the last call summed over its frames (compvhip_houghkht_stage_ms order), the wall
  * time of the call and the number of workers. */
 COMPVHIP_API int compvhip_plan_houghkht(compvhip_plan* plan, const uint8_t* d_edges, float rho, float thetaDeg, int threshold, int maxLines,

@@ -699,6 +699,8 @@ hipError_t launch_canny_tiles_swar(const CannyArgs& a0, int frames, bool gap, hi
 	// the launch (a tile's time follows its candidate count).
 #ifdef LAB_PAIRS2
 	return launch_swar<2, 32>(a0, frames, gap, stream);
+#elif defined(LAB_ROWS)
+	return launch_swar<1, LAB_ROWS>(a0, frames, gap, stream);
 #else
 	return launch_swar<1, 32>(a0, frames, gap, stream);
 #endif
