@@ -39,7 +39,7 @@ EXPORTS = [
     "compvhip_gauss_kernel_fixedpoint", "compvhip_convlt1_fixedpoint_u8", "compvhip_plan_convlt1_fixedpoint", "compvhip_plan_to_cartesian",
     "compvhip_plan_pipeline_async", "compvhip_plan_wait", "compvhip_houghsht_to_cartesian", "compvhip_houghkht_to_cartesian",
     "compvhip_houghkht_kernels_u8", "compvhip_houghkht_stage_ms", "compvhip_convlt1_8u16s16s", "compvhip_convlt1_16s16s16s",
-    "compvhip_plan_pipeline_ex", "compvhip_plan_houghkht", "compvhip_plan_houghkht_stage_ms",
+    "compvhip_plan_pipeline_ex", "compvhip_plan_houghkht", "compvhip_plan_houghkht_stage_ms", "compvhip_houghkht_link_u8",
 ]
 
 
@@ -389,6 +389,23 @@ class Plan:
         ms = (C.c_float * cap)()
         n = self.lib.compvhip_plan_get_timing(self.h, names, ms, cap)
         return [(names[i].decode(), ms[i]) for i in range(max(n, 0))]
+
+
+def houghkht_link(edges, min_size=10):
+    """The host stage of KHT alone (compvhip_houghkht_link_u8, no device): (points[n, 2] int32 as (x, y), string end indices)."""
+    lib = load()
+    e = np.ascontiguousarray(edges, dtype=np.uint8)
+    H, W = e.shape
+    sz = C.c_size_t
+    lib.compvhip_houghkht_link_u8.argtypes = [C.c_void_p, sz, sz, sz, sz, C.c_void_p, sz, C.c_void_p, C.c_void_p, sz, C.c_void_p]
+    n_set = int((e != 0).sum())
+    xy = np.zeros((max(n_set, 1), 2), np.int32)
+    ends = np.zeros(max(n_set, 1), np.uint32)
+    npts, nstr = sz(0), sz(0)
+    rc = lib.compvhip_houghkht_link_u8(_ptr(e), W, H, e.strides[0], min_size, _ptr(xy), len(xy), C.byref(npts), _ptr(ends), len(ends), C.byref(nstr))
+    if rc:
+        raise CompvHipError(rc, "compvhip_houghkht_link_u8")
+    return xy[:npts.value].copy(), ends[:nstr.value].copy()
 
 
 def to_cartesian(W, H, lines, kht=False):

@@ -1619,6 +1619,25 @@ int compvhip_houghkht_kernels_u8(compvhip_ctx* ctx, const uint8_t* edges, size_t
 	return COMPVHIP_OK;
 }
 
+int compvhip_houghkht_link_u8(const uint8_t* edges, size_t W, size_t H, size_t S, size_t clusterMinSize, int32_t* xy, size_t cap, size_t* nPoints,
+                              uint32_t* stringEnds, size_t stringCap, size_t* nStrings)
+{
+	if (!edges || !nPoints || !nStrings || (cap && !xy) || (stringCap && !stringEnds) || S < W || !W || !H || !clusterMinSize || W > 32767 || H > 32767)
+		return COMPVHIP_E_INVALID_PARAMETER;
+	try {
+		KhtBitPlane plane;
+		std::vector<KhtPoint> pts; std::vector<KhtRange> strings;
+		khtPackBytes(edges, W, H, S, plane);
+		khtLink(plane, clusterMinSize, pts, strings);
+		*nPoints = pts.size(); *nStrings = strings.size();
+		if (pts.size() > cap || strings.size() > stringCap) return COMPVHIP_E_OUT_OF_BOUND;
+		for (size_t i = 0; i < pts.size(); ++i) { xy[2 * i] = pts[i].x; xy[2 * i + 1] = pts[i].y; }
+		for (size_t i = 0; i < strings.size(); ++i) stringEnds[i] = static_cast<uint32_t>(strings[i].end);
+	}
+	catch (...) { return COMPVHIP_E_OUT_OF_MEMORY; }
+	return COMPVHIP_OK;
+}
+
 int compvhip_houghkht_stage_ms(compvhip_ctx* ctx, double* ms6)
 {
 	if (!ctx || !ms6) return COMPVHIP_E_INVALID_PARAMETER;

@@ -176,6 +176,12 @@ COMPVHIP_API int compvhip_houghkht_kernels_u8(compvhip_ctx* ctx, const uint8_t* 
                                               double clusterMinDeviation, size_t clusterMinSize,
                                               double* kernels7, size_t cap, size_t* n, double* hmax);
 COMPVHIP_API int compvhip_houghkht_stage_ms(compvhip_ctx* ctx, double* ms6);
+/* The host stage of KHT on its own -- linking_AppendixA (houghkht.cxx:544-760) on the bit-plane linker, no device involved (ctx is not needed):
+ * xy receives the (x, y) pairs of the points of all strings, string after string (2 * *nPoints int32; cap = capacity in POINTS), stringEnds[i] the
+ * index one past the last point of string i (string i = points [stringEnds[i-1], stringEnds[i])).  COMPVHIP_E_OUT_OF_BOUND when a capacity is too
+ * small (*nPoints / *nStrings hold what is needed).  What CPU-only hosts test the linker with. */
+COMPVHIP_API int compvhip_houghkht_link_u8(const uint8_t* edges, size_t W, size_t H, size_t S, size_t clusterMinSize, int32_t* xy, size_t cap, size_t* nPoints,
+                                           uint32_t* stringEnds, size_t stringCap, size_t* nStrings);
 
 /* CompVHoughSht::toCartesian (core/features/hough/compv_core_feature_houghsht.cxx:264-304,566-589) and
  * CompVHoughKht::toCartesian (core/features/hough/compv_core_feature_houghkht.cxx:449-489,1249-1280) for caller-held polar lines:

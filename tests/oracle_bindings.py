@@ -130,6 +130,35 @@ class Oracle:
         assert r == 0, r
         return [(buf[i].rho, buf[i].theta, buf[i].strength, buf[i].rho_index, buf[i].theta_index) for i in range(min(n.value, cap))], gs.value
 
+    def kht_link(self, edges, min_size=10):
+        """linking_AppendixA restated (oracle/kht_oracle.c::orc_kht_link): (points[n, 2] int32 as (x, y), string end indices)."""
+        H, W = edges.shape
+        L = self.lib
+        sz = C.c_size_t
+
+        class Pos(C.Structure):
+            _fields_ = [("y", C.c_int), ("x", C.c_int), ("cy", C.c_double), ("cx", C.c_double)]
+
+        class Range(C.Structure):
+            _fields_ = [("begin", sz), ("end", sz)]
+        L.orc_kht_link.argtypes = [C.c_void_p, sz, sz, sz, sz, C.POINTER(C.c_void_p), C.POINTER(sz), C.POINTER(C.c_void_p), C.POINTER(sz)]
+        L.orc_free.argtypes = [C.c_void_p]
+        poss = C.c_void_p(); strings = C.c_void_p()
+        npos = sz(0); ns = sz(0)
+        assert L.orc_kht_link(_p(edges), W, H, edges.strides[0], min_size, C.byref(poss), C.byref(npos), C.byref(strings), C.byref(ns)) == 0
+        try:
+            pa = C.cast(poss, C.POINTER(Pos)); sa = C.cast(strings, C.POINTER(Range))
+            ends = np.array([sa[i].end for i in range(ns.value)], np.uint32)
+            n = int(ends[-1]) if ns.value else 0
+            xy = np.array([(pa[i].x, pa[i].y) for i in range(n)], np.int32).reshape(n, 2)
+            if ns.value:
+                assert sa[0].begin == 0 and all(sa[i].begin == sa[i - 1].end for i in range(1, ns.value))   # strings are contiguous
+            return xy, ends
+        finally:
+            for q in (poss, strings):
+                if q.value:
+                    L.orc_free(q)
+
     def kht_kernels(self, edges, min_dev=2.0, min_size=10):
         """linking_AppendixA + clusters_find + voting_Algorithm2_Kernels restated: (kernels[n, 7] float64 in CompVHoughKhtKernel field
         order, before the height pruning; hmax)."""

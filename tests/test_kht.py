@@ -44,3 +44,37 @@ def test_kht_empty_and_maxlines(oracle):
     full, _ = oracle.kht(can)
     top, _ = oracle.kht(can, max_lines=5)
     assert top == full[:5]
+
+
+@pytest.mark.parametrize("W,H,tl,th,min_size", [(320, 240, 59., 119., 10), (641, 480, 59., 119., 5), (257, 129, 0.8, 1.6, 3), (64, 64, 59., 119., 10),
+                                                 (130, 70, 59., 119., 2), (1282, 720, 0.8, 1.6, 10), (1920, 1080, 59., 119., 10)])
+def test_bit_plane_linker_matches_the_restated_byte_walk(oracle, W, H, tl, th, min_size):
+    """compvhip_houghkht_link_u8 -- the product's host stage of KHT: edge map as a bit plane, 8-bit neighbour code in the reference's priority order +
+    count-trailing-zeros, run following, word-wise seed scan (compv_amd/csrc/kht_host.cpp) -- against the oracle's restatement of the reference's byte
+    walk (linking_AppendixA, houghkht.cxx:544-760): the same strings with the same points in the same order.  No device involved."""
+    from compv_amd import capi
+    img = synth_frame(W, H, 777)
+    rc, edges = oracle.canny(img, tl, th)
+    assert rc == 0
+    for e in (edges, np.ascontiguousarray(edges[:, ::-1]), np.ascontiguousarray(edges.T)):   # + mirrored and transposed maps (other walk directions)
+        exp_xy, exp_ends = oracle.kht_link(e, min_size)
+        got_xy, got_ends = capi.houghkht_link(e, min_size)
+        assert np.array_equal(got_ends, exp_ends)
+        assert np.array_equal(got_xy, exp_xy)
+
+
+def test_bit_plane_linker_borders_and_word_boundaries(oracle):
+    """Pixels on the image border (never seeds, but reachable by a walk), runs across 64-bit word boundaries, isolated pixels, full rows."""
+    from compv_amd import capi
+    rng = np.random.RandomState(5)
+    for W, H in ((63, 9), (64, 9), (65, 9), (128, 5), (129, 33), (200, 3), (3, 200)):
+        e = np.zeros((H, W), np.uint8)
+        e[H // 2, :] = 255                       # a full row: leftward and rightward runs over every word boundary
+        e[:, W // 2] = 255                       # a full column
+        e[0, :] = 255; e[:, 0] = 255; e[H - 1, ::2] = 255; e[::2, W - 1] = 255     # the border
+        e |= (rng.rand(H, W) < 0.08).astype(np.uint8) * 255
+        for ms in (1, 2, 10):
+            exp_xy, exp_ends = oracle.kht_link(e, ms)
+            got_xy, got_ends = capi.houghkht_link(e, ms)
+            assert np.array_equal(got_ends, exp_ends), (W, H, ms)
+            assert np.array_equal(got_xy, exp_xy), (W, H, ms)
