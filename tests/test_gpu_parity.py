@@ -41,6 +41,33 @@ def test_edge_dete_matches_oracle(hip_ctx, oracle, W, H):
         assert (got == exp).all(), (W, H, op, int((got != exp).sum()))
 
 
+def _extreme_images(W, H):
+    yy, xx = np.mgrid[0:H, 0:W]
+    rng = np.random.RandomState(W * 131 + H)
+    return {"vstripes": ((xx & 1) * 255).astype(np.uint8), "hstripes": ((yy & 1) * 255).astype(np.uint8),
+            "checker1": (((xx + yy) & 1) * 255).astype(np.uint8), "checker2": ((((xx >> 1) + (yy >> 1)) & 1) * 255).astype(np.uint8),
+            "binary_noise": (rng.rand(H, W) < 0.5).astype(np.uint8) * 255, "noise": rng.randint(0, 256, (H, W)).astype(np.uint8),
+            "steps": ((xx >= W // 2) * 255).astype(np.uint8), "ramp": ((xx * 255) // max(W - 1, 1)).astype(np.uint8)}
+
+
+@pytest.mark.parametrize("W,H", [(130, 70), (515, 67), (256, 64), (300, 129)])
+def test_packed_gradient_at_extreme_contrast(hip_ctx, oracle, W, H):
+    """The packed (two pixels per register, biased 16-bit halves) gradient of the Canny tile kernel and of the detector kernels at the ends of its
+    value range: 0 / 255 stripes, checkerboards and noise drive |gx|, |gy| to their maxima (1020 for Sobel, 4080 for Scharr) with both signs in adjacent
+    pixels -- a carry or borrow between the halves of a register would show here first."""
+    from compv_amd import capi
+    for name, img in _extreme_images(W, H).items():
+        for op, oop in [(capi.OP_SOBEL, 0), (capi.OP_SCHARR, 2), (capi.OP_PREWITT, 3)]:
+            exp, _ = oracle.edge_dete(img, oop)
+            got = hip_ctx.edge_dete(img, op)
+            assert (got == exp).all(), (name, op, int((got != exp).sum()))
+        for tl, th in ((59.0, 119.0), (1.0, 3.0), (900.0, 2000.0)):
+            rc, exp = oracle.canny(img, tl, th)
+            assert rc == 0
+            got = hip_ctx.canny(img, tl, th)
+            assert (got == exp).all(), (name, tl, th, int((got != exp).sum()))
+
+
 def test_edge_dete_constant_image_is_zero(hip_ctx, oracle):
     img = np.full((48, 80), 77, np.uint8)     # gmax == 0 -> scale = inf -> all zeros (edge_dete.cxx:199)
     exp, gmax = oracle.edge_dete(img)
