@@ -11,6 +11,7 @@ for n in bench_under_rocprof bench_inflight1_under_rocprof kht_under_rocprof; do
   grep '^{' "$P/$n.log" | tail -1 > "$O/$n.json"
 done
 python "$R/tools/pmc_summary.py" "$P/pmc_FETCH_SIZE" "$P/pmc_WRITE_SIZE" "$P/pmc_sq1" "$P/pmc_sq2" > "$O/pmc_counters_per_dispatch.txt" 2>&1
+python "$R/tools/pmc_summary.py" "$P/pmc_kht_FETCH_SIZE" "$P/pmc_kht_WRITE_SIZE" > "$O/kht_pmc_counters_per_dispatch.txt" 2>&1
 python "$R/tools/traffic_from_pmc.py" "$P" "$O/traffic.json" > /dev/null
 [ -f "$P/bench_default_run.json" ] && cp "$P/bench_default_run.json" "$O/bench_default_run.json"
 echo "profiles/$TAG assembled"

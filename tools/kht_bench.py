@@ -16,7 +16,7 @@ stages = []
 wall = []
 for _ in range(reps):
     t0 = time.perf_counter()
-    lines, gs = ctx.houghkht(edges, 1.0, 1.0, 100)
+    lines, gs = ctx.houghkht(edges, 1.0, 1.0, int(sys.argv[2]) if len(sys.argv) > 2 else 100)
     wall.append((time.perf_counter() - t0) * 1e3)
     stages.append(ctx.houghkht_stage_ms())
 st = np.median(np.array(stages), axis=0)
