@@ -22,6 +22,10 @@
 //     (E = strong, U = weak & ~strong) together with the edge BYTES of the strong pixels (16-byte stores).  There is no in-tile flood
 //     any more: the 512-bit carry-chain flood of the first two generations cost 20 % of the kernel in lock step on every tile, the
 //     band kernel does the same work on packed words, only where there is something to do (canny_kernels.hip, canny_resolve_kernel).
+// Round 4 (tools/canny_lab: variants of this kernel compared bit for bit, timed interleaved): with everything above in place the kernel sat on a STORE floor, not on
+// the VALU -- the list and the NMS cost nothing while the stores were there.  The 16 edge bytes of a lane leave as ONE 16-byte store (the compiler had split them 12 + 4),
+// input rows are fetched two steps ahead, the dense stage uses three-operand forms (v_xad / v_lshl_add / v_add3: 31 instead of 39 instructions per row).  What is left of the
+// floor are the 2-byte stores of the mask dword two tiles share (sub-dword stores cost far more than their bytes here): DESIGN.md section 4.1.
 // A wave owns 240 output columns x kSwRows rows, 4 pixels per lane: lanes 0, 1 and 62, 63 compute the gradient of the 8 columns either
 // side of the tile (the NMS of columns 0 and 239 needs one of them; two lanes per side keep the tile's bit masks half-word aligned:
 // 240 = 15 half-words) but own no pixels.  Every input byte is fetched once per tile (+ 4/64 row halo, + 16/240 column halo).
