@@ -24,6 +24,14 @@
 
 namespace compvhip {
 
+// static_cast<int32_t>(double) as the reference's x86 build performs it (houghkht.cxx:1123, cvttsd2si): a value that does not fit -- the vote of a
+// kernel whose points are EXACTLY collinear (synthetic checkerboards: sigma -> the floor, the Gaussian's peak beyond 2^31) -- or a NaN becomes
+// INT_MIN, "no vote" for the loops below.  v_cvt_i32_f64 saturates to INT_MAX instead and the walk would go on voting (found by tools/fuzz_parity.py).
+__device__ __forceinline__ int cvttsd2si(double v)
+{
+	return (v < 2147483648.0 && v > -2147483649.0) ? (int)v : (int)0x80000000u;
+}
+
 __device__ __forceinline__ double exp_fast_small(double x)
 {
 	// (1 + x/1024)^1024, houghkht.cxx:77-88
@@ -262,7 +270,7 @@ __global__ __launch_bounds__(64) void kht_vote_kernel(KhtGpuArgs a)
 			const double ki = k * incRho;
 			double z = ((rho * rho) * p.srsScale) - krho + w;
 			int votes;
-			while ((rhoIndex <= rhoSize) && (votes = (int)(((p.x * exp_fast_small(-z * p.y)) * a.gs) + 0.5)) > 0) {
+			while ((rhoIndex <= rhoSize) && (votes = cvttsd2si(((p.x * exp_fast_small(-z * p.y)) * a.gs) + 0.5)) > 0) {
 				atomicAdd(&pcount[rhoIndex], votes);
 				rhoIndex += (long long)incRhoIndex;
 				rho += incRho;
@@ -349,3 +357,4 @@ hipError_t launch_kht_peaks(const KhtGpuArgs& a, hipStream_t stream)
 }
 
 } // namespace compvhip
+

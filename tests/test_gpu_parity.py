@@ -554,6 +554,21 @@ def test_houghkht_matches_oracle(hip_ctx, oracle, W, H, tl, th, rho, deg, thr):
         assert _kht_tuple(top) == _kht_tuple(got[:3])
 
 
+@pytest.mark.parametrize("W,H,p,amp", [(697, 34, 4, 200), (700, 40, 8, 150), (946, 27, 3, 180), (1093, 224, 5, 230)])
+def test_houghkht_exactly_collinear_clusters(hip_ctx, oracle, W, H, p, amp):
+    """Checkerboards give EXACTLY collinear clusters: the kernels' sigmas hit their floor and the Gaussian's peak vote exceeds 2^31.  The reference
+    converts it with static_cast<int32_t> -- cvttsd2si on its x86 build: INT_MIN, i.e. "no vote" -- and the device conversion saturates to INT_MAX
+    instead unless it is told not to (kht_kernels.hip, cvttsd2si; found by tools/fuzz_parity.py in round 4: lines of strength 2147483627)."""
+    yy, xx = np.mgrid[0:H, 0:W]
+    img = ((((xx // p) + (yy // p)) & 1) * amp).astype(np.uint8)
+    rc, edges = oracle.canny(img, 59.0, 119.0)
+    assert rc == 0
+    exp, gs_exp = oracle.kht(edges, 1.0, 1.0, 1)
+    got, gs = hip_ctx.houghkht(edges, 1.0, 1.0, 1)
+    assert gs == gs_exp and len(exp) > 0
+    assert _kht_tuple(got) == [(float(np.float32(l[0])), float(np.float32(l[1])), int(l[2])) for l in exp]
+
+
 @pytest.mark.parametrize("W,H,tl,th,min_dev,min_size", [(320, 240, 59., 119., 2.0, 10), (1282, 720, 0.8, 1.6, 2.0, 10), (641, 480, 59., 119., 0.5, 5),
                                                          (1920, 1080, 59., 119., 2.0, 10), (333, 77, 0.8, 1.6, 4.0, 3),
                                                          (320, 240, 59., 119., 2.0, 2),      # smallest clusters the recursion can produce
