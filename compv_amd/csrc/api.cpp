@@ -21,6 +21,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <memory>
 #include <vector>
 
 using namespace compvhip;
@@ -51,7 +52,7 @@ struct KhtScratch {
 	uint32_t* dBits = nullptr; size_t dBitsWords = 0;          // plan workers: the frame's edge map as bit-mask rows (bytes_to_bits_kernel), device
 	uint32_t* hostBits = nullptr; size_t hostBitsWords = 0;    // ... and its pinned host copy: 1/8 of the edge map's bytes cross PCIe
 	KhtBitPlane plane;                                         // the linker's working copy (zero border, destroyed by the walk)
-	std::vector<KhtPoint> linked;                              // points of the strings, string after string
+	KhtPoint* linked = nullptr; size_t linkedCap = 0;         // points of the strings, string after string: PINNED host memory, written by the linker, uploaded without staging
 	KhtPeaksWork peaks;                                        // sort records, visited map, axes of the peak stage
 	std::vector<KhtCell> cellsHost;                            // the vote cells of the frame, downloaded
 	double stageMs[6] = {};   // link, subdivide (GPU), statistics (GPU), prune + Gmin, vote + peaks (GPU), sort + sweep: last frame (ctx) / sums (plan worker)
@@ -176,6 +177,7 @@ void khtScratchFree(compvhip_ctx* ctx, KhtScratch& k)
 	dfree(ctx, k.strings); dfree(ctx, k.counts32); dfree(ctx, k.scratch); dfree(ctx, k.stack);
 	dfree(ctx, k.dBits); k.dBitsWords = 0;
 	if (k.hostBits) { (void)hipHostFree(k.hostBits); k.hostBits = nullptr; k.hostBitsWords = 0; }
+	if (k.linked) { (void)hipHostFree(k.linked); k.linked = nullptr; k.linkedCap = 0; }
 	if (k.ownStream && k.stream) { (void)hipStreamDestroy(k.stream); k.stream = nullptr; }
 }
 
@@ -1454,12 +1456,21 @@ static int khtBuildKernels(compvhip_ctx* ctx, KhtScratch& K, size_t W, size_t H,
 	auto ms = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
 	kernels.clear(); hmax = 0.0;
 	const auto t0 = clk::now();
-	std::vector<KhtPoint>& pts = K.linked; std::vector<KhtRange> strings;
-	khtLink(K.plane, clusterMinSize, pts, strings);
+	std::vector<KhtRange> strings;
+	const size_t most = khtPlaneCount(K.plane);
+	if (most > 0x7fffffffull) { K.err = "too many edge pixels"; return COMPVHIP_E_INVALID_PARAMETER; }
+	if (K.linkedCap < most) {
+		KCHK(K, hipSetDevice(ctx->device));
+		if (K.linked) (void)hipHostFree(K.linked);
+		K.linked = nullptr; K.linkedCap = 0;
+		const size_t want = most + most / 4 + 4096;   // (frames of a stream resemble each other: no reallocation for a slightly denser one)
+		KCHK(K, hipHostMalloc(reinterpret_cast<void**>(&K.linked), want * sizeof(KhtPoint)));
+		K.linkedCap = want;
+	}
+	const size_t nPts = khtLink(K.plane, clusterMinSize, K.linked, strings);
 	const auto t1 = clk::now();
 	K.stageMs[0] += ms(t0, t1);
 	if (strings.empty()) return COMPVHIP_OK;
-	if (pts.size() > 0x7fffffffull) { K.err = "too many edge pixels"; return COMPVHIP_E_INVALID_PARAMETER; }
 
 	// device: cluster subdivision (one wave per string), per-cluster statistics (one thread per cluster)
 	std::vector<KhtStringDesc> descs(strings.size());
@@ -1470,7 +1481,7 @@ static int khtBuildKernels(compvhip_ctx* ctx, KhtScratch& K, size_t W, size_t H,
 		slots += khtSubdivSlots(strings[i].end - strings[i].begin, clusterMinSize);
 	}
 	KCHK(K, hipSetDevice(ctx->device));
-	if (K.ptsCap < pts.size()) { dfree(ctx, K.pts); K.ptsCap = 0; KCHK(K, dmalloc(ctx, &K.pts, pts.size())); K.ptsCap = pts.size(); }
+	if (K.ptsCap < nPts) { dfree(ctx, K.pts); K.ptsCap = 0; KCHK(K, dmalloc(ctx, &K.pts, K.linkedCap)); K.ptsCap = K.linkedCap; }
 	if (K.stringsCap < descs.size()) {
 		dfree(ctx, K.strings); dfree(ctx, K.counts32); K.stringsCap = 0;
 		KCHK(K, dmalloc(ctx, &K.strings, descs.size())); KCHK(K, dmalloc(ctx, &K.counts32, descs.size() + 2)); K.stringsCap = descs.size();
@@ -1481,7 +1492,7 @@ static int khtBuildKernels(compvhip_ctx* ctx, KhtScratch& K, size_t W, size_t H,
 		KCHK(K, dmalloc(ctx, &K.kernelsDev, slots)); K.spansCap = slots;
 	}
 	hipStream_t st = K.stream;
-	KCHK(K, hipMemcpyAsync(K.pts, pts.data(), pts.size() * sizeof(KhtPoint), hipMemcpyHostToDevice, st));
+	KCHK(K, hipMemcpyAsync(K.pts, K.linked, nPts * sizeof(KhtPoint), hipMemcpyHostToDevice, st));
 	KCHK(K, hipMemcpyAsync(K.strings, descs.data(), descs.size() * sizeof(KhtStringDesc), hipMemcpyHostToDevice, st));
 	KhtSubdivArgs sv;
 	sv.pts = K.pts; sv.strings = K.strings; sv.nStrings = static_cast<int>(descs.size());
@@ -1626,12 +1637,13 @@ int compvhip_houghkht_link_u8(const uint8_t* edges, size_t W, size_t H, size_t S
 		return COMPVHIP_E_INVALID_PARAMETER;
 	try {
 		KhtBitPlane plane;
-		std::vector<KhtPoint> pts; std::vector<KhtRange> strings;
+		std::vector<KhtRange> strings;
 		khtPackBytes(edges, W, H, S, plane);
-		khtLink(plane, clusterMinSize, pts, strings);
-		*nPoints = pts.size(); *nStrings = strings.size();
-		if (pts.size() > cap || strings.size() > stringCap) return COMPVHIP_E_OUT_OF_BOUND;
-		for (size_t i = 0; i < pts.size(); ++i) { xy[2 * i] = pts[i].x; xy[2 * i + 1] = pts[i].y; }
+		std::unique_ptr<KhtPoint[]> pts(new KhtPoint[khtPlaneCount(plane) + 1]);
+		const size_t n = khtLink(plane, clusterMinSize, pts.get(), strings);
+		*nPoints = n; *nStrings = strings.size();
+		if (n > cap || strings.size() > stringCap) return COMPVHIP_E_OUT_OF_BOUND;
+		for (size_t i = 0; i < n; ++i) { xy[2 * i] = pts[i].x; xy[2 * i + 1] = pts[i].y; }
 		for (size_t i = 0; i < strings.size(); ++i) stringEnds[i] = static_cast<uint32_t>(strings[i].end);
 	}
 	catch (...) { return COMPVHIP_E_OUT_OF_MEMORY; }

@@ -31,7 +31,9 @@ struct KhtBitPlane {
 void khtPackBytes(const uint8_t* edges, size_t W, size_t H, size_t S, KhtBitPlane& plane);
 void khtPlaneFromWords(const uint32_t* words, size_t wordsPerRow, size_t W, size_t H, KhtBitPlane& plane);
 // Appendix A: strings of linked pixels, in the reference's order; destroys the plane
-void khtLink(KhtBitPlane& plane, size_t minSize, std::vector<KhtPoint>& pts, std::vector<KhtRange>& strings);
+size_t khtPlaneCount(const KhtBitPlane& plane);   // set pixels = the most points khtLink can write
+// pts: room for khtPlaneCount(plane) points; returns the number of points written (string after string)
+size_t khtLink(KhtBitPlane& plane, size_t minSize, KhtPoint* pts, std::vector<KhtRange>& strings);
 void khtFinishKernels(std::vector<KhtKernel>& kernels, double& hmax);
 double khtPruneAndScale(std::vector<KhtKernel>& kernels, double hmax, double minHeight);
 void khtVoteParams(const KhtAxes& ax, const std::vector<KhtKernel>& kernels, std::vector<KhtVoteParams>& params);

@@ -53,12 +53,13 @@ void khtFillAxes(const KhtAxes& ax, std::vector<double>& rho, std::vector<double
 // ---- Appendix A: linking (Algorithms 5 and 6) on a bit plane ------------------------------------------------------------------------------
 // The reference walks a byte map: per step up to eight neighbour tests in the fixed priority TL,T,TR, L,R, BL,B,BR (:666-703), and the raster
 // scan for the next seed touches every byte.  Here the edge map is ONE BIT per pixel in rows of 64-bit words with a zero border (a pad word left
-// and right of every row, zero rows above and below): a step reads the 3-bit windows of the rows y-1, y, y+1 from three aligned words, packs them
-// into an 8-bit code whose bit order IS the priority order -- bit 0 = TL ... bit 7 = BR -- and the next pixel is count-trailing-zeros of that
-// code; pixels outside the image read as zero, which is what the reference's bounds tests amount to.  Loads and the erasing store are aligned
-// 64-bit accesses of the same words (a narrower store followed by a wider load of the same bytes defeats store forwarding: +40 % on the walk).
-// The seed scan walks the words.  The device-resident batch path downloads the plane already packed (1/8 of the bytes).  Same strings, same
-// point order as the byte walk (tests: fixtures from the compiled reference).
+// and right of every row, zero rows above and below): a step reads the 3-bit windows of the rows y-1, y, y+1, packs them into a 9-bit code whose
+// bit order IS the priority order (TL T TR | L C R | BL B BR, the centre masked out) and looks the next pixel up by that code; pixels outside the
+// image read as zero, which is what the reference's bounds tests amount to.  Loads and the erasing store are aligned 64-bit accesses of the same
+// words (a narrower store followed by a wider load of the same bytes defeats store forwarding: +40 % on the walk).  The seed scan walks the words.
+// The device-resident batch path downloads the plane already packed (1/8 of the bytes).  Same strings, same point order as the byte walk (tests:
+// fixtures from the compiled reference).  tools/kht_lab/link_bench times this file alone (4K benchmark map, EPYC 9575F host of the GPU box: 2.6 ms,
+// 7.8 ns per linked pixel -- the dependency chain of a step: three loads -> code -> table -> next address).
 void KhtBitPlane::reset(size_t W_, size_t H_)
 {
 	W = W_; H = H_;
@@ -117,65 +118,113 @@ void khtPlaneFromWords(const uint32_t* words, size_t wordsPerRow, size_t W, size
 	}
 }
 
-void khtLink(KhtBitPlane& plane, size_t minSize, std::vector<KhtPoint>& pts, std::vector<KhtRange>& strings)
+namespace {
+// Horizontal run of the walk, many pixels per call (out of line: inlined, its registers cost the single-step loop a sixth of its speed).  The walk stands on
+// pixel x (bit bx of *mw) and its next step goes right (d == 5: nothing above, nothing to the left) or left (d == 3: nothing above): it goes on to x +- 2, ...
+// for as long as the next pixel is set and the pixel it is LEFT FROM has nothing in the row above (its other neighbour in the row is the pixel just erased;
+// L and R outrank the row below).  Within the current word.  Erases and appends the n >= 1 pixels of the run; returns n.
+__attribute__((noinline)) int khtRun(uint64_t* mw, ptrdiff_t P, int bx, bool right, int x, int y, KhtPoint* out)
 {
-	pts.clear(); strings.clear();
+	const uint64_t* const tw = mw - P;
+	const uint64_t T0 = tw[0];
+	// blocked pixels: the row above has a pixel at p - 1, p or p + 1 (neighbour words included); bit bx is clear
+	const uint64_t blk = T0 | (T0 << 1) | (T0 >> 1) | (tw[-1] >> 63) | (tw[1] << 63);
+	int n;
+	if (right) {
+		const int cntSet = __builtin_ctzll(~(mw[0] >> (bx + 1)));              // set pixels right of x, up to the end of the word
+		const uint64_t br = blk >> bx;                                          // bit j = pixel x + j blocked
+		const int firstBlocked = br ? __builtin_ctzll(br) : 64;
+		n = cntSet < firstBlocked ? cntSet : firstBlocked;                     // >= 1: this is the step the caller's code decided
+		mw[0] &= ~((n >= 64 ? ~0ull : ((1ull << n) - 1ull)) << (bx + 1));
+		for (int j = 1; j <= n; ++j) { out->x = x + j; out->y = y; ++out; }
+	}
+	else {
+		const int cntSet = __builtin_clzll(~(mw[0] << (64 - bx)));             // set pixels left of x, down to the start of the word
+		const uint64_t bl = blk << (63 - bx);                                   // bit 63 - j = pixel x - j blocked
+		const int firstBlocked = bl ? __builtin_clzll(bl) : 64;
+		n = cntSet < firstBlocked ? cntSet : firstBlocked;
+		mw[0] &= ~((n >= 64 ? ~0ull : ((1ull << n) - 1ull)) << (bx - n));
+		for (int j = 1; j <= n; ++j) { out->x = x - j; out->y = y; ++out; }
+	}
+	return n;
+}
+} // namespace
+
+// set pixels of the plane = the most points khtLink can produce (every point it emits erases one)
+size_t khtPlaneCount(const KhtBitPlane& plane)
+{
+	const uint64_t* w = reinterpret_cast<const uint64_t*>(plane.buf.data());
+	const size_t n = plane.buf.size() / 8;
+	size_t c = 0;
+	for (size_t i = 0; i < n; ++i) c += static_cast<size_t>(__builtin_popcountll(w[i]));
+	return c;
+}
+
+// pts: room for khtPlaneCount(plane) points (the caller's buffer: pinned memory on the device path, so that the strings upload without staging)
+size_t khtLink(KhtBitPlane& plane, size_t minSize, KhtPoint* pts, std::vector<KhtRange>& strings)
+{
+	strings.clear();
 	const int W = static_cast<int>(plane.W), H = static_cast<int>(plane.H);
 	const ptrdiff_t P = static_cast<ptrdiff_t>(plane.pitch / 8);              // words per row
-	uint64_t* const base = reinterpret_cast<uint64_t*>(plane.row(0));          // pixel (x, y) = bit (x & 63) of base[y * P + 1 + (x >> 6)]
-	pts.reserve(static_cast<size_t>(1) << 16);
-	// walks from (x, y) -- a pixel that is already erased -- appending every pixel it reaches and erasing it; returns when no neighbour is left
-	auto walk = [&](int x, int y) {
+	const int64_t PB = static_cast<int64_t>(P) * 64;                           // bits per row
+	uint64_t* const base = reinterpret_cast<uint64_t*>(plane.row(0));          // pixel (x, y) = bit pos = y * PB + 64 + x of the plane behind base (row -1 and the pad words are zero)
+	// The position of the walk is ONE number, the bit index: word = pos >> 6, bit = pos & 63, a step adds dy * PB + dx -- no multiply, no (x, y) -> address
+	// arithmetic in the dependency chain of a step (window loads -> code -> table -> next position); x and y ride along for the output only.
+	// The 9-bit code is TL T TR | L C R | BL B BR with the centre (the pixel the walk stands on) masked out: its lowest set bit is the reference's
+	// priority order (TL, T, TR, L, R, BL, B, BR), d = 3 (dy + 1) + (dx + 1), and the whole step comes out of ONE table lookup by the code
+	// (512 x 8 bytes): bit-index delta, dx, dy, d.
+	struct Step { int32_t delta; int8_t dx, dy, d, pad; };
+	Step steps[512];
+	for (int code = 1; code < 512; ++code) {
+		const int d = __builtin_ctz(static_cast<unsigned>(code));
+		Step s; s.dx = static_cast<int8_t>(d % 3 - 1); s.dy = static_cast<int8_t>(d / 3 - 1); s.d = static_cast<int8_t>(d); s.pad = 0;
+		s.delta = static_cast<int32_t>(s.dy * PB + s.dx);
+		steps[code] = s;
+	}
+	steps[0] = Step{ 0, 0, 0, 4, 0 };
+	// The horizontal-run shortcut (khtRun) pays on line art -- up to 63 pixels per call: a 4K map of stripes links in 0.7 instead of 5.6 ms -- and costs on
+	// noisy maps, whose runs are one or two pixels long (72 000 calls for 120 000 pixels on the benchmark frame).  It is off until kRunProbe horizontal single
+	// steps in a row were seen and switches itself off again while the runs it finds stay short.
+	constexpr int kRunScore = 4, kRunProbe = 32;
+	int runScore = 0, hz = 0;
+	KhtPoint* out = pts;
+	const uint64_t* const rowT = base - P; const uint64_t* const rowB = base + P;   // the rows above / below, same word index
+	// walks from (x, y), appending every pixel it reaches and erasing it (and the start pixel); returns when no neighbour is left
+	auto walk = [&](int64_t pos, int x, int y) {
 		for (;;) {
-			const int q = x + 63;                                  // bit index (in the padded row) of x - 1
-			const uint64_t* c = base + static_cast<ptrdiff_t>(y) * P + (q >> 6);
-			const int sh = q & 63;
-			uint32_t t, m, b;
-			if (sh <= 61) { t = static_cast<uint32_t>(c[-P] >> sh) & 7u; m = static_cast<uint32_t>(c[0] >> sh) & 7u; b = static_cast<uint32_t>(c[P] >> sh) & 7u; }
-			else {                                                 // the window straddles two words (x & 63 is 63 or 0)
-				const int up = 64 - sh;
-				t = static_cast<uint32_t>((c[-P] >> sh) | (c[-P + 1] << up)) & 7u;
-				m = static_cast<uint32_t>((c[0] >> sh) | (c[1] << up)) & 7u;
-				b = static_cast<uint32_t>((c[P] >> sh) | (c[P + 1] << up)) & 7u;
+			int d, bx;
+			// single steps: nothing in this loop but the step itself (the run shortcut is left through a break -- with its call inside the loop the register
+			// allocator spills in the loop, 15 % of the walk)
+			for (;;) {
+				const int64_t q = pos - 1;                               // bit index of the left neighbour
+				const int64_t wi = q >> 6;
+				const int sh = static_cast<int>(q & 63);
+				// the window may straddle two words (x & 63 is 63 or 0: rare in a photograph, 42 % of the steps on the benchmark frames, whose checkerboard edges sit on
+				// multiples of 64): always funnel the next word in -- for sh <= 61 its bits land above the three that are kept -- rather than branch on it
+				const int up = 63 - sh;
+				const uint64_t t = (rowT[wi] >> sh) | ((rowT[wi + 1] << 1) << up);
+				const uint64_t m = (base[wi] >> sh) | ((base[wi + 1] << 1) << up);
+				const uint64_t b = (rowB[wi] >> sh) | ((rowB[wi + 1] << 1) << up);
+				// the pixel the walk stands on is masked out of the code here and erased in memory BEHIND the loads of its window (a store in front of them, to the
+				// very word the centre row is read from, puts a read-modify-write and a store-to-load forward into every step's dependency chain)
+				const uint32_t code = (static_cast<uint32_t>(t & 7u) | (static_cast<uint32_t>(m & 7u) << 3) | (static_cast<uint32_t>(b & 7u) << 6)) & ~0x10u;
+				base[pos >> 6] &= ~(1ull << (pos & 63));
+				if (!code) return;
+				const Step st = steps[code];
+				d = st.d;
+				bx = static_cast<int>(pos & 63);                         // = x & 63
+				if (__builtin_expect(runScore > 0, 0) && ((d == 5 && bx != 63) || (d == 3 && bx != 0))) break;
+				pos += st.delta;
+				x += st.dx;
+				y += st.dy;
+				out->x = x; out->y = y; ++out;
+				hz = (d == 5 || d == 3) ? hz + 1 : 0;                    // (a select, not a branch)
+				if (__builtin_expect(hz >= kRunProbe, 0)) { runScore = kRunScore; hz = 0; }
 			}
-			const uint32_t code = t | ((m & 1u) << 3) | ((m & 4u) << 2) | (b << 5);   // TL T TR L R BL B BR
-			if (!code) return;
-			const int d = __builtin_ctz(code);
-			if ((d == 4 && (x & 63) != 63) || (d == 3 && (x & 63) != 0)) {
-				// Horizontal run, many pixels per iteration.  d == 4: nothing above (t == 0), nothing to the left, so the walk goes to x + 1 -- and on to
-				// x + 2, ... for as long as the next pixel is set and the pixel it is LEFT FROM has nothing in the row above (its left neighbour is the pixel
-				// just erased; R outranks the row below).  d == 3 is the mirror image (L outranks R and the row below).  Within the current word.
-				uint64_t* const mw = base + static_cast<ptrdiff_t>(y) * P + 1 + (x >> 6);
-				const uint64_t* const tw = mw - P;
-				const int bx = x & 63;
-				const uint64_t T0 = tw[0];
-				// blocked pixels: the row above has a pixel at p - 1, p or p + 1 (neighbour words included); bit bx is clear (t == 0)
-				const uint64_t blk = T0 | (T0 << 1) | (T0 >> 1) | (tw[-1] >> 63) | (tw[1] << 63);
-				int n;
-				if (d == 4) {
-					const int cntSet = __builtin_ctzll(~(mw[0] >> (bx + 1)));              // set pixels right of x, up to the end of the word
-					const uint64_t br = blk >> bx;                                          // bit j = pixel x + j blocked
-					const int firstBlocked = br ? __builtin_ctzll(br) : 64;
-					n = cntSet < firstBlocked ? cntSet : firstBlocked;                     // >= 1: this is the step the code above decided
-					mw[0] &= ~((n >= 64 ? ~0ull : ((1ull << n) - 1ull)) << (bx + 1));
-					for (int j = 1; j <= n; ++j) { KhtPoint pt; pt.x = x + j; pt.y = y; pts.push_back(pt); }
-					x += n;
-				}
-				else {
-					const int cntSet = __builtin_clzll(~(mw[0] << (64 - bx)));             // set pixels left of x, down to the start of the word
-					const uint64_t bl = blk << (63 - bx);                                   // bit 63 - j = pixel x - j blocked
-					const int firstBlocked = bl ? __builtin_clzll(bl) : 64;
-					n = cntSet < firstBlocked ? cntSet : firstBlocked;
-					mw[0] &= ~((n >= 64 ? ~0ull : ((1ull << n) - 1ull)) << (bx - n));
-					for (int j = 1; j <= n; ++j) { KhtPoint pt; pt.x = x - j; pt.y = y; pts.push_back(pt); }
-					x -= n;
-				}
-				continue;
-			}
-			x += static_cast<int>((0x9224u >> (2 * d)) & 3u) - 1;   // dx + 1 of the eight directions, two bits each
-			y += static_cast<int>((0xa940u >> (2 * d)) & 3u) - 1;   // dy + 1
-			base[static_cast<ptrdiff_t>(y) * P + 1 + (x >> 6)] &= ~(1ull << (x & 63));
-			KhtPoint pt; pt.x = x; pt.y = y; pts.push_back(pt);
+			const int n = khtRun(base + (pos >> 6), P, bx, d == 5, x, y, out);
+			const int sn = (d == 5) ? n : -n;
+			x += sn; pos += sn; out += n;
+			runScore = (n >= 8) ? (runScore < 62 ? runScore + 2 : 64) : runScore - 1;
 		}
 	};
 	// raster scan of rows 1..H-2, columns 1..W-2 (:552-556), 64 pixels at a time; a walk may erase pixels of the word being scanned: reload
@@ -190,21 +239,22 @@ void khtLink(KhtBitPlane& plane, size_t minSize, std::vector<KhtPoint>& pts, std
 				const uint64_t v = row[k] & valid;
 				if (!v) break;
 				const int xr = 64 * k + __builtin_ctzll(v);
-				const size_t begin = pts.size();
+				const int64_t pr = static_cast<int64_t>(yr) * PB + 64 + xr;
+				KhtPoint* const begin = out;
 				row[k] &= ~(1ull << (xr & 63));
-				KhtPoint seed; seed.x = xr; seed.y = yr; pts.push_back(seed);
-				walk(xr, yr);                                        // forward: append and erase (:724-728)
-				const size_t rev = pts.size();
-				walk(xr, yr);                                        // backward from the reference pixel (:733-746)
-				const size_t end = pts.size();
-				if ((end - begin) >= minSize) {
-					std::reverse(pts.begin() + begin, pts.begin() + rev); // the string then runs end to end (:751-755)
-					KhtRange r; r.begin = begin; r.end = end; strings.push_back(r);
+				out->x = xr; out->y = yr; ++out;
+				walk(pr, xr, yr);                                    // forward: append and erase (:724-728)
+				KhtPoint* const rev = out;
+				walk(pr, xr, yr);                                    // backward from the reference pixel (:733-746)
+				if (static_cast<size_t>(out - begin) >= minSize) {
+					std::reverse(begin, rev);                        // the string then runs end to end (:751-755)
+					KhtRange r; r.begin = static_cast<size_t>(begin - pts); r.end = static_cast<size_t>(out - pts); strings.push_back(r);
 				}
-				else pts.resize(begin);
+				else out = begin;
 			}
 		}
 	}
+	return static_cast<size_t>(out - pts);
 }
 
 namespace {

@@ -78,3 +78,29 @@ def test_bit_plane_linker_borders_and_word_boundaries(oracle):
             got_xy, got_ends = capi.houghkht_link(e, ms)
             assert np.array_equal(got_ends, exp_ends), (W, H, ms)
             assert np.array_equal(got_xy, exp_xy), (W, H, ms)
+
+
+def test_bit_plane_linker_long_runs_switch_the_shortcut_on(oracle):
+    """Line art: the linker's horizontal-run shortcut is off until 32 horizontal single steps in a row were walked and stays on while its runs are long.  Long
+    stripes with gaps, pixels in the row above that end a run (a pixel a run would leave has a neighbour above: the reference turns upwards there), stripes two
+    rows apart, bars crossing them, noise that switches the shortcut off again -- walked rightwards (forward walks) and leftwards (backward walks, mirrored map)."""
+    from compv_amd import capi
+    rng = np.random.RandomState(11)
+    for W, H, noise in ((700, 64, 0.0), (1000, 90, 0.002), (513, 70, 0.01), (2000, 40, 0.0005)):
+        e = np.zeros((H, W), np.uint8)
+        for y in range(3, H - 3, 5):
+            e[y, 2:W - 2] = 255
+            for g in rng.randint(3, W - 3, size=W // 150):           # gaps
+                e[y, g:g + rng.randint(1, 4)] = 0
+            for g in rng.randint(3, W - 3, size=W // 100):           # blockers in the row above
+                e[y - 1, g] = 255
+        e[6:H - 6:10, 5:W - 5:3] = 255                              # dotted rows two above a stripe
+        e[2:H - 2, W // 3] = 255; e[2:H - 2, (2 * W) // 3 + 1] = 255   # bars
+        e |= (rng.rand(H, W) < noise).astype(np.uint8) * 255
+        for m in (e, np.ascontiguousarray(e[:, ::-1]), np.ascontiguousarray(e[::-1, :])):
+            for ms in (2, 10):
+                exp_xy, exp_ends = oracle.kht_link(m, ms)
+                got_xy, got_ends = capi.houghkht_link(m, ms)
+                assert np.array_equal(got_ends, exp_ends), (W, H, noise, ms)
+                assert np.array_equal(got_xy, exp_xy), (W, H, noise, ms)
+

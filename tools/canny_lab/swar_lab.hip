@@ -156,7 +156,29 @@ __global__ __launch_bounds__(WAVES * 64, 8) void canny_swar_tile_kernel(CannyArg
 	uint16_t* const carry = reinterpret_cast<uint16_t*>(lds_all + WAVES * kLdsBytes);
 #else
 	int tileX, group;
+#if defined(LAB_XCD_CONTIG)
+	{
+		// every XCD takes a CONTIGUOUS range of row groups, in order: vertically adjacent tiles (4 shared halo rows) run on the same XCD one after the other
+		const int b = blockIdx.x, xcd = b & 7, k = b >> 3;
+		const int per = (a.groups + 7) >> 3;
+		const int gi = k / a.tilesX;
+		group = xcd * per + gi;
+		tileX = k - gi * a.tilesX;
+		if (gi >= per || group >= a.groups) return;
+	}
+#elif defined(LAB_XCD_COLS)
+	{
+		// column-major inside an XCD's contiguous range: the tiles of one COLUMN strip follow each other (top to bottom)
+		const int b = blockIdx.x, xcd = b & 7, k = b >> 3;
+		const int per = (a.groups + 7) >> 3;
+		tileX = k / per;
+		const int gi = k - tileX * per;
+		group = xcd * per + gi;
+		if (tileX >= a.tilesX || group >= a.groups) return;
+	}
+#else
 	if (!xcd_tile_map(blockIdx.x, a.tilesX, a.groups, tileX, group)) return;
+#endif
 	const int frame = group / a.blockRows;
 	const int tileY = (group - frame * a.blockRows) * WAVES + wave;
 	if (tileY >= a.tilesY) return; // whole wave
@@ -419,8 +441,17 @@ __global__ __launch_bounds__(WAVES * 64, 8) void canny_swar_tile_kernel(CannyArg
 		const uint32_t m = nb[PH][0], l = nb[PH][1], r = nb[PH][2];
 		load(yin + 4, nb[PH][0], nb[PH][1], nb[PH][2]); // prefetch, four rows ahead
 #elif defined(LAB_PF2)
+#if defined(LAB_DPP_LR)
+		// ONE load per lane and row: the neighbouring lanes' dwords arrive through DPP wave shifts (lanes 0 / 63 keep their own dword: halo lanes whose outer columns nothing reads)
+		const uint32_t m = nb[PH & 1][0];
+		uint32_t l = m, r = m;
+		asm volatile("v_mov_b32_dpp %0, %1 wave_shr:1 row_mask:0xf bank_mask:0xf" : "+v"(l) : "v"(m));
+		asm volatile("v_mov_b32_dpp %0, %1 wave_shl:1 row_mask:0xf bank_mask:0xf" : "+v"(r) : "v"(m));
+		nb[PH & 1][0] = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)xm, min(max(yin + 2, 0), H - 1) * S, 0);
+#else
 		const uint32_t m = nb[PH & 1][0], l = nb[PH & 1][1], r = nb[PH & 1][2];
 		load(yin + 2, nb[PH & 1][0], nb[PH & 1][1], nb[PH & 1][2]); // prefetch, two rows ahead
+#endif
 #else
 		const uint32_t m = nm, l = nl, r = nr;
 		load(yin + 1, nm, nl, nr); // prefetch
