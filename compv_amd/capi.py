@@ -32,7 +32,7 @@ FMT_BYTES = [4, 4, 4, 3, 3, 2, 2, 2, 2, 2, 2, 1]
 EXPORTS = [
     "compvhip_device_count", "compvhip_ctx_create", "compvhip_ctx_destroy", "compvhip_last_error",
     "compvhip_live_allocations", "compvhip_edge_dete_u8", "compvhip_canny_u8", "compvhip_houghsht_u8",
-    "compvhip_houghsht_dims", "compvhip_plan_create", "compvhip_plan_destroy", "compvhip_plan_canny",
+    "compvhip_houghsht_dims", "compvhip_houghsht_vote_grid", "compvhip_plan_create", "compvhip_plan_destroy", "compvhip_plan_canny",
     "compvhip_plan_houghsht", "compvhip_plan_pipeline", "compvhip_plan_acc", "compvhip_plan_edge_counts",
     "compvhip_plan_set_timing", "compvhip_plan_get_timing", "compvhip_plan_acc_export", "compvhip_plan_edge_dete",
     "compvhip_houghkht_u8", "compvhip_grayscale_u8", "compvhip_otsu_u8", "compvhip_plan_grayscale", "compvhip_plan_otsu",
@@ -106,6 +106,7 @@ def load():
     L.compvhip_houghkht_u8.argtypes = [vp, vp, sz, sz, sz, C.c_float, C.c_float, i32, i32, C.c_double, sz, C.c_double, vp, sz, C.POINTER(sz),
                                        C.POINTER(C.c_double)]
     L.compvhip_houghsht_dims.argtypes = [sz, sz, C.c_float, C.POINTER(sz), C.POINTER(sz), C.POINTER(C.c_float)]
+    L.compvhip_houghsht_vote_grid.argtypes = [sz, sz, C.c_float, sz, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]
     L.compvhip_plan_create.argtypes = [vp, sz, sz, sz, sz, C.c_float, C.POINTER(vp)]
     L.compvhip_plan_destroy.argtypes = [vp]
     L.compvhip_plan_destroy.restype = None

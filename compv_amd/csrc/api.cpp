@@ -240,57 +240,91 @@ void shtTables(float thetaDeg, size_t T, std::vector<int32_t>& sinQ, std::vector
 }
 
 // ---- tiles of the second-generation vote kernel (sht_tiles_kernels.hip) ----
-// Smallest grid of equal tiles (width a multiple of 32 px) whose rho windows -- per theta, the span of (lx cosQ + ly sinQ + Clo) >> 16
-// over the tile -- have at most kShtMaxWindow rows; fills the [tiles][T] tables K and rowBase (int64 arithmetic here, int32 on the device).
-bool planVoteTiles(size_t W, size_t H, const std::vector<int32_t>& sinQ, const std::vector<int32_t>& cosQ, ShtTileArgs& v, std::vector<int32_t>& kt,
-                   std::vector<int32_t>& rowBase)
+// Grid of equal tiles (width a multiple of 32 px) whose rho windows -- per theta, the span of (lx cosQ + ly sinQ + Clo) >> 16 over the tile -- have at
+// most kShtMaxWindow rows; fills the [tiles][T] tables K and rowBase (int64 arithmetic here, int32 on the device).  Grids are tried in order of tile
+// count (split the dimension with the longer tile side) and the smallest one that fits is taken -- except when it leaves the chip nearly empty (fewer
+// than 64 workgroups = frames x tiles x theta groups: the single-frame plans of the host entry points): then the next four grids are priced with a model
+// calibrated on the 4K benchmark (a workgroup: 67 us per 960 x 720 pixels of tile + 9.3 us per 1208 window rows; the reduce kernel: 36 us per
+// 32 x 12 x 1208 partial-window rows) and the cheapest is taken: 7 x 4 instead of 4 x 3 tiles for one 4K frame, 0.349 -> 0.320 ms per compvhip_houghsht_u8
+// call.  Measured and NOT done: the same model for batches (round 4: 32 x 1080p on 4 x 2 instead of 2 x 2 tiles = three full rounds of the 256 CUs instead
+// of one and a half: no change, that step is bound by the launch chain; 32 x 720p on 4 x 2 instead of 2 x 1: 0.180 against 0.170 ms per step).
+static bool voteGridTables(size_t W, size_t H, const std::vector<int32_t>& sinQ, const std::vector<int32_t>& cosQ, int split, int& nx, int& ny, int& TW, int& TH, long long& worst,
+                           std::vector<int32_t>* kt, std::vector<int32_t>* rowBase)
 {
 	const size_t T = sinQ.size();
 	const long long barrier = static_cast<long long>(W + H);
-	for (int split = 0; split < 512; ++split) {
-		// try grids in order of tile count: split the dimension with the longer tile side
-		int nx = 1, ny = 1;
-		for (int k = 0; k < split; ++k) {
-			const double tw = static_cast<double>(W) / nx, th = static_cast<double>(H) / ny;
-			if (tw >= th) ++nx; else ++ny;
-		}
-		const int TW = static_cast<int>(alignUp((W + nx - 1) / nx, 32)), TH = static_cast<int>((H + ny - 1) / ny);
-		nx = static_cast<int>((W + TW - 1) / TW); // the rounding to 32 columns may save a column of tiles
-		const int tiles = nx * ny;
-		kt.assign(static_cast<size_t>(tiles) * T, 0); rowBase.assign(static_cast<size_t>(tiles) * T, 0);
-		long long worst = 0;
-		for (int ty = 0; ty < ny; ++ty) for (int tx = 0; tx < nx; ++tx) {
-			const long long x0 = static_cast<long long>(tx) * TW, y0 = static_cast<long long>(ty) * TH;
-			const long long mx = TW - 1, my = TH - 1; // largest local coordinates (tiles at the image border are not clipped: simpler, still exact)
-			for (size_t t = 0; t < T; ++t) {
-				const long long c = cosQ[t], sn = sinQ[t];
-				const long long C = x0 * c + y0 * sn;
-				long long Chi = C / 65536; if (C - Chi * 65536 < 0) --Chi; // floor
-				const long long Clo = C - Chi * 65536;
-				const long long corners[4] = { Clo, mx * c + Clo, my * sn + Clo, mx * c + my * sn + Clo };
-				long long qmin = 0, qmax = 0;
-				for (int k = 0; k < 4; ++k) {
-					long long q = corners[k] / 65536; if (corners[k] - q * 65536 < 0) --q;
-					if (k == 0 || q < qmin) qmin = q;
-					if (k == 0 || q > qmax) qmax = q;
-				}
-				// the window starts on a multiple of 16 accumulator rows (d extra rows at its top): the reduce kernel adds whole 16-byte groups of count bytes
-				const long long base = barrier - Chi - qmax;
-				const long long d = ((base % 16) + 16) % 16;
-				worst = std::max(worst, qmax - qmin + 1 + d);
-				kt[(static_cast<size_t>(ty) * nx + tx) * T + t] = static_cast<int32_t>((qmax + d) * 65536 + 65535 - Clo);
-				rowBase[(static_cast<size_t>(ty) * nx + tx) * T + t] = static_cast<int32_t>(base - d);
+	nx = 1; ny = 1;
+	for (int k = 0; k < split; ++k) {
+		const double tw = static_cast<double>(W) / nx, th = static_cast<double>(H) / ny;
+		if (tw >= th) ++nx; else ++ny;
+	}
+	TW = static_cast<int>(alignUp((W + nx - 1) / nx, 32)); TH = static_cast<int>((H + ny - 1) / ny);
+	nx = static_cast<int>((W + TW - 1) / TW); // the rounding to 32 columns may save a column of tiles
+	const int tiles = nx * ny;
+	if (kt) { kt->assign(static_cast<size_t>(tiles) * T, 0); rowBase->assign(static_cast<size_t>(tiles) * T, 0); }
+	worst = 0;
+	for (int ty = 0; ty < ny; ++ty) for (int tx = 0; tx < nx; ++tx) {
+		const long long x0 = static_cast<long long>(tx) * TW, y0 = static_cast<long long>(ty) * TH;
+		const long long mx = TW - 1, my = TH - 1; // largest local coordinates (tiles at the image border are not clipped: simpler, still exact)
+		for (size_t t = 0; t < T; ++t) {
+			const long long c = cosQ[t], sn = sinQ[t];
+			const long long C = x0 * c + y0 * sn;
+			long long Chi = C / 65536; if (C - Chi * 65536 < 0) --Chi; // floor
+			const long long Clo = C - Chi * 65536;
+			const long long corners[4] = { Clo, mx * c + Clo, my * sn + Clo, mx * c + my * sn + Clo };
+			long long qmin = 0, qmax = 0;
+			for (int k = 0; k < 4; ++k) {
+				long long q = corners[k] / 65536; if (corners[k] - q * 65536 < 0) --q;
+				if (k == 0 || q < qmin) qmin = q;
+				if (k == 0 || q > qmax) qmax = q;
+			}
+			// the window starts on a multiple of 16 accumulator rows (d extra rows at its top): the reduce kernel adds whole 16-byte groups of count bytes
+			const long long base = barrier - Chi - qmax;
+			const long long d = ((base % 16) + 16) % 16;
+			worst = std::max(worst, qmax - qmin + 1 + d);
+			if (kt) {
+				(*kt)[(static_cast<size_t>(ty) * nx + tx) * T + t] = static_cast<int32_t>((qmax + d) * 65536 + 65535 - Clo);
+				(*rowBase)[(static_cast<size_t>(ty) * nx + tx) * T + t] = static_cast<int32_t>(base - d);
 			}
 		}
-		if (alignUp(static_cast<size_t>(worst), 16) <= static_cast<size_t>(kShtMaxWindow) && TW <= 1280 && static_cast<long long>(TW - 1) * 65535 + static_cast<long long>(TH - 1) * 65535 < 0x7f000000LL) {
-			v.nx = nx; v.ny = ny; v.TW = TW; v.TH = TH; v.tiles = tiles;
-			v.Rw = static_cast<int>(alignUp(static_cast<size_t>(worst), 16)); v.rwPitch = v.Rw;
-			v.groups = static_cast<int>((T + 63) / 64); v.Tpad = v.groups * 64;
-			v.tileCap = static_cast<size_t>(TW) * TH;
-			return true;
-		}
 	}
-	return false;
+	return alignUp(static_cast<size_t>(worst), 16) <= static_cast<size_t>(kShtMaxWindow) && TW <= 1280 &&
+	       static_cast<long long>(TW - 1) * 65535 + static_cast<long long>(TH - 1) * 65535 < 0x7f000000LL;
+}
+
+bool planVoteTiles(size_t W, size_t H, size_t frames, const std::vector<int32_t>& sinQ, const std::vector<int32_t>& cosQ, ShtTileArgs& v, std::vector<int32_t>& kt,
+                   std::vector<int32_t>& rowBase)
+{
+	const size_t T = sinQ.size();
+	const int groups = static_cast<int>((T + 63) / 64);
+	int first = -1;
+	for (int split = 0; split < 512 && first < 0; ++split) {
+		int nx, ny, TW, TH; long long worst;
+		if (voteGridTables(W, H, sinQ, cosQ, split, nx, ny, TW, TH, worst, nullptr, nullptr)) first = split;
+	}
+	if (first < 0) return false;
+	int best = first; double bestCost = 0.0;
+	int nx0, ny0, TW0, TH0; long long worst0;
+	(void)voteGridTables(W, H, sinQ, cosQ, first, nx0, ny0, TW0, TH0, worst0, nullptr, nullptr);
+	const bool starved = static_cast<double>(frames) * nx0 * ny0 * groups < 64.0;   // a quarter of the CUs at most: single frames (the host entry points)
+	for (int split = first; starved && split <= first + 4; ++split) {
+		int nx, ny, TW, TH; long long worst;
+		if (!voteGridTables(W, H, sinQ, cosQ, split, nx, ny, TW, TH, worst, nullptr, nullptr)) continue;
+		const double rw = static_cast<double>(alignUp(static_cast<size_t>(worst), 16));
+		const double wgs = static_cast<double>(frames) * nx * ny * groups;
+		const double rounds = wgs <= 1024.0 ? std::ceil(wgs / 256.0) : wgs / 256.0;   // a few rounds are quantised, many level out (the dispatcher hands workgroups out as CUs free up)
+		const double perWg = 67.0 * (static_cast<double>(TW) * TH) / (960.0 * 720.0) + 9.3 * rw / 1208.0;
+		const double reduce = 36.0 * (static_cast<double>(frames) * nx * ny * rw) / (32.0 * 12.0 * 1208.0);
+		const double cost = rounds * perWg + reduce;
+		if (split == first || cost < bestCost * 0.97) { best = split; bestCost = cost; }   // a finer grid has to win by 3 % (more partial windows, more memory)
+	}
+	int nx, ny, TW, TH; long long worst;
+	if (!voteGridTables(W, H, sinQ, cosQ, best, nx, ny, TW, TH, worst, &kt, &rowBase)) return false;
+	v.nx = nx; v.ny = ny; v.TW = TW; v.TH = TH; v.tiles = nx * ny;
+	v.Rw = static_cast<int>(alignUp(static_cast<size_t>(worst), 16)); v.rwPitch = v.Rw;
+	v.groups = groups; v.Tpad = v.groups * 64;
+	v.tileCap = static_cast<size_t>(TW) * TH;
+	return true;
 }
 
 // timing mode 1 = every kernel; 2 = only the two kernels bench.py prices against the roofline (an event pair costs a few
@@ -660,6 +694,21 @@ int compvhip_houghkht_to_cartesian(size_t W, size_t H, const compvhip_line* line
 	return COMPVHIP_OK;
 }
 
+int compvhip_houghsht_vote_grid(size_t W, size_t H, float thetaDeg, size_t frames, int* nx, int* ny, int* windowRows)
+{
+	size_t R = 0, T = 0; float st = 0.f;
+	if (!nx || !ny || !windowRows || !frames) return COMPVHIP_E_INVALID_PARAMETER;
+	const int rc = shtDims(W, H, thetaDeg, &R, &T, &st);
+	if (rc) return rc;
+	if (T < 5) return COMPVHIP_E_NOT_IMPLEMENTED;
+	std::vector<int32_t> sq, cq, kt, rb;
+	shtTables(thetaDeg, T, sq, cq);
+	ShtTileArgs v = {};
+	if (!planVoteTiles(W, H, frames, sq, cq, v, kt, rb)) return COMPVHIP_E_NOT_IMPLEMENTED;
+	*nx = v.nx; *ny = v.ny; *windowRows = v.Rw;
+	return COMPVHIP_OK;
+}
+
 int compvhip_houghsht_dims(size_t W, size_t H, float thetaDeg, size_t* R, size_t* T, float* step)
 {
 	if (!R || !T) return COMPVHIP_E_INVALID_PARAMETER;
@@ -698,7 +747,7 @@ int compvhip_plan_create(compvhip_ctx* ctx, size_t W, size_t H, size_t S, size_t
 			if (p->voteTiles && shtDims(W, H, thetaDeg, &R, &T, &step) == COMPVHIP_OK && T >= 5) {
 				std::vector<int32_t> sq, cq;
 				shtTables(thetaDeg, T, sq, cq);
-				if (!planVoteTiles(W, H, sq, cq, p->vt, p->vtKt, p->vtRowBase)) p->voteTiles = false;
+				if (!planVoteTiles(W, H, frames, sq, cq, p->vt, p->vtKt, p->vtRowBase)) p->voteTiles = false;
 			}
 			else p->voteTiles = false;
 			p->lineBlocks = p->voteTiles ? sht_lines_blocks(static_cast<int>(R)) : 0;

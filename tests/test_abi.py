@@ -35,6 +35,28 @@ def test_dims_helper_matches_reference_geometry():
     assert lib.compvhip_houghsht_dims(640, 480, 0.0, ctypes.byref(R), ctypes.byref(T), ctypes.byref(st)) == capi.E_INVALID_PARAMETER
 
 
+def test_vote_grid_helper():
+    """compvhip_houghsht_vote_grid: the tile grid a plan votes with (host arithmetic).  Batches take the smallest grid whose rho windows fit the LDS
+    (4 x 3 at 4K, 2 x 2 at 1080p); a single frame -- a launch that would leave most CUs idle -- takes a finer one; every window fits 1264 rows."""
+    from compv_amd import capi
+    lib = capi.load()
+
+    def grid(W, H, frames, deg=1.0):
+        nx, ny, rw = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+        rc = lib.compvhip_houghsht_vote_grid(W, H, ctypes.c_float(deg), frames, ctypes.byref(nx), ctypes.byref(ny), ctypes.byref(rw))
+        return rc, nx.value, ny.value, rw.value
+    assert grid(3840, 2160, 32)[:3] == (0, 4, 3)
+    assert grid(1920, 1080, 32)[:3] == (0, 2, 2)
+    assert grid(1280, 720, 32)[:3] == (0, 2, 1)
+    rc, nx, ny, rw = grid(3840, 2160, 1)
+    assert rc == 0 and nx * ny > 12
+    for W, H, F in ((3840, 2160, 32), (3840, 2160, 1), (32767, 64, 1), (64, 32767, 1), (8192, 8192, 1), (17, 9, 4), (641, 480, 1)):
+        rc, nx, ny, rw = grid(W, H, F)
+        assert rc == 0 and nx >= 1 and ny >= 1 and 16 <= rw <= 1264 and rw % 16 == 0, (W, H, F, rc, nx, ny, rw)
+    assert grid(640, 480, 0)[0] == capi.E_INVALID_PARAMETER
+    assert grid(640, 480, 1, 0.0)[0] == capi.E_INVALID_PARAMETER
+
+
 def test_no_gpu_means_loud_failure():
     from compv_amd import capi
     lib = capi.load()
