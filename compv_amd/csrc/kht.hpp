@@ -16,12 +16,13 @@ struct KhtLine { float rho, theta; int32_t strength, rhoIndex, thetaIndex; };
 
 // per-kernel constants of vote_Algorithm4, precomputed on the host (all divisions / square roots)
 struct KhtVoteParams { double srsScale, stsScale, sScale, r2, x, y; unsigned rhoIndex, thetaIndex; };
-// one vote cell that passed the 3x3 smoothing + threshold; `order` = position in the reference's emission order
-struct KhtCell { uint32_t order; uint32_t rhoIndex; uint32_t thetaIndex; int32_t count; };
+// one vote cell that passed the 3x3 smoothing + threshold; `order` = position in the reference's emission order = thetaIndex * 2 (rhoN + 2) + rhoIndex, or
+// ... + (rhoN + 2) + rhoIndex for the cells the reference's scalar remainder pushes (quirk Q6): the indices are recovered on the host (8 bytes per cell cross PCIe)
+struct KhtCell { uint32_t order; int32_t count; };
 
 bool khtAxes(size_t W, size_t H, float rho, float thetaDeg, KhtAxes& ax);
 void khtFillAxes(const KhtAxes& ax, std::vector<double>& rho, std::vector<double>& theta);
-struct KhtPoint { int32_t x, y; };
+struct KhtPoint { int16_t x, y; };   // W, H <= 32 767 (the reference keeps int16 coordinates too, canny hysteresis :628); 4 bytes per point: half the upload of the strings
 // the edge map of one frame, one bit per pixel, with a zero border: row y (-1 <= y <= H) starts at row(y); pixel x is bit x + 8 of the row
 struct KhtBitPlane {
 	std::vector<uint8_t> buf; size_t pitch = 0, W = 0, H = 0;
@@ -40,7 +41,8 @@ void khtVoteParams(const KhtAxes& ax, const std::vector<KhtKernel>& kernels, std
 // buffers of the peak stage that survive from frame to frame (one per KhtScratch)
 struct KhtPeaksWork {
 	struct Rec { int32_t count; uint32_t pos; };
-	std::vector<KhtCell> tmp; std::vector<Rec> recs; std::vector<uint8_t> visited; std::vector<double> rho, theta;
+	struct Idx { uint32_t rho, theta; };
+	std::vector<KhtCell> tmp; std::vector<Rec> recs; std::vector<Idx> idx; std::vector<uint8_t> visited; std::vector<double> rho, theta;
 	size_t axW = 0, axH = 0; double axRho = 0.0, axTheta = 0.0;
 };
 void khtPeaks(const KhtAxes& ax, std::vector<KhtCell>& cells, int maxLines, std::vector<KhtLine>& lines, KhtPeaksWork& work);

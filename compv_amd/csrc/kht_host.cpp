@@ -389,6 +389,20 @@ void khtPeaks(const KhtAxes& ax, std::vector<KhtCell>& cells, int maxLines, std:
 	std::vector<KhtPeaksWork::Rec>& recs = wk.recs;
 	recs.resize(cells.size());
 	for (size_t i = 0; i < cells.size(); ++i) { recs[i].count = cells[i].count; recs[i].pos = static_cast<uint32_t>(i); }
+	// the indices of the cells out of their keys (kht_peaks_kernel: order = theta * 2 vs + rho, or ... + vs + rho): the keys are sorted, theta only ever grows -- no division
+	std::vector<KhtPeaksWork::Idx>& idx = wk.idx;
+	idx.resize(cells.size());
+	{
+		const uint64_t vsKey = ax.rhoN + 2, row = 2 * vsKey;
+		uint64_t ti = 0, base = 0;   // base = ti * row
+		for (size_t i = 0; i < cells.size(); ++i) {
+			const uint64_t o = cells[i].order;
+			while (o >= base + row) { ++ti; base += row; }
+			const uint64_t rem = o - base;
+			idx[i].theta = static_cast<uint32_t>(ti);
+			idx[i].rho = static_cast<uint32_t>(rem >= vsKey ? rem - vsKey : rem);
+		}
+	}
 	std::sort(recs.begin(), recs.end(), [](const KhtPeaksWork::Rec& a, const KhtPeaksWork::Rec& b) { return a.count > b.count; });
 	// the axes and the visited map live in the caller's workspace: a worker thread of the batch entry point would otherwise map and unmap a megabyte per
 	// frame (32 threads doing that at once spent more time in the kernel's address-space lock than in the sweep)
@@ -401,21 +415,21 @@ void khtPeaks(const KhtAxes& ax, std::vector<KhtCell>& cells, int maxLines, std:
 	if (wk.visited.size() != (ax.T + 2) * vs) wk.visited.assign((ax.T + 2) * vs, 0);
 	std::vector<uint8_t>& visited = wk.visited;   // all zero on entry; the cells marked below are cleared again on the way out
 	for (const KhtPeaksWork::Rec& rec : recs) {
-		const KhtCell& c = cells[rec.pos];
-		uint8_t* p = visited.data() + static_cast<size_t>(c.thetaIndex) * vs + c.rhoIndex;
+		const KhtPeaksWork::Idx c = idx[rec.pos];
+		uint8_t* p = visited.data() + static_cast<size_t>(c.theta) * vs + c.rho;
 		const uint8_t *t = p - vs, *b = p + vs;
 		const bool seen = t[-1] || t[0] || t[1] || p[-1] || p[1] || b[-1] || b[0] || b[1];
 		if (!seen) {
 			KhtLine l;
-			l.rho = static_cast<float>(rho[c.rhoIndex]);
-			l.theta = static_cast<float>((theta[c.thetaIndex] * kPi) / 180.0); // COMPV_MATH_DEGREE_TO_RADIAN
-			l.strength = c.count;
-			l.rhoIndex = static_cast<int32_t>(c.rhoIndex); l.thetaIndex = static_cast<int32_t>(c.thetaIndex);
+			l.rho = static_cast<float>(rho[c.rho]);
+			l.theta = static_cast<float>((theta[c.theta] * kPi) / 180.0); // COMPV_MATH_DEGREE_TO_RADIAN
+			l.strength = rec.count;
+			l.rhoIndex = static_cast<int32_t>(c.rho); l.thetaIndex = static_cast<int32_t>(c.theta);
 			lines.push_back(l);
 		}
 		*p = 0xff;
 	}
-	for (const KhtCell& c : cells) visited[static_cast<size_t>(c.thetaIndex) * vs + c.rhoIndex] = 0;
+	for (const KhtPeaksWork::Idx& c : idx) visited[static_cast<size_t>(c.theta) * vs + c.rho] = 0;
 	if (maxLines > 0 && lines.size() > static_cast<size_t>(maxLines)) lines.resize(static_cast<size_t>(maxLines));
 }
 

@@ -310,7 +310,7 @@ __global__ __launch_bounds__(256) void kht_peaks_kernel(KhtGpuArgs a, int sseCov
 	if (s < a.threshold) return;
 	const int idx = atomicAdd(a.cellCount, 1);
 	if (idx < a.cellCap) {
-		KhtCell o; o.order = order; o.rhoIndex = (uint32_t)emitRho; o.thetaIndex = (uint32_t)ti; o.count = s;
+		KhtCell o; o.order = order; o.count = s;   // (rho index emitRho and theta index ti are in `order`)
 		a.cells[idx] = o;
 	}
 }
