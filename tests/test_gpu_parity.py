@@ -554,6 +554,22 @@ def test_houghkht_matches_oracle(hip_ctx, oracle, W, H, tl, th, rho, deg, thr):
         assert _kht_tuple(top) == _kht_tuple(got[:3])
 
 
+@pytest.mark.parametrize("W,H", [(32767, 48), (48, 32767), (8191, 200)])
+def test_houghkht_at_the_coordinate_limits(hip_ctx, oracle, W, H):
+    """Images as wide / tall as the API takes (W, H <= 32 767: the reference's int16 coordinates, and the 4-byte points of the product's strings): pixel
+    coordinates up to 32 765, 32 768 rho bins.  Lines (values and order) and GS against the oracle."""
+    img = synth_frame(W, H, 99)
+    rc, edges = oracle.canny(img, 59.0, 119.0)
+    assert rc == 0
+    edges = edges.copy()
+    edges[2:H - 2, W - 2] = 255; edges[H - 2, 2:W - 2] = 255      # strings along the last interior column and row: x = W - 2, y = H - 2
+    edges[H // 2, W - 40:W - 1] = 255
+    exp, gs_exp = oracle.kht(edges, 1.0, 1.0, 1)
+    got, gs = hip_ctx.houghkht(edges, 1.0, 1.0, 1)
+    assert gs == gs_exp and len(exp) > 100
+    assert _kht_tuple(got) == [(float(np.float32(l[0])), float(np.float32(l[1])), int(l[2])) for l in exp]
+
+
 @pytest.mark.parametrize("W,H,p,amp", [(697, 34, 4, 200), (700, 40, 8, 150), (946, 27, 3, 180), (1093, 224, 5, 230)])
 def test_houghkht_exactly_collinear_clusters(hip_ctx, oracle, W, H, p, amp):
     """Checkerboards give EXACTLY collinear clusters: the kernels' sigmas hit their floor and the Gaussian's peak vote exceeds 2^31.  The reference

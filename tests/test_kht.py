@@ -67,7 +67,7 @@ def test_bit_plane_linker_borders_and_word_boundaries(oracle):
     """Pixels on the image border (never seeds, but reachable by a walk), runs across 64-bit word boundaries, isolated pixels, full rows."""
     from compv_amd import capi
     rng = np.random.RandomState(5)
-    for W, H in ((63, 9), (64, 9), (65, 9), (128, 5), (129, 33), (200, 3), (3, 200)):
+    for W, H in ((63, 9), (64, 9), (65, 9), (128, 5), (129, 33), (200, 3), (3, 200), (32767, 6), (5, 32767)):   # ... and the largest coordinates the API takes
         e = np.zeros((H, W), np.uint8)
         e[H // 2, :] = 255                       # a full row: leftward and rightward runs over every word boundary
         e[:, W // 2] = 255                       # a full column
