@@ -23,7 +23,7 @@ struct KhtCell { uint32_t order; int32_t count; };
 bool khtAxes(size_t W, size_t H, float rho, float thetaDeg, KhtAxes& ax);
 void khtFillAxes(const KhtAxes& ax, std::vector<double>& rho, std::vector<double>& theta);
 struct KhtPoint { int16_t x, y; };   // W, H <= 32 767 (the reference keeps int16 coordinates too, canny hysteresis :628); 4 bytes per point: half the upload of the strings
-// the edge map of one frame, one bit per pixel, with a zero border: row y (-1 <= y <= H) starts at row(y); pixel x is bit x + 8 of the row
+// the edge map of one frame, one bit per pixel, with a zero border: row y (-1 <= y <= H) starts at row(y) with one zero pad word (8 bytes); pixel x is bit 64 + x of the row
 struct KhtBitPlane {
 	std::vector<uint8_t> buf; size_t pitch = 0, W = 0, H = 0;
 	void reset(size_t W, size_t H);
