@@ -385,7 +385,7 @@ void khtPeaks(const KhtAxes& ax, std::vector<KhtCell>& cells, int maxLines, std:
 		if (src != cells.data()) std::memcpy(cells.data(), src, cells.size() * sizeof(KhtCell));
 	}
 	// (2) the reference's std::sort on the count alone (:1195-1205): unstable, but a function of the sequence of counts only -- the permutation is
-	// found on 8-byte (count, position) records (same comparisons, same moves as on the cells themselves, half the bytes) and applied afterwards
+	// found on 8-byte (count, position) records (same comparisons, same moves as on the reference's 24-byte cells) and applied afterwards
 	std::vector<KhtPeaksWork::Rec>& recs = wk.recs;
 	recs.resize(cells.size());
 	for (size_t i = 0; i < cells.size(); ++i) { recs[i].count = cells[i].count; recs[i].pos = static_cast<uint32_t>(i); }
