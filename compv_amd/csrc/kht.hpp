@@ -19,10 +19,12 @@ struct KhtVoteParams { double srsScale, stsScale, sScale, r2, x, y; unsigned rho
 // one vote cell that passed the 3x3 smoothing + threshold; `order` = position in the reference's emission order = thetaIndex * 2 (rhoN + 2) + rhoIndex, or
 // ... + (rhoN + 2) + rhoIndex for the cells the reference's scalar remainder pushes (quirk Q6): the indices are recovered on the host (8 bytes per cell cross PCIe)
 struct KhtCell { uint32_t order; int32_t count; };
+static_assert(sizeof(KhtCell) == 8, "vote cells cross PCIe as 8-byte records");
 
 bool khtAxes(size_t W, size_t H, float rho, float thetaDeg, KhtAxes& ax);
 void khtFillAxes(const KhtAxes& ax, std::vector<double>& rho, std::vector<double>& theta);
 struct KhtPoint { int16_t x, y; };   // W, H <= 32 767 (the reference keeps int16 coordinates too, canny hysteresis :628); 4 bytes per point: half the upload of the strings
+static_assert(sizeof(KhtPoint) == 4, "points cross PCIe as 4-byte records");
 // the edge map of one frame, one bit per pixel, with a zero border: row y (-1 <= y <= H) starts at row(y) with one zero pad word (8 bytes); pixel x is bit 64 + x of the row
 struct KhtBitPlane {
 	std::vector<uint8_t> buf; size_t pitch = 0, W = 0, H = 0;
