@@ -1640,6 +1640,9 @@ static int khtCheckParams(compvhip_ctx* ctx, size_t W, size_t H, float rho, floa
 	if (clusterMinSize < 2) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "clusterMinSize must be >= 2 (the reference's recursion does not terminate for 1)");
 	if (!W || !H || W > 32767 || H > 32767) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "image size out of range");
 	if (!khtAxes(W, H, rho, thetaDeg, ax)) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "degenerate KHT parameter space");
+	// the peak stage identifies a vote cell by the 32-bit key theta * 2 (rhoN + 2) + rho (KhtCell::order) and indexes the vote map with ints
+	if (static_cast<uint64_t>(ax.T + 2) * 2u * (ax.rhoN + 2) >= (1ull << 32) || static_cast<uint64_t>(ax.T + 2) * (ax.rhoN + 2) > 0x7fffffffull)
+		return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "KHT parameter space too fine for this image size ((T + 2) * 2 (rhoN + 2) must stay below 2^32)");
 	return COMPVHIP_OK;
 }
 

@@ -414,6 +414,11 @@ void khtPeaks(const KhtAxes& ax, std::vector<KhtCell>& cells, int maxLines, std:
 	const size_t vs = ax.rhoN + 2;
 	if (wk.visited.size() != (ax.T + 2) * vs) wk.visited.assign((ax.T + 2) * vs, 0);
 	std::vector<uint8_t>& visited = wk.visited;   // all zero on entry; the cells marked below are cleared again on the way out
+	// the map is shared by the frames a worker handles one after the other: whatever ends the sweep (push_back may throw) must leave it all zero
+	struct VisitedGuard {
+		std::vector<uint8_t>& v; const std::vector<KhtPeaksWork::Idx>& idx; size_t vs;
+		~VisitedGuard() { for (const KhtPeaksWork::Idx& c : idx) v[static_cast<size_t>(c.theta) * vs + c.rho] = 0; }
+	} guard{ visited, idx, vs };
 	for (const KhtPeaksWork::Rec& rec : recs) {
 		const KhtPeaksWork::Idx c = idx[rec.pos];
 		uint8_t* p = visited.data() + static_cast<size_t>(c.theta) * vs + c.rho;
@@ -429,7 +434,6 @@ void khtPeaks(const KhtAxes& ax, std::vector<KhtCell>& cells, int maxLines, std:
 		}
 		*p = 0xff;
 	}
-	for (const KhtPeaksWork::Idx& c : idx) visited[static_cast<size_t>(c.theta) * vs + c.rho] = 0;
 	if (maxLines > 0 && lines.size() > static_cast<size_t>(maxLines)) lines.resize(static_cast<size_t>(maxLines));
 }
 

@@ -10,10 +10,14 @@ OUT="$HERE/_build"
 mkdir -p "$OUT"
 # the C++ multi-GPU batch driver: C ABI + RCCL only, no CompV checkout needed
 ROCM="${ROCM_PATH:-/opt/rocm}"
-g++ -std=c++14 -O2 -w -D__HIP_PLATFORM_AMD__ -I"$ROCM/include" -o "$OUT/multi_gpu_batch" "$HERE/multi_gpu_batch.cxx" \
-  -L"$ROOT/compv_amd/lib" -lcompv_hip -L"$ROCM/lib" -lamdhip64 -lrccl \
-  -Wl,-rpath,'$ORIGIN/../../compv_amd/lib' -Wl,-rpath,"$ROCM/lib" -lpthread
-echo "integration/build.sh: OK -> $OUT/multi_gpu_batch"
+if [ -f "$ROCM/lib/librccl.so" ] && [ -f "$ROCM/lib/libamdhip64.so" ] && [ -f "$ROOT/compv_amd/lib/libcompv_hip.so" ]; then
+  g++ -std=c++14 -O2 -w -D__HIP_PLATFORM_AMD__ -I"$ROCM/include" -o "$OUT/multi_gpu_batch" "$HERE/multi_gpu_batch.cxx" \
+    -L"$ROOT/compv_amd/lib" -lcompv_hip -L"$ROCM/lib" -lamdhip64 -lrccl \
+    -Wl,-rpath,'$ORIGIN/../../compv_amd/lib' -Wl,-rpath,"$ROCM/lib" -lpthread
+  echo "integration/build.sh: OK -> $OUT/multi_gpu_batch"
+else
+  echo "integration/build.sh: no ROCm/RCCL or libcompv_hip.so not built yet -> multi_gpu_batch skipped"
+fi
 if [ ! -d "$REF/base/include" ] || [ ! -f "$ROOT/oracle/_ref/libcompv_ref.so" ]; then
   echo "integration/build.sh: no CompV checkout / library -> skipping"; exit 0
 fi

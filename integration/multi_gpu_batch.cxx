@@ -224,14 +224,15 @@ int main(int argc, char** argv)
 			Rank& q = rk[r];
 			CVOK(q.ctx, compvhip_plan_pipeline_async(q.plan, q.in, tLow, tHigh, threshold, 0, q.edges, q.lines, cap, q.counts, q.stream, &q.ticket));
 		}
-		// (3) the only result exchange: per-frame line counts, all-gathered
+		// (3) every rank's step made final first (plan_wait replays a step whose speculative hysteresis rounds did not suffice and rewrites its counts) ...
+		for (int r = 0; r < R; ++r) CVOK(rk[r].ctx, compvhip_plan_wait(rk[r].plan, rk[r].ticket));
+		// ... then the only result exchange: per-frame line counts, all-gathered
 		if (useRccl) {
 			NCCLOK(ncclGroupStart());
 			for (int r = 0; r < R; ++r) NCCLOK(ncclAllGather(rk[r].counts, rk[r].allCounts, F, ncclInt32, rk[r].comm, rk[r].stream));
 			NCCLOK(ncclGroupEnd());
 		}
-		for (int r = 0; r < R; ++r) CVOK(rk[r].ctx, compvhip_plan_wait(rk[r].plan, rk[r].ticket));
-		if (!useRccl) {   // virtual ranks: gather with device copies once every rank's step is final
+		else {   // virtual ranks: gather with device copies once every rank's step is final
 			for (int r = 0; r < R; ++r)
 				for (int s = 0; s < R; ++s) HIPOK(hipMemcpyAsync(rk[r].allCounts + (size_t)s * F, rk[s].counts, sizeof(int32_t) * F, hipMemcpyDeviceToDevice, rk[r].stream));
 		}

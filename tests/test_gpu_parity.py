@@ -633,6 +633,12 @@ def test_houghkht_empty_and_errors(hip_ctx):
         with pytest.raises(capi.CompvHipError) as ex:
             fn()
         assert ex.value.code == capi.E_INVALID_PARAMETER
+    # a parameter space whose cell key theta * 2 (rhoN + 2) + rho no longer fits 32 bits is refused instead of decoded wrongly:
+    # 4K with rho = 0.01, theta = 0.02 deg has ~7.9e9 keys
+    big = np.zeros((2160, 3840), np.uint8)
+    with pytest.raises(capi.CompvHipError) as ex:
+        hip_ctx.houghkht(big, rho=0.01, theta_deg=0.02)
+    assert ex.value.code == capi.E_INVALID_PARAMETER
 
 
 def test_plan_to_cartesian_on_device(hip_ctx, oracle):
