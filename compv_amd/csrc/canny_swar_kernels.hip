@@ -26,6 +26,10 @@
 // the VALU -- the list and the NMS cost nothing while the stores were there.  The 16 edge bytes of a lane leave as ONE 16-byte store (the compiler had split them 12 + 4),
 // input rows are fetched two steps ahead, the dense stage uses three-operand forms (v_xad / v_lshl_add / v_add3: 31 instead of 39 instructions per row).  What is left of the
 // floor are the 2-byte stores of the mask dword two tiles share (sub-dword stores cost far more than their bytes here): DESIGN.md section 4.1.
+// Round 5 built the obvious alternative to the halo lanes -- 256 OWNED columns per wave, the gradient of the two columns either side of the tile from a
+// per-tile prologue (lane = row, both sides packed in one register), whole mask dwords and 256-byte aligned edge rows -- bit-exact and 5 % SLOWER
+// (profiles/r05/canny_lab_swar256.txt, commit 7eabbb1): the prologue's 144 single-dword gather loads per tile cost 14 % of the kernel, more than the
+// halo lanes (6 %) and the 2-byte stores (8 %) together.  The halo lanes stay.
 // A wave owns 240 output columns x kSwRows rows, 4 pixels per lane: lanes 0, 1 and 62, 63 compute the gradient of the 8 columns either
 // side of the tile (the NMS of columns 0 and 239 needs one of them; two lanes per side keep the tile's bit masks half-word aligned:
 // 240 = 15 half-words) but own no pixels.  Every input byte is fetched once per tile (+ 4/64 row halo, + 16/240 column halo).
@@ -37,18 +41,13 @@
 #include <cstdlib>
 #include <type_traits>
 
-// tools/canny_lab builds this file several times (one namespace and one set of SWAR_* switches per variant) and runs the variants side by side;
-// the product build defines none of them.
+// tools/canny_lab builds this file several times (one namespace and one set of SWAR_* switches per variant) and runs the variants side by side,
+// comparing outputs bit for bit; the product build defines none of them.
 #ifndef COMPVHIP_SWAR_NS
 #define COMPVHIP_SWAR_NS compvhip
 #endif
 #ifndef SWAR_ROWS
 #define SWAR_ROWS 32
-#endif
-// diagnosis switches of the lab (outputs differ from the shipped kernel's): SWAR_X_NOSTORE no global stores, SWAR_X_NOSPARSE no candidate list / NMS,
-// SWAR_X_NOHALO no halo-column prologue / hand-over, SWAR_X_MEMONLY loads + flush + stores without the gradient, SWAR_X_LDSPAD=n extra LDS bytes per wave
-#ifndef SWAR_X_LDSPAD
-#define SWAR_X_LDSPAD 0
 #endif
 
 namespace COMPVHIP_SWAR_NS {
@@ -397,380 +396,6 @@ __global__ __launch_bounds__(WAVES * 64, 8) void canny_swar_tile_kernel(CannyArg
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// Fourth generation (round 5): the wave tile is 256 OWNED columns -- no halo lanes.  The 240-column tile paid for its two halo lanes per side three
-// times: 16 of 256 computed columns thrown away, mask rows that start on a half-word (the dword two tiles share left as two 2-byte stores, which cost
-// far more than their bytes on this memory system: tools/canny_lab, round 4) and edge-byte rows that start in the middle of a cache line.  Here the
-// gradient of the two columns either side of the tile (x = 256 t - 1 and 256 t + 256) is computed ONCE per tile by a prologue -- lane = row, the
-// left column in the high and the right column in the low half of the packed registers, 34 rows in one pass -- and kept in a 34-dword LDS array;
-// the ring rows carry an 8-byte pad either side of their 256 u16 (row stride 544 B) and the NMS of a row pair finds the halo values of its four
-// rows there (one ds_read + ds_write2 by four lanes per pair), so a candidate in column 0 or 255 fetches its neighbours like any other.
-// Everything the tile stores is whole and aligned: 8 mask dwords per row and plane, 256 edge bytes per row.
-namespace {
-constexpr int kCols4 = 256;                     // owned columns per wave tile
-constexpr int kRing4 = 544;                     // ring row: [0,8) pad (halo L = the u16 at bytes 6..7), [8,520) 256 u16 in pixel order, [520,528) pad (halo R = bytes 520..521), 16 spare
-                                                // (544 = 17 * 32: (address - 8) >> 5 is a candidate's dword in the 17-dword nibble rows, no row arithmetic)
-constexpr int kAux4 = 4 * kRing4;               // aux ring, 2 rows at the ring's stride and in-row offsets: row r lives in slot r & 1
-constexpr int kList4 = kAux4 + 2 * kRing4;      // candidate list of a row pair: <= 512 u16 entries (= ring byte addresses of the candidates); the prologue's row partials before that
-constexpr int kNib4 = kList4 + 1024;            // result nibbles, 4 rows x 17 dwords (the 17th is padding): byte l of a row = lane l's four pixels, U in bits 0..3, E in bits 4..7
-constexpr int kNibRow4 = 68;
-constexpr int kHal4 = kNib4 + 4 * kNibRow4 + 16;   // halo columns: dword k = tile row k - 1: (g' of column 256 t - 1) << 16 | g' of column 256 t + 256
-constexpr int kLds4 = kHal4 + 36 * 4;           // 4704 B per wave: 8 waves per SIMD = 147 KB of the CU's 160 KB
-static_assert(kLds4 <= 5120 && kHal4 % 8 == 0 && kNib4 % 8 == 0, "LDS budget of 8 waves per SIMD");
-}
-
-template <bool GAP, int kSwRows>
-__global__ __launch_bounds__(64, 8) void canny_swar256_tile_kernel(CannyArgs a)
-{
-	__shared__ __attribute__((aligned(16))) uint8_t lds[kLds4 + SWAR_X_LDSPAD];
-
-	const int lane = threadIdx.x;
-	int tileX, group;
-	if (!xcd_tile_map(blockIdx.x, a.tilesX, a.groups, tileX, group)) return;
-	const int frame = group / a.blockRows;
-	const int tileY = group - frame * a.blockRows;
-
-	const int W = a.W, H = a.H, S = a.S;
-	const int xbase = tileX * kCols4;
-	const int x0 = xbase + lane * kSwPx;
-	const int y0 = tileY * kSwRows;
-	const uint8_t* __restrict__ in = a.in + (size_t)frame * a.inFrameStride;
-
-	int tLow = a.tLow, tHigh = a.tHigh;
-	if (a.thrDev) { const int2 t = a.thrDev[frame]; tLow = t.x; tHigh = t.y; }
-	tLow = min(__builtin_amdgcn_readfirstlane(tLow), 4000);   // g <= 2040: larger thresholds select nothing
-	tHigh = min(__builtin_amdgcn_readfirstlane(tHigh), 8000);
-	const int tLowQ = tLow + 2048, tHighQ = tHigh + 2048;      // thresholds on g' = g + 2048
-	uint32_t thrV = (uint32_t)tLowQ;
-	asm volatile("" : "+v"(thrV));                             // the candidate compare takes it from a VGPR (SDWA compares have no SGPR operand on gfx9)
-
-	// g is forced to 0 (g' = 2048) outside columns [1, W-2]: zero OUTPUT border of the convolution (compv_math_convlt.h:181-209)
-	const bool edgeTile = (xbase < 1) || (xbase + kCols4 > W - 1);
-	uint32_t okm[2] = { 0xffffffffu, 0xffffffffu };
-	if (edgeTile) {
-#pragma unroll
-		for (int k = 0; k < 2; ++k) {
-			const int xa = x0 + 2 * k, xb = xa + 1;
-			okm[k] = ((xa >= 1 && xa <= W - 2) ? 0x0000ffffu : 0u) | ((xb >= 1 && xb <= W - 2) ? 0xffff0000u : 0u);
-		}
-	}
-	// tiles whose gradient rows touch the image border rows (g forced to 0 there) or run past the image
-	const bool vEdgeTile = (tileY == 0) || (y0 + kSwRows + 1 >= H - 1);
-	const bool borderTile = edgeTile || vEdgeTile;
-
-	uint32_t* const ebase = a.ebits + (size_t)frame * a.bitsFrameStride;
-	uint32_t* const ubase = a.ubits + (size_t)frame * a.bitsFrameStride;
-	uint8_t* const obase = a.out + (size_t)frame * a.outFrameStride;
-
-	// Row loads through a buffer descriptor of the frame: the row offset rides in an SGPR (soffset), the lane's column offset is a
-	// loop-invariant VGPR.  Columns are clamped into the row (clamped lanes only feed columns whose g is forced to 0), rows into the frame.
-	const uint32_t xm = (uint32_t)min(max(x0, 0), S - 4);
-	const uint32_t xl = (uint32_t)min(max(x0 - 4, 0), S - 4);
-	const uint32_t xr = (uint32_t)min(max(x0 + 4, 0), S - 4);
-	const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t*>(in), 0, (int)((size_t)H * S), 0x00020000);
-	auto load = [&](int y, uint32_t& m, uint32_t& l, uint32_t& r) {
-		const int so = min(max(y, 0), H - 1) * S;
-		m = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)xm, so, 0);
-		l = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)xl, so, 0);
-		r = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)xr, so, 0);
-	};
-
-	uint32_t nb[2][3];
-	load(y0 - 2, nb[0][0], nb[0][1], nb[0][2]);
-	load(y0 - 1, nb[1][0], nb[1][1], nb[1][2]);
-
-	// ---- prologue: g' of the two halo columns, all 34 rows (tile rows -1 .. kSwRows) in one pass.  Lane j < kSwRows + 4 takes INPUT row y0 - 2 + j:
-	// its three pixels around either halo column, packed (left column in the high half, right column in the low half), give the row's horizontal
-	// smooth and difference; lane k < kSwRows + 2 then combines rows k, k + 1, k + 2 exactly as the row loop below does for the columns of the tile.
-#if !defined(SWAR_X_NOHALO) && !defined(SWAR_X_NOPROLOGUE)
-	{
-		const int ry = min(max(y0 - 2 + lane, 0), H - 1);
-		const int ro = ry * S;   // H * S < 2^31
-		const uint32_t dl0 = __builtin_amdgcn_raw_buffer_load_b32(rsrc, ro + min(max(xbase - 4, 0), S - 4), 0, 0);
-		const uint32_t dl1 = __builtin_amdgcn_raw_buffer_load_b32(rsrc, ro + min(xbase, S - 4), 0, 0);
-		const uint32_t dr0 = __builtin_amdgcn_raw_buffer_load_b32(rsrc, ro + min(xbase + 252, S - 4), 0, 0);
-		const uint32_t dr1 = __builtin_amdgcn_raw_buffer_load_b32(rsrc, ro + min(xbase + 256, S - 4), 0, 0);
-		const uint32_t pa = __builtin_amdgcn_perm(dl0, dr0, 0x0c060c03u);   // I[xb - 2] << 16 | I[xb + 255]
-		const uint32_t pb = __builtin_amdgcn_perm(dl0, dr1, 0x0c070c00u);   // I[xb - 1] << 16 | I[xb + 256]
-		const uint32_t pc = __builtin_amdgcn_perm(dl1, dr1, 0x0c040c01u);   // I[xb]     << 16 | I[xb + 257]
-		const uint32_t hrow = pa + 2u * pb + pc;                            // <= 1020 per half
-		const uint32_t drow = (pa ^ 0x00ff00ffu) + pc;                      // I[x + 1] - I[x - 1] + 255
-		if (lane < kSwRows + 4) *reinterpret_cast<uint2*>(lds + kList4 + lane * 8) = make_uint2(hrow, drow);
-		__builtin_amdgcn_wave_barrier();
-		if (lane < kSwRows + 2) {
-			const uint2 r0 = *reinterpret_cast<const uint2*>(lds + kList4 + lane * 8);
-			const uint2 r1 = *reinterpret_cast<const uint2*>(lds + kList4 + lane * 8 + 8);
-			const uint2 r2 = *reinterpret_cast<const uint2*>(lds + kList4 + lane * 8 + 16);
-			const uint32_t gxb = r0.y + 2u * r1.y + r2.y + 0x00040004u;        // gx + 1024
-			const uint32_t gyb = (r0.x ^ 0x03ff03ffu) + r2.x;                  // gy + 1023
-			const uint32_t mx = pk_max_u16(gxb, kBias2k - gxb);
-			const uint32_t my = pk_max_u16(gyb, 0x07fe07feu - gyb);
-			uint32_t gq = mx + my + 0x00010001u;                               // g + 2048
-			const int y = y0 - 1 + lane;
-			const int xhl = xbase - 1, xhr = xbase + kCols4;
-			uint32_t m = ((xhl >= 1 && xhl <= W - 2) ? 0xffff0000u : 0u) | ((xhr >= 1 && xhr <= W - 2) ? 0x0000ffffu : 0u);
-			if (!(y >= 1 && y <= H - 2)) m = 0u;
-			gq = (gq & m) | (kBias2k & ~m);
-			*reinterpret_cast<uint32_t*>(lds + kHal4 + lane * 4) = gq;
-		}
-		__builtin_amdgcn_wave_barrier();
-	}
-#endif
-
-	// rolling state: two pixels per register, pairs k = (x0 + 2k, x0 + 2k + 1)
-	uint32_t P[2] = { 0, 0 };              // d[y-2] + 2 d[y-1]   (bias 765)
-	uint32_t dprev[2] = { 0, 0 };          // d[y-1]              (bias 255)
-	uint32_t hy[2][2] = { { 0, 0 }, { 0, 0 } }; // horizontal smooth of rows y-1 / y-2 (ring)
-
-	const uint32_t lane8 = (uint32_t)lane * 8u + 8u;       // byte offset of the lane's 4 u16 inside a ring row
-	const bool fullRow = (xbase + kCols4 <= a.So);         // every 16-byte group of the tile's edge bytes lies inside the output row
-	auto zero_nibbles = [&]() {                            // 4 rows x 17 dwords
-		uint32_t* const z = reinterpret_cast<uint32_t*>(lds + kNib4) + lane;
-		z[0] = 0u; z[4] = 0u;
-	};
-	zero_nibbles();
-	uint32_t listCount = 0;                // entries in the candidate list (wave-uniform)
-	// halo hand-over of the NMS (lanes 0..3 = rows 2j - 1 .. 2j + 2 of pair j): where the lane reads (advances by two dwords per pair) and the ring slot it writes
-	uint32_t halRd = (uint32_t)(kHal4 + lane * 4);
-	const uint32_t halWr0 = (uint32_t)(((lane + 3) & 3) * kRing4 + 4);   // pairs with sA == 0: rows 2j - 1 .. 2j + 2 live in slots 3, 0, 1, 2
-	const uint32_t halWr2 = (uint32_t)(((lane + 1) & 3) * kRing4 + 4);   // pairs with sA == 2: slots 1, 2, 3, 0
-	const bool halLane = lane < 4;
-
-	uint32_t k255 = 0x00ff00ffu, k4 = 0x00040004u, k3ff = 0x03ff03ffu, k1 = 0x00010001u;
-	asm volatile("" : "+s"(k255), "+s"(k4), "+s"(k3ff), "+s"(k1));
-
-	// One row step: push input row yin = y0 - 2 + it  ->  gradient row yc = yin - 1 = y0 + (it - 3)  ->  ring slot (it - 3) & 3.
-	// After the steps with odd it >= 5 the rows 2j, 2j + 1 (j = (it - 5) / 2) of the tile have all three g rows of their neighbourhood
-	// in the ring and their candidates in the list: NMS of the pair.  After every second pair the four result rows are flushed.
-	auto step = [&](auto phase, auto with_nms, int it) {
-		constexpr int PH = decltype(phase)::value;            // it & 3
-		constexpr bool NMS = decltype(with_nms)::value;
-		constexpr int sNew = (PH + 1) & 3;                    // ring slot of the gradient row produced now
-		constexpr int aNew = (PH + 1) & 1;                    // its aux slot = its row parity
-		const int yin = y0 - 2 + it;
-		const uint32_t m = nb[PH & 1][0], l = nb[PH & 1][1], r = nb[PH & 1][2];
-		load(yin + 2, nb[PH & 1][0], nb[PH & 1][1], nb[PH & 1][2]); // prefetch
-
-		// ---- dense stage: packed pairs straight from the raw dwords (one v_perm each) ----
-		uint32_t A[2], L[3];
-		A[0] = __builtin_amdgcn_perm(0u, m, 0x0c010c00u);     // (p0, p1)
-		A[1] = __builtin_amdgcn_perm(0u, m, 0x0c030c02u);     // (p2, p3)
-		L[0] = __builtin_amdgcn_perm(m, l, 0x0c040c03u);      // (p-1, p0)
-		L[1] = __builtin_amdgcn_perm(0u, m, 0x0c020c01u);     // (p1, p2)
-		L[2] = __builtin_amdgcn_perm(r, m, 0x0c040c03u);      // (p3, p4)
-		uint32_t gq[2], aux[2];
-		uint32_t (&hyTop)[2] = hy[PH & 1]; // hy of row yin-2; overwritten with hy of row yin
-#ifdef SWAR_X_MEMONLY
-		gq[0] = m ^ l; gq[1] = m ^ r; aux[0] = l; aux[1] = r; (void)A; (void)L; (void)hyTop;
-#else
-#pragma unroll
-		for (int k = 0; k < 2; ++k) {
-			const uint32_t Lk = L[k], Rk = L[k + 1], Ck = A[k];
-			const uint32_t hyN = lshl1_add(Ck, Lk + Rk);               // I[x-1] + 2 I[x] + I[x+1]           (<= 1020)
-			const uint32_t d = xad(Lk, k255, Rk);                      // I[x+1] - I[x-1] + 255    ((L ^ 0xff) = 255 - L per half)
-			const uint32_t gxb = add3(P[k], d, k4);                    // gx + 1024                (P carries 3 x 255)
-			P[k] = lshl1_add(d, dprev[k]);
-			dprev[k] = d;
-			const uint32_t gyb = xad(hyTop[k], k3ff, hyN);             // gy + 1023                ((t ^ 0x3ff) = 1023 - t: t <= 1020)
-			hyTop[k] = hyN;
-			const uint32_t mx = pk_max_u16(gxb, kBias2k - gxb);        // |gx| + 1024
-			const uint32_t my = pk_max_u16(gyb, 0x07fe07feu - gyb);    // |gy| + 1023
-			gq[k] = add3(mx, my, k1);                                  // g + 2048
-			// bit 10 of gxb ^ gyb = sign(gx) != sign(gy), except that gy = 0 reads as negative: a pixel with gy = 0 is in the horizontal class
-			// (or has g = 0) and the sign only selects between the two diagonals
-			aux[k] = bfi(kBias1k, gxb ^ gyb, mx);                      // bits 0..9 |gx|, bit 10 = ((gx ^ gy) < 0)
-		}
-#endif
-		const int yc = yin - 1;
-		if (borderTile) { // one wave-uniform test per row; interior tiles skip all of it (the empty asm keeps the compiler from turning the branch into selects)
-			asm volatile("" : "+v"(gq[0]), "+v"(gq[1]));
-			const uint32_t rowm = (yc >= 1 && yc <= H - 2) ? 0xffffffffu : 0u; // image border rows (and rows past the image): g = 0
-#pragma unroll
-			for (int k = 0; k < 2; ++k) gq[k] = bfi(okm[k] & rowm, gq[k], kBias2k);
-		}
-		*reinterpret_cast<uint2*>(lds + sNew * kRing4 + lane8) = make_uint2(gq[0], gq[1]);
-
-		// ---- sparse stage: NMS + classification of the row pair (2j, 2j + 1) on its candidates ----
-		if (NMS) {
-			static_assert(!NMS || (PH & 1), "pairs complete on odd steps");
-			constexpr int sA = (PH + 3) & 3;                  // ring slot of row 2j: 0 (j even) or 2 (j odd); row 2j + 1 sits in sA + 1
-			// halo columns of rows 2j - 1 .. 2j + 2 into the pads of their ring rows (the high half of the dword in front of pixel 0, the low half of the one behind pixel 255)
-#if !defined(SWAR_X_NOHALO) && !defined(SWAR_X_NOHANDOVER)
-			if (halLane) {
-				const uint32_t hv = *reinterpret_cast<const uint32_t*>(lds + halRd);
-				uint8_t* const hw = lds + (sA == 0 ? halWr0 : halWr2);
-				*reinterpret_cast<uint32_t*>(hw) = hv;
-				*reinterpret_cast<uint32_t*>(hw + 516) = hv;
-			}
-			halRd += 8u;
-#endif
-			__builtin_amdgcn_wave_barrier();
-#if defined(SWAR_X_NOSPARSE) || defined(SWAR_X_MEMONLY)
-			const int total = 0;
-#else
-			const int total = (int)listCount;
-#endif
-			const uint8_t* const auxb = lds + kAux4 - sA * kRing4;   // aux of a candidate = auxb[its ring address]: aux slot q = ring slot sA + q
-#pragma nounroll
-			for (int base = 0; base < total; base += 64) {
-				const int jx = base + lane;
-				if (jx < total) {
-					// entry = ring byte address of the candidate.  The direction class is evaluated first, from the centre and its aux word, and only the
-					// TWO neighbours along the gradient are fetched (round 3: the LDS pipe bounded the kernel while every candidate fetched all eight).
-					const uint32_t c0 = *reinterpret_cast<const uint16_t*>(lds + kList4 + 2 * jx);
-					const int gc = *reinterpret_cast<const uint16_t*>(lds + c0);
-					const uint32_t au = *reinterpret_cast<const uint16_t*>(auxb + c0);
-					const uint32_t ax = au & 0x3ffu;
-					const uint32_t ays = (uint32_t)(gc - 2048 - (int)ax) << 16;      // |gy| << 16
-					// direction class (constants canny_dete.h:58-61: tan(pi/8), tan(3pi/8) in Q16; 158217 = 27145 + 2^17)
-					const uint32_t t1 = __umul24(ax, 27145u);
-					const bool k1c = ays < t1;
-					const bool k2c = ays < t1 + (ax << 17);
-					const bool dg = k2c && ((au & 0x400u) != 0);
-					// rows above / below: the four rows of the pair's neighbourhood sit in slots (sA + 3) & 3, sA, sA + 1, (sA + 2) & 3 -- one of the two wraps
-					uint32_t oU, oD;
-					if constexpr (sA == 0) { oU = (c0 >= (uint32_t)kRing4) ? (uint32_t)-kRing4 : (uint32_t)(3 * kRing4); oD = (uint32_t)kRing4; }
-					else { oU = (uint32_t)-kRing4; oD = (c0 >= (uint32_t)(3 * kRing4)) ? (uint32_t)(-3 * kRing4) : (uint32_t)kRing4; }
-					// neighbours along the gradient: k1 left / right; k2 diagonal ((gx^gy) < 0: (y+1,x-1),(y-1,x+1), else (y-1,x-1),(y+1,x+1)); else up / down,
-					// i.e. (X - d, Y + d) with (X, Y, d) = (C, C, 2) | (D, U, 2) | (U, D, 2) | (U, D, 0)
-					uint32_t X = dg ? oD : oU, Y = dg ? oU : oD;
-					X = k1c ? 0u : X; Y = k1c ? 0u : Y;
-					const uint32_t dl = k2c ? 2u : 0u;
-					const int n1 = *reinterpret_cast<const uint16_t*>(lds + (c0 + X - dl)), n2 = *reinterpret_cast<const uint16_t*>(lds + (c0 + Y + dl));
-					bool weak = gc >= max(n1, n2);  // not suppressed: neither neighbour strictly greater (candidates already have g > tLow)
-					bool strong = gc > tHighQ;
-					const uint32_t t = c0 - 8u;          // (slot * 544 + 2 c): t >> 5 = slot * 17 + (c >> 4), (t >> 1) & 15 = c & 15
-					if (GAP) { // quirk Q3: column coverage of the NMS and of the seed scan, [1,simdEnd) U [cStart,W-1) (canny_dete.cxx:396,514)
-						const bool q = c0 >= (uint32_t)((sA + 1) * kRing4);
-						const int x = xbase + (int)((t - (uint32_t)((sA + (q ? 1 : 0)) * kRing4)) >> 1);
-						const bool in_cov = (x >= 1 && x < a.simdEnd) || (x >= a.cStart && x < W - 1);
-						weak = weak || !in_cov;       // outside the NMS coverage: thresholded only, never a seed
-						strong = strong && in_cov;
-					}
-					// result: bit (c & 3) (U: weak, not strong) or 4 + (c & 3) (E: strong) of byte (c >> 2) of the candidate's nibble row.  One dword
-					// holds four lanes: candidates of one instruction rarely share it
-					if (weak) {
-						uint32_t* const nw = reinterpret_cast<uint32_t*>(lds + kNib4) + (t >> 5);
-						atomicOr(nw, (strong ? 0x10u : 0x01u) << (((t >> 1) & 3u) | (t & 24u)));
-					}
-				}
-			}
-			listCount = 0;
-			if constexpr (PH == 3) {
-				// rows 4m .. 4m + 3 of the tile are classified: masks and edge bytes leave in their final global layout
-				const int rr0 = it - 7;                          // tile row of nibble row 0
-				__builtin_amdgcn_wave_barrier();
-				const uint32_t* const nibw = reinterpret_cast<const uint32_t*>(lds + kNib4);
-				{
-					// masks: lanes 0..31 the U rows (weak & ~strong), 32..63 the E rows (strong); a lane packs the 8 result bytes (= 32 pixels) of one mask dword
-					const int mi = lane >> 5, q = (lane >> 3) & 3, dl = lane & 7;
-					const uint32_t* rn = nibw + q * 17 + 2 * dl;
-					const uint32_t nsh = (uint32_t)mi * 4u;                          // U: low nibbles, E: high nibbles
-					uint32_t th[2];
-#pragma unroll
-					for (int hh = 0; hh < 2; ++hh) {
-						uint32_t tt = (rn[hh] >> nsh) & 0x0f0f0f0fu;                 // 4 lanes = 16 pixels
-						tt = (tt | (tt >> 4)) & 0x00ff00ffu;
-						th[hh] = (tt | (tt >> 8)) & 0x0000ffffu;
-					}
-					const uint32_t v = th[0] | (th[1] << 16);
-					const int row = y0 + rr0 + q, gd = tileX * 8 + dl;
-#ifdef SWAR_X_NOSTORE
-					asm volatile("" :: "v"(v), "v"(row), "v"(gd));
-#else
-					if (row < H && gd < a.wb) ((mi ? ebase : ubase) + (size_t)row * a.wb)[gd] = v;
-#endif
-				}
-				{
-					// edge bytes of the strong pixels (the resolve rounds add the promoted ones): lane = (row q, 16-pixel group gi = lanes 4 gi .. 4 gi + 3): one 16-byte store
-					const int q = lane >> 4, gi = lane & 15;
-					const uint32_t by = nibw[q * 17 + gi];
-					const int row = y0 + rr0 + q;
-					const int x = xbase + gi * 16;
-					if (row < H && x + 8 <= a.So) {
-						uint8_t* dst = obase + (size_t)row * a.So + x;
-						const uint32_t b0 = nibble_bytes((by >> 4) & 0xfu), b1 = nibble_bytes((by >> 12) & 0xfu);
-						if (fullRow) {
-							// (spelled out: with the two tails below in one if / else the compiler merges their common part and emits a 12-byte store plus a
-							// 4-byte store at 16-byte stride -- twice the write requests, every one of them partial)
-							const uint32_t b2 = nibble_bytes((by >> 20) & 0xfu), b3 = nibble_bytes(by >> 28);
-							typedef uint32_t v4u __attribute__((ext_vector_type(4)));
-							const v4u bv = { b0, b1, b2, b3 };
-#ifdef SWAR_X_NOSTORE
-							asm volatile("" :: "v"(dst), "v"(bv));
-#else
-							asm volatile("global_store_dwordx4 %0, %1, off" :: "v"(dst), "v"(bv) : "memory");
-#endif
-						}
-						else if (x + 16 <= a.So) {
-							const uint32_t b2 = nibble_bytes((by >> 20) & 0xfu), b3 = nibble_bytes(by >> 28);
-							*reinterpret_cast<uint4*>(dst) = make_uint4(b0, b1, b2, b3);
-						}
-						else *reinterpret_cast<uint2*>(dst) = make_uint2(b0, b1); // So % 8 == 0: an 8-column tail
-					}
-				}
-				__builtin_amdgcn_wave_barrier();
-				zero_nibbles();
-			}
-			__builtin_amdgcn_wave_barrier();
-		}
-
-		// aux of the new row (its slot held the aux of row 2j until the NMS above was done with it)
-		*reinterpret_cast<uint2*>(lds + kAux4 + aNew * kRing4 + lane8) = make_uint2(aux[0], aux[1]);
-
-		// ---- candidates of the new row join the list: entry = the candidate's ring byte address, position = scalar popcount of the earlier
-		// slots (rides in as the mbcnt base) + mbcnt of the slot's own mask; the store is exec-masked ----
-#if !defined(SWAR_X_NOSPARSE) && !defined(SWAR_X_MEMONLY)
-		if (it >= 3 && it < kSwRows + 3) {   // gradient rows y0 .. y0 + kSwRows - 1 only (uniform)
-			uint8_t* const listw = lds + kList4;
-			uint32_t cnt = listCount;
-#pragma unroll
-			for (int p = 0; p < kSwPx; ++p) {
-				const uint32_t gk = gq[p >> 1];
-				const uint32_t gp = (p & 1) ? (gk >> 16) : (gk & 0xffffu);
-				const bool c = gp > thrV;
-				const uint64_t mk = __ballot(c);
-				if (c) {
-					const uint32_t rk = __builtin_amdgcn_mbcnt_hi((uint32_t)(mk >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)mk, cnt));
-					*reinterpret_cast<uint16_t*>(listw + twice(rk)) = (uint16_t)(lane8 + (uint32_t)(sNew * kRing4 + 2 * p));
-				}
-				cnt += (uint32_t)__popcll(mk);
-			}
-			listCount = __builtin_amdgcn_readfirstlane(cnt);
-		}
-#endif
-	};
-
-	{
-		using T = std::true_type; using F = std::false_type;
-		static_assert(kSwRows % 4 == 0 && kSwRows + 4 <= 64, "the row loop is unrolled by four; the prologue takes one lane per input row");
-		step(std::integral_constant<int, 0>{}, F{}, 0);
-		step(std::integral_constant<int, 1>{}, F{}, 1);
-		step(std::integral_constant<int, 2>{}, F{}, 2);
-		step(std::integral_constant<int, 3>{}, F{}, 3);
-		for (int it = 4; it < kSwRows + 4; it += 4) { // it = 4 .. kSwRows + 3
-			step(std::integral_constant<int, 0>{}, F{}, it);
-			step(std::integral_constant<int, 1>{}, T{}, it + 1);
-			step(std::integral_constant<int, 2>{}, F{}, it + 2);
-			step(std::integral_constant<int, 3>{}, T{}, it + 3);
-		}
-	}
-}
-
-template <int kRows>
-static hipError_t launch_swar256(const CannyArgs& a0, int frames, bool gap, hipStream_t stream)
-{
-	CannyArgs a = a0;
-	a.tilesX = (a.W + kCols4 - 1) / kCols4;
-	a.tilesY = (a.H + kRows - 1) / kRows;
-	a.blockRows = a.tilesY;
-	a.groups = a.blockRows * frames;
-	dim3 grid(8 * ((a.groups + 7) / 8) * a.tilesX);
-	if (gap) hipLaunchKernelGGL((canny_swar256_tile_kernel<true, kRows>), grid, dim3(64), 0, stream, a);
-	else hipLaunchKernelGGL((canny_swar256_tile_kernel<false, kRows>), grid, dim3(64), 0, stream, a);
-	return hipGetLastError();
-}
-
-// ---------------------------------------------------------------------------------------------------------------
 template <int kWaves, int kRows>
 static hipError_t launch_swar(const CannyArgs& a0, int frames, bool gap, hipStream_t stream)
 {
@@ -792,11 +417,7 @@ hipError_t launch_canny_tiles_swar(const CannyArgs& a0, int frames, bool gap, hi
 	// frames.  Measured per 32 x 4K launch (same run): 128 rows 0.232 ms, 64 rows 0.202 ms, 32 rows 0.192 ms, 16 / 24 rows the same as 32 within 1 % -- the
 	// 4-row halo costs 12.5 % more gradient rows than at 64 rows, but twice as many, shorter waves balance the SIMDs better at the end of
 	// the launch (a tile's time follows its candidate count).
-#ifdef SWAR_LEGACY240
 	return launch_swar<1, SWAR_ROWS>(a0, frames, gap, stream);
-#else
-	return launch_swar256<SWAR_ROWS>(a0, frames, gap, stream);
-#endif
 }
 
 } // namespace COMPVHIP_SWAR_NS
