@@ -93,9 +93,15 @@ struct compvhip_plan {
 	int tilesX = 0, tilesY = 0, wb = 0;
 	size_t bitsFrameStride = 0;
 	uint32_t* ebits = nullptr; uint32_t* ubits = nullptr;
-	int* counters = nullptr;  // ONE device allocation zeroed by ONE memset per step: [edgeCounts frames][lineCounts frames][tileCounts frames*tiles][blockCounts frames*lineBlocks][flags kMaxRounds]
+	int* counters = nullptr;  // ONE device allocation zeroed by ONE memset per step: [edgeCounts frames][lineCounts frames][tileCounts frames*tiles][blockCounts frames*lineBlocks][frameTotals frames*kFrameSlot][lineTotal kFrameSlot][flags kMaxRounds]
 	size_t nCounts = 0;       // ints in front of the flags
 	int* flags = nullptr; int* hFlags = nullptr; // device (inside counters) / pinned host (kAsyncDepth + 1 slots)
+	int* frameTotals = nullptr; unsigned int* lineTotal = nullptr; // device (inside counters): NMS survivors per frame (one per 128-byte line) / key slots in use
+	unsigned int* hTotals = nullptr;             // pinned host (behind hFlags): lineTotal of the synchronous call (slot 0) and of the asynchronous steps (1 + ticket)
+	// The line sort covers the key slots that exist.  A synchronous step reads their number before it enqueues the sort; an asynchronous step cannot, so it
+	// sorts a range predicted from the totals of the plan's last steps (0 = none seen yet: the whole capacity) -- compvhip_plan_wait compares with the step's
+	// real total and replays the step when the prediction was too small.
+	unsigned int recentTotals[8] = {}; int recentN = 0;
 	int roundsUsed = 0;
 	int maxRounds = kMaxRounds; // flag slots in use (COMPVHIP_RESOLVE_WRAP lowers it: tests of the slot reuse)
 	bool countersFresh = false; // the step's memset already zeroed the edge/line counts (no second fill in front of the SHT stage)
@@ -121,6 +127,8 @@ struct compvhip_plan {
 	int* blockCounts = nullptr; int lineBlocks = 0;   // NMS survivors per 64 accumulator rows (part of `counters`)
 	void* sortTemp = nullptr; size_t sortTempBytes = 0;
 	int strengthBits = 16, keyBits = 0;
+	// the line sort sized on the device (sht_sort_kernels.hip): used when a strength has at most 13 bits and a frame at most 32 chunks of keys
+	uint16_t* chunkHist = nullptr; uint32_t* chunkStart = nullptr; int sortChunks = 0; bool deviceSort = false;
 	// voting over image tiles (planned at plan creation: the per-tile edge counters live in `counters`)
 	bool voteTiles = false;                      // the tile grid exists
 	ShtTileArgs vt = {};                         // geometry + device tables
@@ -131,7 +139,7 @@ struct compvhip_plan {
 	double khtStageMs[6] = {}; double khtWallMs = 0.0; int khtThreads = 0;
 	// asynchronous steps (compvhip_plan_pipeline_async / compvhip_plan_wait)
 	// seq: enqueue order; replay: an EARLIER step of the plan was replayed after this one ran -- its outputs may have been overwritten
-	struct AsyncStep { bool used = false; bool replay = false; uint64_t seq = 0; hipEvent_t done = nullptr; hipStream_t stream = nullptr; StepParams sp; } steps[kAsyncDepth];
+	struct AsyncStep { bool used = false; bool replay = false; uint64_t seq = 0; hipEvent_t done = nullptr; hipStream_t stream = nullptr; StepParams sp; size_t sortN = 0; } steps[kAsyncDepth];
 	uint64_t stepSeq = 0;
 	// timing
 	int timing = 0; // 0 off, 1 every kernel, 2 canny_tile + sht_vote, 3 sht_vote only, 4 canny_tile only
@@ -490,20 +498,27 @@ int ensureLineCap(compvhip_plan* p, size_t cap)
 	compvhip_ctx* ctx = p->ctx;
 	cap = std::min(cap, p->R * p->T);
 	if (cap <= p->lineCap) return COMPVHIP_OK;
-	dfree(ctx, p->keysA); dfree(ctx, p->keysB); dfree(ctx, p->valsA); dfree(ctx, p->valsB); dfree(ctx, p->sortTemp);
-	p->lineCap = 0;
+	dfree(ctx, p->keysA); dfree(ctx, p->keysB); dfree(ctx, p->valsA); dfree(ctx, p->valsB); dfree(ctx, p->sortTemp); dfree(ctx, p->chunkHist); dfree(ctx, p->chunkStart);
+	p->lineCap = 0; p->deviceSort = false;
 	HIPCHK(ctx, dmalloc(ctx, &p->keysA, cap * p->frames));
 	HIPCHK(ctx, dmalloc(ctx, &p->keysB, cap * p->frames));
 	HIPCHK(ctx, dmalloc(ctx, &p->valsA, cap * p->frames));
 	HIPCHK(ctx, dmalloc(ctx, &p->valsB, cap * p->frames));
 	size_t tb = 0;
-	hipError_t e = sht_sort_pairs(nullptr, tb, p->keysA, p->keysB, p->valsA, p->valsB, cap, static_cast<int>(p->frames), p->keyBits, nullptr);
+	hipError_t e = sht_sort_pairs(nullptr, tb, p->keysA, p->keysB, p->valsA, p->valsB, cap * p->frames, p->keyBits, nullptr);
 	if (e != hipSuccess) return fail(ctx, COMPVHIP_E_HIP, "radix sort size query", e);
 	p->sortTempBytes = tb;
 	uint8_t* tmp = nullptr;
 	HIPCHK(ctx, dmalloc(ctx, &tmp, std::max<size_t>(tb, 16)));
 	p->sortTemp = tmp;
+	p->sortChunks = static_cast<int>((cap + kShtSortChunk - 1) / kShtSortChunk);
+	if (p->strengthBits <= kShtSortMaxStrengthBits && p->sortChunks <= kShtSortMaxChunks) {
+		HIPCHK(ctx, dmalloc(ctx, &p->chunkHist, p->frames * static_cast<size_t>(p->sortChunks) << kShtSortMaxStrengthBits));
+		HIPCHK(ctx, dmalloc(ctx, &p->chunkStart, p->frames * static_cast<size_t>(p->sortChunks) << kShtSortMaxStrengthBits));
+		p->deviceSort = true;
+	}
 	p->lineCap = cap;
+	p->recentN = 0;   // totals clamped to another capacity
 	return COMPVHIP_OK;
 }
 
@@ -512,6 +527,7 @@ ShtArgs shtArgs(compvhip_plan* p, int threshold)
 	ShtArgs a;
 	a.ebits = p->ebits; a.edges = p->edges; a.edgeCounts = p->edgeCounts; a.acc = p->acc;
 	a.sinQ = p->sinQ; a.cosQ = p->cosQ; a.lineKeys = p->keysA; a.lineVals = p->valsA; a.lineCounts = p->lineCounts;
+	a.frameTotals = p->frameTotals; a.lineTotal = p->lineTotal; a.sortN = 0;
 	a.nmsRange = p->nmsRange; a.blockCounts = p->blockCounts; a.lineBlocks = p->lineBlocks; a.nmsFlags = p->nmsFlags; a.nmsRows = static_cast<int>(sht_nms_rows(static_cast<int>(p->R))); a.nmsGroups = sht_nms_groups(static_cast<int>(p->T));
 	a.bitsFrameStride = p->bitsFrameStride; a.edgeCap = p->edgeCap; a.accFrameStride = p->accFrameStride; a.lineCap = p->lineCap;
 	a.W = static_cast<int>(p->W); a.H = static_cast<int>(p->H); a.wb = p->wb;
@@ -751,16 +767,18 @@ int compvhip_plan_create(compvhip_ctx* ctx, size_t W, size_t H, size_t S, size_t
 			}
 			else p->voteTiles = false;
 			p->lineBlocks = p->voteTiles ? sht_lines_blocks(static_cast<int>(R)) : 0;
-			p->nCounts = (2 + static_cast<size_t>(p->voteTiles ? p->vt.tiles : 0) + static_cast<size_t>(p->lineBlocks)) * frames;
+			p->nCounts = (2 + static_cast<size_t>(p->voteTiles ? p->vt.tiles : 0) + static_cast<size_t>(p->lineBlocks)) * frames + (frames + 1) * kFrameSlot;
 		}
 		if (dmalloc(ctx, &p->counters, p->nCounts + kMaxRounds) != hipSuccess) { rc = COMPVHIP_E_OUT_OF_MEMORY; break; }
 		p->edgeCounts = p->counters; p->lineCounts = p->counters + frames; p->tileCounts = p->counters + 2 * frames; p->blockCounts = p->counters + (2 + static_cast<size_t>(p->voteTiles ? p->vt.tiles : 0)) * frames; p->flags = p->counters + p->nCounts;
+		p->frameTotals = p->blockCounts + static_cast<size_t>(p->lineBlocks) * frames; p->lineTotal = reinterpret_cast<unsigned int*>(p->frameTotals + frames * kFrameSlot);
 		if (const char* e = getenv("COMPVHIP_RESOLVE_WRAP")) { const int v = atoi(e); if (v >= 8 && v <= kMaxRounds && (v & 3) == 0) p->maxRounds = v; }
 		if (hipMemset(p->counters, 0, sizeof(int) * (p->nCounts + kMaxRounds)) != hipSuccess) { rc = COMPVHIP_E_HIP; break; }
 		if (dmalloc(ctx, &p->thrDev, frames) != hipSuccess) { rc = COMPVHIP_E_OUT_OF_MEMORY; break; }
 		if (dmalloc(ctx, &p->dirty, canny_resolve_dirty_bytes(static_cast<int>(H), p->wb, static_cast<int>(frames))) != hipSuccess) { rc = COMPVHIP_E_OUT_OF_MEMORY; break; }
 		if (dmalloc(ctx, &p->sums, frames * kFrameSlot) != hipSuccess) { rc = COMPVHIP_E_OUT_OF_MEMORY; break; }
-		if (hipHostMalloc(reinterpret_cast<void**>(&p->hFlags), sizeof(int) * (kAsyncDepth + 1)) != hipSuccess) { rc = COMPVHIP_E_OUT_OF_MEMORY; break; }
+		if (hipHostMalloc(reinterpret_cast<void**>(&p->hFlags), sizeof(int) * 2 * (kAsyncDepth + 1)) != hipSuccess) { rc = COMPVHIP_E_OUT_OF_MEMORY; break; }
+		p->hTotals = reinterpret_cast<unsigned int*>(p->hFlags + kAsyncDepth + 1);
 	} while (0);
 	if (rc) { compvhip_plan_destroy(p); return fail(ctx, rc, "plan allocation"); }
 	*out = p;
@@ -784,7 +802,7 @@ void compvhip_plan_destroy(compvhip_plan* p)
 	dfree(ctx, p->cosT); dfree(ctx, p->invSinT);
 	dfree(ctx, p->dKt); dfree(ctx, p->dRowBase); dfree(ctx, p->partLo); dfree(ctx, p->partHi); dfree(ctx, p->colFlag);
 	dfree(ctx, p->sinQ); dfree(ctx, p->cosQ); dfree(ctx, p->edges); dfree(ctx, p->acc);
-	dfree(ctx, p->keysA); dfree(ctx, p->keysB); dfree(ctx, p->valsA); dfree(ctx, p->valsB); dfree(ctx, p->nmsFlags);
+	dfree(ctx, p->keysA); dfree(ctx, p->keysB); dfree(ctx, p->valsA); dfree(ctx, p->valsB); dfree(ctx, p->nmsFlags); dfree(ctx, p->chunkHist); dfree(ctx, p->chunkStart);
 	dfree(ctx, p->nmsRange); dfree(ctx, p->reach); dfree(ctx, p->sortTemp);
 	delete p;
 }
@@ -946,8 +964,14 @@ int compvhip_plan_edge_dete(compvhip_plan* p, const uint8_t* d_in, int op, uint8
 	return COMPVHIP_OK;
 }
 
+// How many key slots the line sort covers (the reference sorts lines.size() elements, houghsht.cxx:241-249):
+//   kSortAll   the whole capacity, unused slots zeroed by sht_lines_kernel -- the stream-ordered entry point, which may not wait for the device;
+//   kSortExact the slots in use, read back behind sht_lines_kernel (one stream synchronisation) -- the synchronous step, which ends in one anyway;
+//   otherwise  that many slots (a prediction: the asynchronous step; the caller checks it against the real total later).
+constexpr size_t kSortAll = ~static_cast<size_t>(0), kSortExact = kSortAll - 1;
+
 static int planShtImpl(compvhip_plan* p, const uint8_t* d_edges, int threshold, int maxLines, compvhip_line* d_lines, size_t lineCap, int32_t* d_counts,
-                       hipStream_t st, bool clearTimeline, bool pairsOnly = false)
+                       hipStream_t st, bool clearTimeline, bool pairsOnly = false, size_t sortN = kSortAll)
 {
 	compvhip_ctx* ctx = p->ctx;
 	if (threshold <= 0) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "threshold must be > 0"); // houghsht.cxx:82
@@ -966,6 +990,10 @@ static int planShtImpl(compvhip_plan* p, const uint8_t* d_edges, int threshold, 
 		p->bitsValid = false; // U masks no longer match
 	}
 	ShtArgs a = shtArgs(p, threshold);
+	const size_t capAll = p->lineCap * p->frames;
+	const bool deviceSort = p->deviceSort && !pairsOnly;   // every size read on the device: nothing to predict, nothing to pad
+	if (sortN != kSortExact) sortN = std::min(sortN, capAll);
+	a.sortN = (pairsOnly || deviceSort || sortN == kSortExact) ? 0 : sortN;
 	if (!p->countersFresh) HIPCHK(ctx, hipMemsetAsync(p->counters, 0, sizeof(int) * p->nCounts, st)); // edge, line and tile counts
 	p->countersFresh = false;
 	{ Stamp s(p, st, "sht_compact_kernel"); HIPCHK(ctx, launch_sht_compact_tiles(a, p->vt, frames, st)); }
@@ -977,10 +1005,25 @@ static int planShtImpl(compvhip_plan* p, const uint8_t* d_edges, int threshold, 
 		if (d_counts) HIPCHK(ctx, hipMemcpyAsync(d_counts, p->lineCounts, sizeof(int32_t) * frames, hipMemcpyDeviceToDevice, st));
 		return COMPVHIP_OK;
 	}
-	{
+	if (deviceSort) {
+		if (d_lines && lineCap) {
+			Stamp s(p, st, "sht_sort_lines");
+			ShtSortArgs q;
+			q.sortedKeys = p->keysB; q.sortedVals = p->valsB; q.chunkHist = p->chunkHist; q.chunkStart = p->chunkStart; q.chunks = p->sortChunks;
+			HIPCHK(ctx, launch_sht_sort_lines(a, q, frames, p->thetaStep, maxLines, d_lines, lineCap, st));
+		}
+		if (d_counts) HIPCHK(ctx, hipMemcpyAsync(d_counts, p->lineCounts, sizeof(int32_t) * frames, hipMemcpyDeviceToDevice, st));
+		return COMPVHIP_OK;
+	}
+	if (sortN == kSortExact) {
+		HIPCHK(ctx, hipMemcpyAsync(p->hTotals, p->lineTotal, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
+		HIPCHK(ctx, hipStreamSynchronize(st));
+		sortN = std::min(static_cast<size_t>(p->hTotals[0]), capAll);
+	}
+	if (sortN) {
 		Stamp s(p, st, "sht_sort_lines");
 		size_t tb = p->sortTempBytes;
-		hipError_t e = sht_sort_pairs(p->sortTemp, tb, p->keysA, p->keysB, p->valsA, p->valsB, p->lineCap, frames, p->keyBits, st);
+		hipError_t e = sht_sort_pairs(p->sortTemp, tb, p->keysA, p->keysB, p->valsA, p->valsB, sortN, p->keyBits, st);
 		if (e != hipSuccess) return fail(ctx, COMPVHIP_E_HIP, "radix sort", e);
 	}
 	if (d_lines && lineCap) {
@@ -1043,9 +1086,9 @@ static int enqueueStep(compvhip_plan* p, const StepParams& sp, hipStream_t st, b
 
 static int toCartesianImpl(compvhip_plan* p, const compvhip_line* d_lines, const int32_t* d_counts, size_t lineCap, int maxLines, float* d_cart, void* stream);
 
-static int enqueueStepTail(compvhip_plan* p, const StepParams& sp, hipStream_t st)
+static int enqueueStepTail(compvhip_plan* p, const StepParams& sp, hipStream_t st, size_t sortN)
 {
-	int rc = planShtImpl(p, nullptr, sp.threshold, sp.maxLines, sp.d_lines, sp.lineCap, sp.d_counts, st, false);
+	int rc = planShtImpl(p, nullptr, sp.threshold, sp.maxLines, sp.d_lines, sp.lineCap, sp.d_counts, st, false, false, sortN);
 	if (rc) return rc;
 	if (sp.d_cart) {
 		rc = toCartesianImpl(p, sp.d_lines, sp.d_counts, sp.lineCap, sp.maxLines, sp.d_cart, st);   // d_counts = the UNCUT counts; only min(count, lineCap, maxLines) slots were decoded
@@ -1062,7 +1105,7 @@ static int runStepSync(compvhip_plan* p, const StepParams& sp, hipStream_t st)
 	if (rc) return rc;
 	const size_t bytes = p->S * p->H * p->frames;
 	for (;;) {
-		rc = enqueueStepTail(p, sp, st);
+		rc = enqueueStepTail(p, sp, st, kSortExact);
 		if (rc) return rc;
 		bool done = false;
 		rc = resolveConverged(p, st, &done);
@@ -1100,11 +1143,25 @@ static int runStepAsync(compvhip_plan* p, const StepParams& sp, hipStream_t st, 
 	if (p->timeline.size() > kMaxTimeline) timelineClear(p);
 	int rc = enqueueStep(p, sp, st, false);
 	if (rc) return rc;
-	rc = enqueueStepTail(p, sp, st);
+	// the sorted range: the largest total of the plan's recent steps + 1/16 + 4096 slots (nothing seen yet: everything)
+	size_t sortN = kSortAll;
+	if (p->recentN > 0) {
+		unsigned int m = 0;
+		for (int i = 0; i < std::min(p->recentN, 8); ++i) m = std::max(m, p->recentTotals[i]);
+		sortN = static_cast<size_t>(m) + (m >> 4) + 4096;
+	}
+	rc = ensureSht(p);
+	if (rc) return rc;
+	rc = ensureLineCap(p, std::max(sp.lineCap, kMinLineCap));
+	if (rc) return rc;
+	if (p->deviceSort) sortN = kSortAll;   // sized on the device: no prediction to check
+	sortN = std::min(sortN, p->lineCap * p->frames);
+	rc = enqueueStepTail(p, sp, st, sortN);
 	if (rc) return rc;
 	HIPCHK(ctx, hipMemcpyAsync(p->hFlags + 1 + slot, p->flags + (p->roundsUsed - 1), sizeof(int), hipMemcpyDeviceToHost, st));
+	HIPCHK(ctx, hipMemcpyAsync(p->hTotals + 1 + slot, p->lineTotal, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
 	HIPCHK(ctx, hipEventRecord(stp.done, st));
-	stp.used = true; stp.replay = false; stp.seq = ++p->stepSeq; stp.stream = st; stp.sp = sp;
+	stp.used = true; stp.replay = false; stp.seq = ++p->stepSeq; stp.stream = st; stp.sp = sp; stp.sortN = sortN;
 	*ticket = slot;
 	return COMPVHIP_OK;
 }
@@ -1161,9 +1218,13 @@ int compvhip_plan_wait(compvhip_plan* p, int ticket)
 	HIPCHK(ctx, hipSetDevice(ctx->device));
 	HIPCHK(ctx, hipEventSynchronize(stp.done));
 	stp.used = false;
-	if (p->hFlags[1 + ticket] == 0 && !stp.replay) return COMPVHIP_OK; // the speculative rounds reached the fixed point (the usual case)
-	// Rare: the hysteresis of this step needed more rounds than were enqueued, and a later step may already have reused the
-	// plan's masks.  Let the stream drain and run the step again, synchronously, from its (unmodified) input.  The replay writes this
+	const unsigned int total = p->hTotals[1 + ticket];
+	p->recentTotals[p->recentN++ & 7] = total;
+	if (p->recentN >= 16) p->recentN -= 8;   // the ring index keeps counting, "entries seen" saturates at 8
+	const bool sorted = static_cast<size_t>(total) <= stp.sortN;   // the predicted range covered every line of the step
+	if (p->hFlags[1 + ticket] == 0 && sorted && !stp.replay) return COMPVHIP_OK; // the speculative rounds reached the fixed point and the sort covered the lines (the usual case)
+	// Rare: the hysteresis of this step needed more rounds than were enqueued (or it produced more lines than the sorted range held), and a later step may
+	// already have reused the plan's masks.  Let the stream drain and run the step again, synchronously, from its (unmodified) input.  The replay writes this
 	// step's output buffers AFTER the later steps of the plan ran: if they share those buffers (a caller that only consumes the newest
 	// result), their results are gone -- every step enqueued after this one is therefore replayed as well when it is waited for, in order.
 	HIPCHK(ctx, hipStreamSynchronize(stp.stream));

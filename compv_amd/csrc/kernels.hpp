@@ -106,8 +106,8 @@ struct ShtArgs {
 	uint16_t* acc;            // [frames][T][accPitch], u16: a cell never exceeds 65535
 	const int32_t* sinQ;      // [T]
 	const int32_t* cosQ;      // [T]
-	uint32_t* lineKeys;       // [frames][lineCap] sort keys: frameTag << strengthBits | strength
-	uint32_t* lineVals;       // [frames][lineCap] their accumulator cells: row * T + col
+	uint32_t* lineKeys;       // [frames * lineCap] sort keys: frameTag << strengthBits | strength -- DENSE: frame f's lines follow frame f-1's (min(count, lineCap) each)
+	uint32_t* lineVals;       // [frames * lineCap] their accumulator cells: row * T + col
 	uint8_t* nmsFlags;        // [frames][nmsGroups][nmsRows] NMS survivors: bit j of byte (group, row) = column 8 group + j
 	int nmsRows;              // rows of a flag plane
 	int* blockCounts;         // [frames][lineBlocks] NMS survivors per 64 accumulator rows (one row block of sht_lines_kernel); written by sht_count_kernel
@@ -115,6 +115,9 @@ struct ShtArgs {
 	const int2* nmsRange;     // [nmsGroups] accumulator rows [x, y) the windows of the group's columns (+ one either side) can reach, widened by one row
 	int nmsGroups;            // groups of 8 theta columns
 	int* lineCounts;          // per frame
+	int* frameTotals;         // [frames * kFrameSlot] NMS survivors per frame, one counter per 128-byte line (sht_count_kernel adds its row blocks, zeroed per step)
+	unsigned int* lineTotal;  // sum over the frames of min(survivors, lineCap) = the key slots in use (written by sht_lines_kernel)
+	size_t sortN;             // key slots the sort will cover: sht_lines_kernel zeroes [lineTotal, sortN) (0: nothing to pad -- the sort is sized after the fact)
 	size_t bitsFrameStride, edgeCap, accFrameStride, lineCap;
 	int W, H, wb;
 	int R, T, accPitch, barrier;
@@ -153,8 +156,21 @@ int sht_lines_blocks(int R);
 hipError_t launch_sht_cartesian(const void* lines /*compvhip_line*/, const int* counts, size_t lineCap, int maxLines, int frames, int T, const float* cosT,
                                 const float* invSinT, float widthF, float r, float* out /*[frames][lineCap][4]*/, hipStream_t stream);
 hipError_t launch_sht_acc_transpose(const uint16_t* accT, int R, int T, int accPitch, int32_t* out, size_t outStride, hipStream_t stream);
-// one stable descending radix sort over the (key, value) slots of all frames; temp == nullptr queries tempBytes
-hipError_t sht_sort_pairs(void* temp, size_t& tempBytes, const uint32_t* keysIn, uint32_t* keysOut, const uint32_t* valsIn, uint32_t* valsOut, size_t lineCap,
-                          int frames, int keyBits, hipStream_t stream);
+// the line sort sized on the device (sht_sort_kernels.hip): counting sort on the strength, stable ranks from chunks sorted in the LDS
+constexpr int kShtSortChunk = 4096;             // lines per chunk (one workgroup)
+constexpr int kShtSortMaxStrengthBits = 13;     // 8192 strength bins: max(W, H) <= 4095
+constexpr int kShtSortMaxChunks = 32;           // chunks per frame it is used for (line capacities up to 131 072 per frame)
+struct ShtSortArgs {
+	uint32_t* sortedKeys;     // [frames * lineCap] per line of a sorted chunk: (inverted strength << 12) | rank inside its run of equal strengths
+	uint32_t* sortedVals;     // [frames * lineCap] its accumulator cell
+	uint16_t* chunkHist;      // [frames][chunks][8192] lines per inverted strength of a chunk (written whole by the chunks that have lines)
+	uint32_t* chunkStart;     // [frames][chunks][8192] first slot, in the frame's sorted line list, of the lines of a chunk with that inverted strength
+	int chunks;               // chunks per frame = ceil(lineCap / 4096)
+};
+hipError_t launch_sht_sort_lines(const ShtArgs& a, const ShtSortArgs& q, int frames, float thetaStep, int maxLines, void* lines /*compvhip_line*/, size_t outCap,
+                                 hipStream_t stream);
+// one stable descending radix sort over the first n (key, value) slots; temp == nullptr queries tempBytes (for n = the capacity)
+hipError_t sht_sort_pairs(void* temp, size_t& tempBytes, const uint32_t* keysIn, uint32_t* keysOut, const uint32_t* valsIn, uint32_t* valsOut, size_t n,
+                          int keyBits, hipStream_t stream);
 
 } // namespace compvhip

@@ -215,7 +215,10 @@ __global__ __launch_bounds__(kLnRows) void sht_count_kernel(ShtArgs a)
 	}
 #pragma unroll
 	for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
-	if (lane == 0) a.blockCounts[frame * nblk + blk] = (int)cnt;
+	if (lane == 0) {
+		a.blockCounts[frame * nblk + blk] = (int)cnt;
+		if (cnt) atomicAdd(a.frameTotals + (size_t)frame * kFrameSlot, (int)cnt);   // the frame's total: where the NEXT frame's lines start (dense key array)
+	}
 }
 
 // One WAVE per 64 complete accumulator rows, lane = row: no barriers, every workgroup of the launch resident at once (the version with
@@ -272,10 +275,20 @@ __global__ __launch_bounds__(kLnRows) void sht_lines_kernel(ShtArgs a)
 			count += (i < nblk) ? v[u] : 0u;
 		}
 	}
+	// the frame's first slot in the DENSE key array = the lines (clamped to lineCap) of the earlier frames; `grand` = those of all frames.  The sort then
+	// covers the slots that exist instead of frames * lineCap padded ones (the reference sorts lines.size() elements, houghsht.cxx:241-249)
+	const uint32_t capU = (uint32_t)min(a.lineCap, (size_t)0xffffffffu);
+	uint32_t fbase = 0, grand = 0;
+	for (int g0 = 0; g0 < a.frames; g0 += kLnRows) {
+		const int g = g0 + lane;
+		const uint32_t c = min((uint32_t)max(a.frameTotals[(size_t)min(g, a.frames - 1) * kFrameSlot], 0), capU);   // clamped index: unconditional load
+		fbase += (g < frame) ? c : 0u;
+		grand += (g < a.frames) ? c : 0u;
+	}
 #pragma unroll
-	for (int o = 32; o > 0; o >>= 1) { first += __shfl_xor(first, o); count += __shfl_xor(count, o); }
-	uint32_t* __restrict__ keys = a.lineKeys + (size_t)frame * a.lineCap;
-	uint32_t* __restrict__ vals = a.lineVals + (size_t)frame * a.lineCap;
+	for (int o = 32; o > 0; o >>= 1) { first += __shfl_xor(first, o); count += __shfl_xor(count, o); fbase += __shfl_xor(fbase, o); grand += __shfl_xor(grand, o); }
+	uint32_t* __restrict__ keys = a.lineKeys + (size_t)fbase;
+	uint32_t* __restrict__ vals = a.lineVals + (size_t)fbase;
 	// 3. the survivors in (row, column) order: key = frameTag | strength, value = cell (row * T + col), put in place in the LDS and stored
 	// coalesced (a lane storing its own few items would touch 64 different cache lines per instruction)
 	if (total) {
@@ -327,12 +340,16 @@ __global__ __launch_bounds__(kLnRows) void sht_lines_kernel(ShtArgs a)
 			}
 		}
 	}
-	// 4. the line count, and this block's slice of the unused key slots (a zero key sorts last: every real key carries a strength > 0).
-	// (Left to the frame's last block alone, the zeroing is 24 us on the critical path of a frame with few lines.)
-	if (blk == 0 && lane == 0) a.lineCounts[frame] = (int)min(count, 0x7fffffffu);
-	if ((size_t)count < a.lineCap) {
-		const size_t pad = a.lineCap - count, per = (pad + (size_t)nblk - 1) / (size_t)nblk;
-		for (size_t i = (size_t)blk * per + lane; i < min((size_t)(blk + 1) * per, pad); i += kLnRows) keys[(size_t)count + i] = 0u;
+	// 4. the line count, the slots in use, and this block's slice of the slots between them and the end of the sorted range (a zero key sorts
+	// last: every real key carries a strength > 0).  (Left to one block alone, the zeroing is 24 us on the critical path of a frame with few lines.)
+	if (blk == 0 && lane == 0) {
+		a.lineCounts[frame] = (int)min(count, 0x7fffffffu);
+		if (frame == 0) *a.lineTotal = grand;
+	}
+	if ((size_t)grand < a.sortN) {
+		const size_t nb = (size_t)a.frames * (size_t)nblk, bi = (size_t)frame * (size_t)nblk + (size_t)blk;
+		const size_t pad = a.sortN - grand, per = (pad + nb - 1) / nb;
+		for (size_t i = bi * per + lane; i < min((bi + 1) * per, pad); i += kLnRows) a.lineKeys[(size_t)grand + i] = 0u;
 	}
 }
 
@@ -440,13 +457,13 @@ hipError_t launch_sht_lines(const ShtArgs& a, int frames, hipStream_t stream)
 }
 
 // one stable descending radix sort over the (key, value) slots of all frames (rocPRIM device primitive)
-hipError_t sht_sort_pairs(void* temp, size_t& tempBytes, const uint32_t* keysIn, uint32_t* keysOut, const uint32_t* valsIn, uint32_t* valsOut, size_t lineCap,
-                          int frames, int keyBits, hipStream_t stream)
+hipError_t sht_sort_pairs(void* temp, size_t& tempBytes, const uint32_t* keysIn, uint32_t* keysOut, const uint32_t* valsIn, uint32_t* valsOut, size_t n,
+                          int keyBits, hipStream_t stream)
 {
 	// 10-bit digits: the 18-bit key of the 4K benchmark (5 frame bits + 13 strength bits) takes two onesweep passes
 	using Onesweep = rocprim::radix_sort_onesweep_config<rocprim::kernel_config<1024, 8>, rocprim::kernel_config<1024, 10>, 10, rocprim::block_radix_rank_algorithm::match>;
 	using Config = rocprim::radix_sort_config<rocprim::default_config, rocprim::default_config, Onesweep>;
-	return rocprim::radix_sort_pairs_desc<Config>(temp, tempBytes, keysIn, keysOut, valsIn, valsOut, lineCap * (size_t)frames, 0u, (unsigned int)keyBits, stream);
+	return rocprim::radix_sort_pairs_desc<Config>(temp, tempBytes, keysIn, keysOut, valsIn, valsOut, n, 0u, (unsigned int)keyBits, stream);
 }
 
 hipError_t launch_sht_decode(const uint32_t* keys, const uint32_t* vals, const int* counts, size_t lineCap, int frames, int T, int barrier, float thetaStep,

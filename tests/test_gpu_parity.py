@@ -989,6 +989,65 @@ def test_plan_pipeline_async_matches_sync(hip_ctx, oracle):
         plan.close()
 
 
+def test_plan_wide_frames_use_the_library_sort_sized_by_the_lines(hip_ctx, oracle):
+    """max(W, H) > 4095: a strength needs 14 bits, so the line sort is the library's radix sort over the key slots in use -- read back by the
+    synchronous step, predicted from the plan's earlier steps by the asynchronous one.  Three asynchronous steps (the second has far more lines
+    than the first lets it predict: the replay of compvhip_plan_wait; the third has fewer), then the synchronous and the stream-ordered
+    entry points on the same plan; every list against the oracle, element by element, in the canonical order."""
+    import torch
+    from compv_amd import capi
+    W, H, n, cap = 4104, 72, 2, 8192
+    dev = torch.device("cuda:0")
+
+    def frames_with(nbars):
+        out = []
+        for f in range(n):
+            img = np.full((H, W), 40, np.uint8)
+            for b in range(nbars + f):
+                x = 20 + 37 * b
+                img[6:H - 6, x:x + 3] = 200
+            out.append(img)
+        return np.stack(out)
+
+    batches = [frames_with(2), frames_with(100), frames_with(40)]
+    plan = capi.Plan(hip_ctx, W, H, W, n, 1.0)
+    st = torch.cuda.Stream(device=dev)
+
+    def check(batch, d_e, d_l, d_c, thr, what):
+        edges = d_e.cpu().numpy(); counts = d_c.cpu().numpy(); raw = d_l.cpu().numpy().view(np.uint8).reshape(n, cap, 20)
+        for f in range(n):
+            rc, e = oracle.canny(batch[f], 59.0, 119.0)
+            assert (edges[f] == e).all(), (what, f)
+            exp = oracle.sht(e, 1.0, thr)
+            assert counts[f] == len(exp), (what, f, counts[f], len(exp))
+            assert _lines_tuple(np.frombuffer(raw[f].tobytes(), dtype=capi.LINE_DTYPE)[:min(len(exp), cap)]) == _orc_tuple(exp[:cap]), (what, f)
+        return int(counts.sum())
+
+    try:
+        totals = []
+        for k, b in enumerate(batches):
+            d_in = torch.from_numpy(b).to(dev); d_e = torch.empty_like(d_in)
+            d_l = torch.zeros((n, cap, 5), dtype=torch.int32, device=dev); d_c = torch.zeros(n, dtype=torch.int32, device=dev)
+            torch.cuda.synchronize()
+            t = plan.pipeline_async(d_in.data_ptr(), 59.0, 119.0, 30, 0, d_e.data_ptr(), d_l.data_ptr(), cap, d_c.data_ptr(), st.cuda_stream)
+            plan.wait(t); st.synchronize()
+            totals.append(check(b, d_e, d_l, d_c, 30, "async %d" % k))
+        assert totals[0] > 0 and totals[1] > totals[0] + (totals[0] >> 4) + 4096, totals   # step 1 has more lines than step 0 lets it predict: replayed
+        b = batches[2]
+        d_in = torch.from_numpy(b).to(dev); d_e = torch.empty_like(d_in)
+        d_l = torch.zeros((n, cap, 5), dtype=torch.int32, device=dev); d_c = torch.zeros(n, dtype=torch.int32, device=dev)
+        torch.cuda.synchronize()
+        plan.pipeline(d_in.data_ptr(), 59.0, 119.0, 30, 0, d_e.data_ptr(), d_l.data_ptr(), cap, d_c.data_ptr(), st.cuda_stream)
+        st.synchronize()
+        check(b, d_e, d_l, d_c, 30, "sync")
+        d_l.zero_(); d_c.zero_(); torch.cuda.synchronize()
+        plan.houghsht(d_e.data_ptr(), 30, 0, d_l.data_ptr(), cap, d_c.data_ptr(), st.cuda_stream)   # stream-ordered: the whole capacity is sorted
+        st.synchronize()
+        check(b, d_e, d_l, d_c, 30, "stream-ordered")
+    finally:
+        plan.close()
+
+
 def test_async_replay_with_shared_output_buffers(hip_ctx, oracle):
     """compvhip_plan_wait's replay rule (include/compv_hip.h): steps in flight may SHARE their output buffers; when an earlier step is replayed
     (its hysteresis needed more rounds than were enqueued), the later steps are replayed too when they are waited for, so after wait(t) the
