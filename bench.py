@@ -88,19 +88,25 @@ class FrameSynth:
 # ------------------------------------------------------------------------------------------------------------------------------------
 # CPU baseline
 # ------------------------------------------------------------------------------------------------------------------------------------
-def _ref_worker(threads, first_seed, n, work_s, W, H, barrier, queue):
+def _ref_worker(threads, first_seed, n, work_s, W, H, barrier, queue, task="pipeline"):
     """One process of the frame-parallel baseline: its own CompV instance with `threads` workers, its own frames.  Import, library start-up and
-    frame synthesis happen BEFORE the cross-process barrier; the clock runs over passes over the worker's n frames until work_s seconds are up."""
+    frame synthesis happen BEFORE the cross-process barrier; the clock runs over passes over the worker's n frames until work_s seconds are up.
+    task "pipeline": Canny + SHT on the frames; task "kht": CompVHoughKht::process on the frames' Canny edge maps (made before the barrier)."""
     try:
         from oracle_bindings import RefShim, synth_frame
         ref = RefShim(threads)
         frames = np.stack([synth_frame(W, H, first_seed + f) for f in range(n)])
-        ref.bench_pipeline(frames[:1], T_LOW, T_HIGH, THETA_DEG, SHT_THRESHOLD)   # warm the pool and the scratch buffers
+        if task == "kht":
+            maps = np.stack([ref.canny(fr, T_LOW, T_HIGH)[1] for fr in frames])
+            run = lambda i: ref.bench_kht(maps[i:i + 1], 1.0, THETA_DEG, 1)
+        else:
+            run = lambda i: ref.bench_pipeline(frames[i:i + 1], T_LOW, T_HIGH, THETA_DEG, SHT_THRESHOLD)
+        run(0)   # warm the pool and the scratch buffers
         barrier.wait()
         t0 = time.time()
         done = 0
         while time.time() - t0 < work_s:
-            ref.bench_pipeline(frames[done % n:done % n + 1], T_LOW, T_HIGH, THETA_DEG, SHT_THRESHOLD)
+            run(done % n)
             done += 1
         queue.put((t0, time.time(), done))
     except Exception as e:  # a worker that dies must not leave the others at the barrier for ever
@@ -111,16 +117,42 @@ def _ref_worker(threads, first_seed, n, work_s, W, H, barrier, queue):
         queue.put(("error", repr(e), 0))
 
 
-def frame_parallel_baseline(W, H, threads_per_proc, cores, work_s=4.0):
+def host_cpu_budget():
+    """What the host really offers this process: logical CPUs, the affinity mask and the cgroup CPU quota (a container may see 256 CPUs and own 64)."""
+    out = {"logical_cpus": os.cpu_count() or 1}
+    try:
+        out["sched_affinity"] = len(os.sched_getaffinity(0))
+    except Exception:
+        out["sched_affinity"] = None
+    quota = None
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            quota = open(path).read().strip()
+            out["cgroup_cpu_max_file"] = path
+            break
+        except Exception:
+            pass
+    out["cgroup_cpu_max"] = quota
+    try:
+        q = quota.split()
+        if q[0] not in ("max", "-1"):
+            period = float(q[1]) if len(q) > 1 else float(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            out["cgroup_cpus"] = round(float(q[0]) / period, 2)
+    except Exception:
+        pass
+    return out
+
+
+def frame_parallel_baseline(W, H, threads_per_proc, cores, work_s=4.0, procs=None, task="pipeline"):
     """P processes x T threads over independent frames, all released together (barrier); every worker processes frames for work_s seconds."""
     import multiprocessing as mp
     ctx = mp.get_context("spawn")
     tt = max(1, threads_per_proc)
-    procs = max(1, min(cores // tt, 32))
+    procs = max(1, min(cores // tt, 32)) if procs is None else max(1, min(procs, cores // tt))
     n = 4
     barrier = ctx.Barrier(procs)
     queue = ctx.Queue()
-    ps = [ctx.Process(target=_ref_worker, args=(tt, 20000 + 100 * i, n, work_s, W, H, barrier, queue)) for i in range(procs)]
+    ps = [ctx.Process(target=_ref_worker, args=(tt, 20000 + 100 * i, n, work_s, W, H, barrier, queue, task)) for i in range(procs)]
     for pr in ps:
         pr.start()
     res = [queue.get(timeout=600) for _ in ps]
@@ -133,6 +165,7 @@ def frame_parallel_baseline(W, H, threads_per_proc, cores, work_s=4.0):
     frames = sum(r[2] for r in res)
     return {"value": round(frames * W * H / span / 1e6, 2), "unit": "Mpixels/s", "processes": procs, "threads_per_process": tt, "cores": procs * tt,
             "frames": frames, "span_s": round(span, 3), "start_skew_s": round(max(r[0] for r in res) - min(r[0] for r in res), 4),
+            "ms_per_frame": round(span * 1e3 / max(frames, 1), 3), "thread_ms_per_frame": round(span * 1e3 * procs * tt / max(frames, 1), 2),
             "note": "all workers released by one cross-process barrier after start-up, each processes frames for %.0f s; throughput = frames / (last finish - first start)" % work_s}
 
 
@@ -166,9 +199,12 @@ def cpu_baseline(W, H, budget_s=20.0):
                "ms_per_frame": round(ms / n, 3), "ms_per_frame_by_threads": sweep}
         # frame-parallel: CompV's row-band pool stops scaling at ~8 threads, independent frames do not -- P processes x T threads
         # ("all host cores via row-band / frame-parallel threads")
+        out["host"] = host_cpu_budget()
         try:
             tt = max(1, min(best, 8))
             out["frame_parallel"] = frame_parallel_baseline(W, H, tt, cores)
+            # the same harness with ONE thread per process: if P x 8 threads barely beat one process, is it the row-band pool or the host?
+            out["frame_parallel"]["one_thread_per_process"] = frame_parallel_baseline(W, H, 1, cores, work_s=3.0, procs=32)
         except Exception as e:  # reporting only
             out["frame_parallel"] = {"error": str(e)}
         return out
@@ -372,6 +408,9 @@ def main():
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on these hosts (RCCL needs it)
+        if local_rank >= torch.cuda.device_count():
+            raise SystemExit("bench.py: rank %d wants cuda:%d but this node shows %d GPU(s) -- launch with --nproc-per-node <= the visible GPUs"
+                             % (rank, local_rank, torch.cuda.device_count()))
         torch.cuda.set_device(local_rank)
         if args.shared_gpu:
             dist.init_process_group(backend=args.dist_backend)
@@ -385,7 +424,7 @@ def main():
     W, H, F, NB = args.width, args.height, args.frames_per_gpu, max(1, args.batches)
     synth = FrameSynth(torch, dev, W, H)
     # frame f of block b has the global index b * F + f and the seed 12345 + (index mod 256); rank r runs block (r + k) % NB at step k
-    block_seeds = [[sharding.frame_seed((b * F + f) % GOLDEN_FRAMES) for f in range(F)] for b in range(NB)]
+    block_seeds = sharding.block_seeds(F, NB, GOLDEN_FRAMES)
     blocks = [synth.batch(s) for s in block_seeds]
     if rank == 0:   # the device generator against the host one (one frame: the generators are checked exhaustively in tests/)
         from oracle_bindings import synth_frame
@@ -407,7 +446,7 @@ def main():
     TOPK = 64
 
     def my_block(k):
-        return (rank + k) % NB
+        return sharding.block_of_step(rank, k, NB)
 
     def enqueue(q, k):
         """step k on lane q (asynchronous); returns the ticket"""
@@ -416,7 +455,7 @@ def main():
             # the global batch of step k lives on rank 0 (its resident blocks): rank r receives block (r + k) % NB over RCCL
             # (grouped send/recv), ordered on the lane's stream in front of the step's kernels
             with torch.cuda.stream(q["stream"]):
-                sharding.scatter_blocks(dist if dist_on else None, lambda r: blocks[(r + k) % NB], q["in"], src=0)
+                sharding.scatter_blocks(dist if dist_on else None, lambda r: blocks[sharding.block_of_step(r, k, NB)], q["in"], src=0)
             d_in = q["in"]
         return q["plan"].pipeline_async(d_in.data_ptr(), T_LOW, T_HIGH, SHT_THRESHOLD, 0, q["edges"].data_ptr(), q["lines"].data_ptr(), line_cap,
                                         q["counts"].data_ptr(), q["stream"].cuda_stream)
@@ -566,6 +605,15 @@ def main():
         all_counts = sharding.gather_frame_results([int(c) for c in lanes[0]["counts"].cpu().numpy()], dist if dist_on else None, comm_dev)
     except Exception:  # reporting only: never let it hide the throughput number
         all_counts = None
+    # what a SCALE record can be checked against: every rank reports itself through an all-gather, and the collective library's version
+    try:
+        seen = sharding.ranks_seen(dist if dist_on else None, comm_dev)
+    except Exception:  # reporting only
+        seen = []
+    try:
+        rccl_version = ".".join(str(v) for v in torch.cuda.nccl.version()) if dist_on and args.dist_backend == "nccl" else None
+    except Exception:
+        rccl_version = None
     n_ranks = dist.get_world_size() if dist_on else 1
     total_px = n_ranks * F * W * H * args.steps
     value = total_px / elapsed / 1e6
@@ -671,6 +719,7 @@ def main():
             "batches_in_flight": len(lanes),
             "vs_baseline": None, "dtype": "u8", "data": "synthetic",
             "dist_backend": (dist.get_backend() if dist_on else None),
+            "rccl_version": rccl_version, "n_ranks_seen": len(seen), "ranks_seen": seen,
             "config": {"workload": "batched %dx%d uint8 frames, Sobel3x3 -> Canny(59,119) -> HoughSHT(rho=1, theta=1deg, thr=100); %d distinct frames "
                                    "resident per GPU as %d batches of %d, a step processes one batch, steps rotate over the batches"
                                    % (W, H, min(NB * F, GOLDEN_FRAMES), NB, F),
@@ -735,6 +784,42 @@ def kht_figure(capi, ctx, torch, lane, blocks, W, H, F):
         dts.append(time.perf_counter() - t0)
     dt = sorted(dts)[len(dts) // 2]
     stages = q["plan"].houghkht_stage_ms()
+    # the same call with fewer host threads (the default above is min(32, hardware threads / 2)): how much of the figure is the host pool
+    by_threads = {}
+    for nt in (1, 8, 16, 32):
+        try:
+            q["plan"].houghkht(q["edges"].data_ptr(), 1.0, THETA_DEG, 1, threads=nt)
+            ts = []
+            for _ in range(1 if nt == 1 else 3):
+                t0 = time.perf_counter()
+                q["plan"].houghkht(q["edges"].data_ptr(), 1.0, THETA_DEG, 1, threads=nt)
+                ts.append(time.perf_counter() - t0)
+            by_threads[str(nt)] = round(sorted(ts)[len(ts) // 2] * 1e3 / F, 3)
+        except Exception as e:  # reporting only
+            by_threads[str(nt)] = "error: %s" % e
+    # BASELINE config 5 asks for HBM GB/s: SURVEY 8(d)'s algorithmic bytes of the KHT (the edge map read once + the vote map written once) against the time of the
+    # stages that touch the GPU (host clocks of the issuing threads, single-frame call: upload + kernels + download + their synchronisations)
+    roof = None
+    try:
+        ax = capi.houghkht_dims(W, H, 1.0, THETA_DEG) if hasattr(capi, "houghkht_dims") else None
+        if ax:
+            T_, rhoN = ax
+            alg = W * H + (T_ + 2) * (rhoN + 2) * 4
+            one = ctx.houghkht(q["edges"][0].cpu().numpy(), 1.0, THETA_DEG, 1)
+            sm = ctx.houghkht_stage_ms()            # link, subdivide, statistics, prune, vote + peaks, sort + sweep
+            gpu_ms = float(sm[1] + sm[2] + sm[4])
+            traffic = None
+            tj = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r05", "kht_traffic.json")
+            if os.path.exists(tj):
+                tdat = json.load(open(tj))
+                traffic = tdat.get("hbm_bytes_per_call") if tdat.get("so_sha256") == so_sha256() else None
+            roof = {"bound": "hbm", "algorithmic_bytes_per_frame": alg, "gpu_stage_ms_single_frame": round(gpu_ms, 4),
+                    "achieved": round(alg / (gpu_ms * 1e-3) / 1e9, 2) if gpu_ms > 0 else None, "peak": 8000.0, "unit": "GB/s",
+                    "frac": round(alg / (gpu_ms * 1e-3) / 1e9 / 8000.0, 5) if gpu_ms > 0 else None, "traffic": traffic,
+                    "note": "the KHT is latency-bound, not bandwidth-bound: its GPU stages move a few MB per frame (profiles/r05/kht_pmc*); W*H + (T+2)(rhoN+2)*4 bytes per frame "
+                            "over the wall time of the subdivision + statistics + voting/peaks stages of one single-frame call (uploads, kernels, downloads, synchronisations)"}
+    except Exception as e:  # reporting only
+        roof = {"error": str(e)}
     cpu = None
     try:
         from oracle_bindings import RefShim, have_refshim
@@ -753,10 +838,23 @@ def kht_figure(capi, ctx, torch, lane, blocks, W, H, F):
                 sweep[ref.threads] = round(ms / len(maps), 3)
             best = min(sweep, key=sweep.get)
             cpu = {"ms_per_frame": sweep[best], "cores": best, "kind": "reference", "ms_per_frame_by_threads": sweep, "lines_4_frames": int(nl),
-                   "sample": "%d of the batch's %dx%d edge maps, CompVHoughKht::process (AVX2 / SSE intrinsics path, COMPV_ASM=0), best of the thread sweep" % (len(maps), W, H)}
+                   "sample": "%d of the batch's %dx%d edge maps, CompVHoughKht::process (AVX2 / SSE intrinsics path, COMPV_ASM=0), best of the thread sweep; "
+                             "single-frame LATENCY -- the throughput comparison at equal host resources is frame_parallel" % (len(maps), W, H)}
+            # equal resources: P processes x 1 thread of the real CompVHoughKht::process on independent edge maps, behind one barrier
+            # (tests/image/houghkht.cxx times process() in a loop the same way); thread-ms per frame on both sides
+            try:
+                cores = os.cpu_count() or 1
+                fp = frame_parallel_baseline(W, H, 1, cores, work_s=3.0, procs=32, task="kht")
+                cpu["frame_parallel"] = fp
+            except Exception as e:
+                cpu["frame_parallel"] = {"error": str(e)}
     except Exception as e:  # reporting only
         cpu = {"error": str(e)}
+    nthreads = stages.get("threads") or 0
     return {"ms_per_frame": round(dt * 1e3 / F, 3), "ms_per_frame_calls": [round(d * 1e3 / F, 3) for d in dts], "frames": F, "lines_frame0": int(len(res[0][0])),
+            "thread_ms_per_frame": round(dt * 1e3 / F * nthreads, 2) if nthreads else None,
+            "ms_per_frame_by_host_threads": by_threads,
+            "roofline": roof,
             "cpu_baseline": cpu,
             "host_threads": stages.get("threads"),
             "host_share": stages.get("host_share"), "stages_ms_per_frame": stages.get("stages"),

@@ -40,6 +40,7 @@ EXPORTS = [
     "compvhip_plan_pipeline_async", "compvhip_plan_wait", "compvhip_houghsht_to_cartesian", "compvhip_houghkht_to_cartesian",
     "compvhip_houghkht_kernels_u8", "compvhip_houghkht_stage_ms", "compvhip_convlt1_8u16s16s", "compvhip_convlt1_16s16s16s",
     "compvhip_plan_pipeline_ex", "compvhip_plan_houghkht", "compvhip_plan_houghkht_stage_ms", "compvhip_houghkht_link_u8",
+    "compvhip_houghkht_dims",
 ]
 
 
@@ -407,6 +408,17 @@ def houghkht_link(edges, min_size=10):
     if rc:
         raise CompvHipError(rc, "compvhip_houghkht_link_u8")
     return xy[:npts.value].copy(), ends[:nstr.value].copy()
+
+
+def houghkht_dims(W, H, rho=1.0, theta_deg=1.0):
+    """(T, rhoN) of the KHT vote map for a W x H image (compvhip_houghkht_dims)."""
+    lib = load()
+    r = C.c_size_t(0); t = C.c_size_t(0)
+    lib.compvhip_houghkht_dims.argtypes = [C.c_size_t, C.c_size_t, C.c_float, C.c_float, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
+    rc = lib.compvhip_houghkht_dims(W, H, rho, theta_deg, C.byref(r), C.byref(t))
+    if rc:
+        raise CompvHipError(rc, "compvhip_houghkht_dims")
+    return int(t.value), int(r.value)
 
 
 def to_cartesian(W, H, lines, kht=False):

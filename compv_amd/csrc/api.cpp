@@ -731,6 +731,14 @@ int compvhip_houghsht_dims(size_t W, size_t H, float thetaDeg, size_t* R, size_t
 	return shtDims(W, H, thetaDeg, R, T, step);
 }
 
+int compvhip_houghkht_dims(size_t W, size_t H, float rho, float thetaDeg, size_t* rhoN, size_t* T)
+{
+	KhtAxes ax;
+	if (!rhoN || !T || !khtAxes(W, H, rho, thetaDeg, ax)) return COMPVHIP_E_INVALID_PARAMETER;
+	*rhoN = ax.rhoN; *T = ax.T;
+	return COMPVHIP_OK;
+}
+
 // ---- plans -------------------------------------------------------------------------------------------------------
 int compvhip_plan_create(compvhip_ctx* ctx, size_t W, size_t H, size_t S, size_t frames, float thetaDeg, compvhip_plan** out)
 {

@@ -18,6 +18,18 @@ def frame_seed(frame_index):
     return BASE_SEED + frame_index
 
 
+# ---- the benchmark's block rotation (BASELINE config 4: 256 frames = 8 resident blocks of 32) --------------------------------------
+def block_seeds(frames_per_block, n_blocks, golden_frames=256):
+    """Seeds of the resident blocks every rank builds: frame f of block b is frame (b * F + f) mod golden_frames of the global synthetic batch."""
+    return [[frame_seed((b * frames_per_block + f) % golden_frames) for f in range(frames_per_block)] for b in range(n_blocks)]
+
+
+def block_of_step(rank, step, n_blocks):
+    """The resident block rank `rank` processes at step `step`: at any step the ranks of a world of n_blocks hold n_blocks DIFFERENT blocks (with
+    8 ranks and 8 blocks of 32: exactly config 4's 256 frames per step), and consecutive steps of a rank never re-read the same block."""
+    return (rank + step) % n_blocks
+
+
 def max_over_ranks(value, dist=None, device=None):
     """MAX of a python float over all ranks (the timing rule of bench.py); identity when not distributed."""
     if dist is None or not dist.is_initialized():   # a world of ONE initialised rank still goes through the collective (bench.py --force-dist)
@@ -26,6 +38,18 @@ def max_over_ranks(value, dist=None, device=None):
     t = torch.tensor([float(value)], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def ranks_seen(dist=None, device=None):
+    """Every rank contributes its own rank number to an all-gather; the sorted list must be 0 .. world-1 (a SCALE record can be checked against it)."""
+    if dist is None or not dist.is_initialized():
+        return [0]
+    import torch
+    world = dist.get_world_size()
+    mine = torch.tensor([dist.get_rank()], dtype=torch.int64, device=device)
+    out = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(out, mine)
+    return sorted(int(t.item()) for t in out)
 
 
 def gather_frame_results(local_values, dist=None, device=None):

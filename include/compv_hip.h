@@ -195,6 +195,9 @@ COMPVHIP_API int compvhip_houghkht_to_cartesian(size_t W, size_t H, const compvh
 /* Geometry helper: R (rho rows), T (theta bins) and the float32 theta step for a W x H image
  * (initCoords, houghsht.cxx:318-348). */
 COMPVHIP_API int compvhip_houghsht_dims(size_t W, size_t H, float thetaDeg, size_t* R, size_t* T, float* thetaStepRad);
+/* Geometry helper of the KHT: rho bins and theta bins of its vote map for a W x H image (initCoords,
+ * core/features/hough/compv_core_feature_houghkht.cxx:501-541); the map holds (T + 2) x (rhoN + 2) int32 cells. */
+COMPVHIP_API int compvhip_houghkht_dims(size_t W, size_t H, float rho, float thetaDeg, size_t* rhoN, size_t* T);
 /* Geometry helper: the grid of image tiles (nx x ny) and the rho-window rows per tile a plan of `frames` W x H frames votes with
  * (acc_gather, houghsht.cxx:350-481, runs as one workgroup per frame, tile and 64 theta bins).  Host arithmetic only: what
  * compvhip_plan_create would choose, for tests and capacity planning.  COMPVHIP_E_NOT_IMPLEMENTED when no grid fits. */

@@ -164,7 +164,8 @@ int main(int argc, char** argv)
 	}
 	int visible = compvhip_device_count();
 	if (visible <= 0) { fprintf(stderr, "no HIP device\n"); return 2; }
-	if (nDev <= 0 || nDev > visible) nDev = visible;
+	if (nDev > visible) { fprintf(stderr, "multi_gpu_batch: --devices %d but only %d HIP device(s) are visible (a missing peer is an error, not a smaller run)\n", nDev, visible); return 3; }
+	if (nDev <= 0) nDev = visible;
 	const int R = virt > 0 ? virt : nDev;
 	const bool useRccl = virt <= 0;
 	if (F <= 0 || steps <= 0 || W < 3 || H < 3 || (W & 7)) { fprintf(stderr, "bad geometry (W %% 8 == 0: the plan's stride is the width here)\n"); return 1; }

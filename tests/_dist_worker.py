@@ -53,11 +53,12 @@ def main():
     g_counts, g_lines = sharding.gather_lines(dist, my_counts, my_lines)
     ok = torch.tensor([1 if scatter_ok else 0], dtype=torch.int32)
     dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    seen = sharding.ranks_seen(dist)          # what bench.py puts into its line as n_ranks_seen / ranks_seen
     if rank == 0:
         with open(out_path, "w") as f:
             json.dump({"world": world, "counts": allc, "tmax": tmax, "elapsed_rank0": elapsed, "scatter_ok_all_ranks": int(ok.item()),
                        "gathered_counts": g_counts.tolist(), "gathered_lines_shape": list(g_lines.shape),
-                       "gathered_lines_first": [int(g_lines[r * F, 0, 0]) for r in range(world)]}, f)
+                       "gathered_lines_first": [int(g_lines[r * F, 0, 0]) for r in range(world)], "ranks_seen": seen}, f)
     dist.destroy_process_group()
 
 

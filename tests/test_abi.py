@@ -33,6 +33,10 @@ def test_dims_helper_matches_reference_geometry():
     assert lib.compvhip_houghsht_dims(1920, 1080, 1.0, ctypes.byref(R), ctypes.byref(T), ctypes.byref(st)) == 0
     assert (R.value, T.value) == (6001, 180)          # R = 2(W+H)+1, T = round(pi/theta)
     assert lib.compvhip_houghsht_dims(640, 480, 0.0, ctypes.byref(R), ctypes.byref(T), ctypes.byref(st)) == capi.E_INVALID_PARAMETER
+    # KHT vote map (initCoords, houghkht.cxx:501-541): rhoN = (sqrt(W^2 + H^2) + 1) / rho, T = 180 / theta
+    assert capi.houghkht_dims(3840, 2160, 1.0, 1.0) == (180, 4406)
+    with pytest.raises(capi.CompvHipError):
+        capi.houghkht_dims(3840, 2160, 2.0, 1.0)      # rho must be in (0, 1]
 
 
 def test_vote_grid_helper():

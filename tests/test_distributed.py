@@ -45,3 +45,40 @@ def test_two_ranks_gloo(tmp_path, oracle):
     assert res["scatter_ok_all_ranks"] == 1
     assert res["gathered_counts"] == [0, 1, 2, 1000, 1001, 1002]
     assert res["gathered_lines_shape"] == [6, 4, 5] and res["gathered_lines_first"] == [0, 100000]
+    assert res["ranks_seen"] == [0, 1]
+
+
+def test_block_rotation_of_a_world_of_eight_covers_config_4():
+    """bench.py --gpus 8 without a node: the rank arithmetic of the driver's scaling run.  Rank r runs resident block (r + k) mod 8 at step k
+    (sharding.block_of_step); the blocks hold config 4's 256 distinct frames (sharding.block_seeds); every rank verifies all 8 of its resident
+    blocks after the timed region (bench.py's verification loop runs over range(NB) on every rank)."""
+    from compv_amd import sharding
+    world, F, NB = 8, 32, 8
+    seeds = sharding.block_seeds(F, NB, 256)
+    flat = [s for b in seeds for s in b]
+    assert sorted(flat) == list(range(sharding.BASE_SEED, sharding.BASE_SEED + 256))           # 256 distinct frames, the fixture's seeds
+    golden = json.load(open(os.path.join(ROOT, "tests", "golden", "golden_batch.json")))
+    assert {g["seed"] for g in golden["frames"]} == set(flat)                                  # every one of them has a reference-derived record
+    for k in range(3 * NB):
+        blocks = [sharding.block_of_step(r, k, NB) for r in range(world)]
+        assert sorted(blocks) == list(range(NB))                                               # one step of the job = all 256 frames, each exactly once
+    for r in range(world):
+        mine = [sharding.block_of_step(r, k, NB) for k in range(NB)]
+        assert sorted(mine) == list(range(NB))                                                 # a rank meets every block within 8 steps
+        assert all(mine[k] != mine[k + 1] for k in range(NB - 1))                              # and never re-reads the block it has just processed
+    # fewer ranks than blocks (1, 2, 4 GPUs): the ranks' blocks of a step are still pairwise different
+    for w in (1, 2, 4):
+        for k in range(NB):
+            bl = [sharding.block_of_step(r, k, NB) for r in range(w)]
+            assert len(set(bl)) == w
+    # the verification loop of bench.py: lanes take blocks b0, b0 + 1 in turn until all NB are checked -- on EVERY rank
+    lanes = 2
+    checked = []
+    for b0 in range(0, NB, lanes):
+        checked += [b0 + i for i in range(lanes) if b0 + i < NB]
+    assert checked == list(range(NB))
+
+
+def test_ranks_seen_single_process():
+    from compv_amd import sharding
+    assert sharding.ranks_seen(None) == [0]

@@ -105,3 +105,14 @@ def test_cxx_multi_gpu_batch_driver(mode):
     ranks = 2 if mode[0] == "--virtual" else 1
     assert res["ranks"] == ranks and res["frames_checked"] == 3 * ranks and res["Mpixels_per_s"] > 0
     assert ("rccl" in res["transport"]) == (mode[0] == "--devices")
+
+
+@pytest.mark.gpu
+def test_cxx_multi_gpu_batch_driver_refuses_missing_peers():
+    """The first N > 1 run of the C++ driver will be unattended: asking for more devices than the node shows is a clear non-zero exit, not a
+    silently smaller run."""
+    import torch
+    assert os.path.exists(MGB), "integration/_build/multi_gpu_batch is missing: run integration/build.sh"
+    want = torch.cuda.device_count() + 1
+    r = subprocess.run([MGB, "--devices", str(want), "--frames-per-device", "1", "--steps", "1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode == 3 and ("only %d HIP device" % (want - 1)) in r.stderr, (r.returncode, r.stderr[-500:])
