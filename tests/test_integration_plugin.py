@@ -40,6 +40,7 @@ def test_bench_under_torchrun_nccl_single_rank(tmp_path):
     res = json.loads(line)
     assert res["dist_backend"] == "nccl" and res["n_gpus"] == 1 and res["value"] > 0
     assert res["lines_last_step_all_ranks"] is not None and res["lines_frame0"] > 0
+    assert res["n_ranks_seen"] == 1 and res["ranks_seen"] == [0] and res["rccl_version"]      # what a SCALE record is checked against
 
 
 def _two_rank_scatter_run(backend, port):
@@ -82,7 +83,7 @@ def test_bench_two_ranks_on_one_gpu_gloo_host_staged(tmp_path):
     under the N > 1 logic whatever the RCCL build allows on one device."""
     r, res = _two_rank_scatter_run("gloo", 29619)
     assert r.returncode == 0, r.stderr[-3000:]
-    assert res["dist_backend"] == "gloo"
+    assert res["dist_backend"] == "gloo" and res["ranks_seen"] == [0, 1]
     assert res["n_gpus"] == 2 and res["value"] > 0 and "scattered from rank 0 over gloo" in res["config"]["parallelism"]
     assert res["lines_last_step_all_ranks"] is not None and res["lines_frame0"] > 0
 
