@@ -858,7 +858,9 @@ def kht_figure(capi, ctx, torch, lane, blocks, W, H, F):
             "cpu_baseline": cpu,
             "host_threads": stages.get("threads"),
             "host_share": stages.get("host_share"), "stages_ms_per_frame": stages.get("stages"),
-            "note": "compvhip_plan_houghkht on the device edge maps of one batch: one download, host linking on a thread pool pipelined with the GPU stages (subdivision, statistics, voting, peaks) of the previous frames"}
+            "note": "compvhip_plan_houghkht on the device edge maps of one batch: groups of 8 frames, host stages (linking, prune, sort + sweep) as parallel loops over a group's frames, "
+                    "every GPU stage (subdivision, statistics, voting, peaks) ONE launch per group, up to 4 groups in flight; stages_ms_per_frame: host stages = thread time per frame, "
+                    "GPU stages = wall time of the group's stage / its frames"}
 
 
 if __name__ == "__main__":

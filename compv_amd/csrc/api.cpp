@@ -11,6 +11,9 @@
 
 #include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <thread>
 
 #include <hip/hip_runtime.h>
@@ -49,14 +52,39 @@ struct KhtScratch {
 	uint32_t* counts32 = nullptr;
 	KhtSpan* scratch = nullptr;
 	KhtSubdivFrame* stack = nullptr;
-	uint32_t* dBits = nullptr; size_t dBitsWords = 0;          // plan workers: the frame's edge map as bit-mask rows (bytes_to_bits_kernel), device
-	uint32_t* hostBits = nullptr; size_t hostBitsWords = 0;    // ... and its pinned host copy: 1/8 of the edge map's bytes cross PCIe
 	KhtBitPlane plane;                                         // the linker's working copy (zero border, destroyed by the walk)
 	KhtPoint* linked = nullptr; size_t linkedCap = 0;         // points of the strings, string after string: PINNED host memory, written by the linker, uploaded without staging
 	KhtPeaksWork peaks;                                        // sort records, visited map, axes of the peak stage
 	std::vector<KhtCell> cellsHost;                            // the vote cells of the frame, downloaded
-	double stageMs[6] = {};   // link, subdivide (GPU), statistics (GPU), prune + Gmin, vote + peaks (GPU), sort + sweep: last frame (ctx) / sums (plan worker)
+	double stageMs[6] = {};   // link, subdivide (GPU), statistics (GPU), prune + Gmin, vote + peaks (GPU), sort + sweep of the last call
 	std::string err;
+};
+
+struct KhtBatchFrame {      // host state of one frame of the batch; persists from call to call (vectors keep their capacity)
+	KhtBitPlane plane; size_t most = 0, ptsOff = 0, nPts = 0;
+	std::vector<KhtRange> strings; size_t slotBase = 0, slots = 0;
+	uint32_t nClusters = 0;
+	std::vector<KhtKernel> kernels; double hmax = 0.0, GS = 1.0; bool haveGS = false;
+	std::vector<KhtVoteParams> params; size_t paramsBase = 0;
+	std::vector<KhtCell> cells; size_t cellOff = 0; int cellCount = 0;
+	KhtPeaksWork peaks; std::vector<KhtLine> out;
+	double ms[6] = {};
+	int code = COMPVHIP_OK; std::string err;
+};
+struct KhtBatchState {
+	hipStream_t stream = nullptr;
+	uint32_t* dBits = nullptr; uint32_t* hostBits = nullptr; size_t bitsWords = 0;      // [frames of a group][wpr * H]: device / pinned
+	std::vector<hipEvent_t> ready;                                                     // frame f's bit plane has arrived
+	KhtPoint* linked = nullptr; size_t linkedCap = 0; KhtPoint* pts = nullptr; size_t ptsCap = 0;   // points of every frame's strings: pinned arena (the linkers write it) / device
+	KhtStringDesc* strings = nullptr; uint32_t* counts32 = nullptr; size_t stringsCap = 0; KhtStringDesc* stringsHost = nullptr; size_t stringsHostCap = 0;
+	uint32_t* totals = nullptr;                                                        // device [kKhtBatch + 1]: clusters per frame, truncation flag
+	KhtSpan* spans = nullptr; KhtSpan* scratch = nullptr; KhtSubdivFrame* stack = nullptr; KhtKernel* kernelsDev = nullptr; size_t spansCap = 0;
+	KhtKernel* kernelsHost = nullptr; size_t kernelsHostCap = 0;                       // pinned
+	int32_t* counts = nullptr; size_t countsElems = 0;
+	KhtVoteParams* params = nullptr; size_t paramsCap = 0; KhtVoteParams* paramsHost = nullptr; size_t paramsHostCap = 0;
+	KhtCell* cells = nullptr; size_t cellsCap = 0; int* cellCount = nullptr; KhtCell* cellsHost = nullptr; size_t cellsHostCap = 0;
+	std::vector<KhtBatchFrame> frames;
+	double stageMs[6] = {};   // of the groups this state handled in the current call
 };
 
 struct compvhip_ctx {
@@ -135,7 +163,7 @@ struct compvhip_plan {
 	std::vector<int32_t> vtKt, vtRowBase;        // host copies of the [tiles][T] tables
 	int32_t* dKt = nullptr; int32_t* dRowBase = nullptr; uint8_t* partLo = nullptr; uint8_t* partHi = nullptr; uint8_t* colFlag = nullptr; int* tileCounts = nullptr;
 	// batched KHT (compvhip_plan_houghkht): one scratch set + stream per worker thread, stage clocks of the last call
-	std::vector<KhtScratch*> khtWorkers;
+	std::vector<KhtBatchState*> khtBatch;        // device / pinned buffers and per-frame host state of the batched call: one per group of frames in flight
 	double khtStageMs[6] = {}; double khtWallMs = 0.0; int khtThreads = 0;
 	// asynchronous steps (compvhip_plan_pipeline_async / compvhip_plan_wait)
 	// seq: enqueue order; replay: an EARLIER step of the plan was replayed after this one ran -- its outputs may have been overwritten
@@ -183,11 +211,27 @@ void khtScratchFree(compvhip_ctx* ctx, KhtScratch& k)
 	dfree(ctx, k.counts); dfree(ctx, k.params); dfree(ctx, k.cells); dfree(ctx, k.cellCount);
 	dfree(ctx, k.pts); dfree(ctx, k.spans); dfree(ctx, k.kernelsDev);
 	dfree(ctx, k.strings); dfree(ctx, k.counts32); dfree(ctx, k.scratch); dfree(ctx, k.stack);
-	dfree(ctx, k.dBits); k.dBitsWords = 0;
-	if (k.hostBits) { (void)hipHostFree(k.hostBits); k.hostBits = nullptr; k.hostBitsWords = 0; }
 	if (k.linked) { (void)hipHostFree(k.linked); k.linked = nullptr; k.linkedCap = 0; }
 	if (k.ownStream && k.stream) { (void)hipStreamDestroy(k.stream); k.stream = nullptr; }
 }
+
+void khtBatchFree(compvhip_ctx* ctx, KhtBatchState* b)
+{
+	if (!b) return;
+	dfree(ctx, b->dBits); dfree(ctx, b->pts); dfree(ctx, b->strings); dfree(ctx, b->counts32); dfree(ctx, b->totals);
+	dfree(ctx, b->spans); dfree(ctx, b->scratch); dfree(ctx, b->stack); dfree(ctx, b->kernelsDev);
+	dfree(ctx, b->counts); dfree(ctx, b->params); dfree(ctx, b->cells); dfree(ctx, b->cellCount);
+	if (b->hostBits) (void)hipHostFree(b->hostBits);
+	if (b->linked) (void)hipHostFree(b->linked);
+	if (b->stringsHost) (void)hipHostFree(b->stringsHost);
+	if (b->kernelsHost) (void)hipHostFree(b->kernelsHost);
+	if (b->paramsHost) (void)hipHostFree(b->paramsHost);
+	if (b->cellsHost) (void)hipHostFree(b->cellsHost);
+	for (hipEvent_t e : b->ready) (void)hipEventDestroy(e);
+	if (b->stream) (void)hipStreamDestroy(b->stream);
+	delete b;
+}
+
 
 // ---- thresholds: core/features/edges/compv_core_feature_canny_dete.cxx:251-266 (COMPARE_TO_GRADIENT branch) ----
 // cosf / sinf exactly as the reference's scalar calls resolve them (never merged into sincosf)
@@ -638,6 +682,85 @@ int validateCannyParams(compvhip_ctx* ctx, float tLow, float tHigh, int ksize, i
 } // namespace
 
 // ==================================================================================================================
+namespace {
+// helper threads of ONE call: run(n, fn) executes fn(0) .. fn(n - 1), the frames handed out one at a time, the caller working along
+class KhtPool {
+public:
+	explicit KhtPool(size_t threads)
+	{
+		try { for (size_t t = 1; t < threads; ++t) pool_.emplace_back([this] { loop(); }); }
+		catch (...) { /* the system refused another thread: the ones that started (and the caller) share the work */ }
+	}
+	~KhtPool()
+	{
+		{ std::lock_guard<std::mutex> g(m_); quit_ = true; ++gen_; }
+		cv_.notify_all();
+		for (std::thread& t : pool_) t.join();
+	}
+	void run(size_t n, const std::function<void(size_t)>& fn)
+	{
+		if (!n) return;
+		{ std::lock_guard<std::mutex> g(m_); fn_ = &fn; n_ = n; next_.store(0); left_.store(n); ++gen_; }
+		cv_.notify_all();
+		work();
+		std::unique_lock<std::mutex> lk(m_);
+		done_.wait(lk, [this] { return left_.load() == 0; });
+		fn_ = nullptr;
+	}
+private:
+	void work()
+	{
+		for (;;) {
+			const size_t i = next_.fetch_add(1);
+			if (i >= n_) return;
+			(*fn_)(i);
+			if (left_.fetch_sub(1) == 1) { std::lock_guard<std::mutex> g(m_); done_.notify_all(); }
+		}
+	}
+	void loop()
+	{
+		unsigned long seen = 0;
+		for (;;) {
+			{
+				std::unique_lock<std::mutex> lk(m_);
+				cv_.wait(lk, [&] { return gen_ != seen; });
+				seen = gen_;
+				if (quit_) return;
+			}
+			work();
+		}
+	}
+	std::vector<std::thread> pool_;
+	std::mutex m_; std::condition_variable cv_, done_;
+	const std::function<void(size_t)>* fn_ = nullptr; size_t n_ = 0;
+	std::atomic<size_t> next_{0}, left_{0};
+	unsigned long gen_ = 0; bool quit_ = false;
+};
+
+template <typename T>
+hipError_t growPinned(T*& ptr, size_t& cap, size_t want)
+{
+	if (cap >= want) return hipSuccess;
+	if (ptr) (void)hipHostFree(ptr);
+	ptr = nullptr; cap = 0;
+	const size_t n = want + want / 4 + 1024;   // (frames of a stream resemble each other: no reallocation for a slightly denser batch)
+	const hipError_t e = hipHostMalloc(reinterpret_cast<void**>(&ptr), n * sizeof(T));
+	if (e == hipSuccess) cap = n;
+	return e;
+}
+template <typename T>
+hipError_t growDevice(compvhip_ctx* ctx, T*& ptr, size_t& cap, size_t want)
+{
+	if (cap >= want) return hipSuccess;
+	dfree(ctx, ptr); cap = 0;
+	const size_t n = want + want / 4 + 1024;
+	const hipError_t e = dmalloc(ctx, &ptr, n);
+	if (e == hipSuccess) cap = n;
+	return e;
+}
+} // namespace
+
+
 extern "C" {
 
 int compvhip_device_count(void)
@@ -805,8 +928,8 @@ void compvhip_plan_destroy(compvhip_plan* p)
 	dfree(ctx, p->ebits); dfree(ctx, p->ubits); dfree(ctx, p->counters); dfree(ctx, p->thrDev); dfree(ctx, p->sums); dfree(ctx, p->tmpOut);
 	if (p->hFlags) (void)hipHostFree(p->hFlags);
 	dfree(ctx, p->hist); dfree(ctx, p->otsu); dfree(ctx, p->blurTmp); dfree(ctx, p->grayTmp);
-	for (KhtScratch* k : p->khtWorkers) { khtScratchFree(ctx, *k); delete k; }
-	p->khtWorkers.clear();
+	for (KhtBatchState* b : p->khtBatch) khtBatchFree(ctx, b);
+	p->khtBatch.clear();
 	dfree(ctx, p->cosT); dfree(ctx, p->invSinT);
 	dfree(ctx, p->dKt); dfree(ctx, p->dRowBase); dfree(ctx, p->partLo); dfree(ctx, p->partHi); dfree(ctx, p->colFlag);
 	dfree(ctx, p->sinQ); dfree(ctx, p->cosQ); dfree(ctx, p->edges); dfree(ctx, p->acc);
@@ -1566,6 +1689,13 @@ int compvhip_houghsht_u8(compvhip_ctx* ctx, const uint8_t* edges, size_t W, size
 // several of these at the same time on worker threads, so nothing below touches ctx->err or any other shared state (ctx->live is atomic).
 #define KCHK(K, call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { (K).err = std::string(#call) + ": " + hipGetErrorString(e__); return COMPVHIP_E_HIP; } } while (0)
 
+// the reference's AVX (4) / SSE2 (2) kernel-height loops take n & ~(pack - 1) clusters of a frame; the rest go through the C code (other operation order)
+static int khtSimdEnd(size_t n)
+{
+	const size_t pack = n >= 4 ? 4 : (n >= 2 ? 2 : 1);
+	return static_cast<int>(pack > 1 ? (n & ~(pack - 1)) : 0);
+}
+
 // host linking (on K.plane, which it destroys), then cluster subdivision (kht_subdivide_kernel) and per-cluster statistics (kht_stats_kernel) on the GPU; kernels in cluster order
 static int khtBuildKernels(compvhip_ctx* ctx, KhtScratch& K, size_t W, size_t H, double clusterMinDeviation, size_t clusterMinSize,
                            std::vector<KhtKernel>& kernels, double& hmax)
@@ -1615,9 +1745,11 @@ static int khtBuildKernels(compvhip_ctx* ctx, KhtScratch& K, size_t W, size_t H,
 	KhtSubdivArgs sv;
 	sv.pts = K.pts; sv.strings = K.strings; sv.nStrings = static_cast<int>(descs.size());
 	sv.minSize = static_cast<int>(std::min<size_t>(clusterMinSize, 0x7fffffff)); sv.minDev = clusterMinDeviation;
-	sv.scratch = K.scratch; sv.stack = K.stack; sv.counts = K.counts32; sv.clusters = K.spans; sv.total = K.counts32 + descs.size();
+	sv.scratch = K.scratch; sv.stack = K.stack; sv.counts = K.counts32; sv.clusters = K.spans; sv.total = K.counts32 + descs.size(); sv.flagIndex = 1;
 	KCHK(K, hipMemsetAsync(sv.total, 0, 2 * sizeof(uint32_t), st));   // [0] cluster total, [1] "recursion truncated" flag
-	KCHK(K, launch_kht_subdivide(sv, st));
+	KhtBatchStrings one{};   // a batch of one frame
+	one.frames = 1; one.stringBegin[0] = 0; one.stringBegin[1] = static_cast<uint32_t>(descs.size()); one.clusterBase[0] = 0;
+	KCHK(K, launch_kht_subdivide(sv, one, st));
 	uint32_t tot[2] = { 0, 0 };
 	KCHK(K, hipMemcpyAsync(tot, sv.total, sizeof(tot), hipMemcpyDeviceToHost, st));
 	KCHK(K, hipStreamSynchronize(st));
@@ -1628,12 +1760,12 @@ static int khtBuildKernels(compvhip_ctx* ctx, KhtScratch& K, size_t W, size_t H,
 	if (!nClusters) return COMPVHIP_OK;
 	const size_t n = nClusters;
 	KhtStatsArgs sa;
-	sa.pts = K.pts; sa.clusters = K.spans; sa.n = static_cast<int>(n);
-	const size_t pack = n >= 4 ? 4 : (n >= 2 ? 2 : 1); // the reference's AVX (4) / SSE2 (2) kernel-height loops take n & ~(pack - 1) clusters
-	sa.simdEnd = static_cast<int>(pack > 1 ? (n & ~(pack - 1)) : 0);
+	sa.pts = K.pts; sa.clusters = K.spans;
 	sa.hw = static_cast<double>(W) * 0.5; sa.hh = static_cast<double>(H) * 0.5;
 	sa.out = K.kernelsDev;
-	KCHK(K, launch_kht_stats(sa, st));
+	KhtBatchStats ones{};
+	ones.frames = 1; ones.clusterBase[0] = 0; ones.n[0] = static_cast<int>(n); ones.simdEnd[0] = khtSimdEnd(n);
+	KCHK(K, launch_kht_stats(sa, ones, st));
 	kernels.resize(n);
 	KCHK(K, hipMemcpyAsync(kernels.data(), K.kernelsDev, n * sizeof(KhtKernel), hipMemcpyDeviceToHost, st));
 	KCHK(K, hipStreamSynchronize(st));
@@ -1681,8 +1813,10 @@ static int khtFrame(compvhip_ctx* ctx, KhtScratch& K, size_t W, size_t H, const 
 	a.params = K.params; a.nKernels = static_cast<int>(params.size()); a.counts = K.counts; a.stride = stride;
 	a.rhoN = static_cast<int>(ax.rhoN); a.T = static_cast<int>(ax.T); a.dRho = ax.dRho; a.dThetaDeg = ax.dThetaDeg; a.gs = GS;
 	a.threshold = threshold; a.cells = K.cells; a.cellCount = K.cellCount; a.cellCap = static_cast<int>(cellCap);
-	KCHK(K, launch_kht_vote(a, st));
-	KCHK(K, launch_kht_peaks(a, st));
+	KhtBatchVote onev{};
+	onev.frames = 1; onev.paramsBase[0] = 0; onev.nKernels[0] = a.nKernels; onev.gs[0] = GS; onev.mapElems = countsElems; onev.cellCap = cellCap;
+	KCHK(K, launch_kht_vote(a, onev, st));
+	KCHK(K, launch_kht_peaks(a, onev, st));
 	int cellCount = 0;
 	KCHK(K, hipMemcpyAsync(&cellCount, K.cellCount, sizeof(int), hipMemcpyDeviceToHost, st));
 	KCHK(K, hipStreamSynchronize(st));
@@ -1808,6 +1942,232 @@ int compvhip_houghkht_u8(compvhip_ctx* ctx, const uint8_t* edges, size_t W, size
 // buffers.  A worker downloads its frame (pinned buffer, asynchronous copy on its stream), links it, and drives the GPU stages of that
 // frame (subdivision, statistics, voting, peaks); while one worker links, the kernels and copies of the others run, so the GPU work
 // and the PCIe transfers of the batch hide under the host stage that bounds it.
+// ---- batched KHT (compvhip_plan_houghkht) ------------------------------------------------------------------------------------------------------
+// The frames of a batch go through the stages TOGETHER: the host stages (bit-plane linking, prune / Gmin, sort + sweep: sequential per frame, independent
+// between frames) run as parallel loops over the frames on a pool of host threads, the GPU stages are ONE launch each over the strings / clusters /
+// kernels / vote maps of all frames (kht.hpp: the per-frame tables travel in the kernel arguments), with one upload and one download per stage.
+// (Rounds 3-4 gave every worker thread its own stream and let it drive its frame's five small launches and four synchronisations: with 32 workers the
+// GPU-touching stages took 5-9 x their single-frame time -- a launch / synchronisation pile-up, not compute.)
+// one group of up to kKhtBatch frames
+static int khtBatchGroup(compvhip_plan* p, KhtBatchState& B, KhtPool& pool, const uint8_t* d_edges, size_t G, const KhtAxes& ax, int threshold, int maxLines,
+                         double clusterMinDeviation, size_t clusterMinSize, double kernelMinHeight, compvhip_line* lines, size_t cap, size_t* counts, double* gs, bool* overflow,
+                         std::string& err)
+{
+	using clk = std::chrono::steady_clock;
+	auto msSince = [](clk::time_point a) { return std::chrono::duration<double, std::milli>(clk::now() - a).count(); };
+	compvhip_ctx* ctx = p->ctx;
+	const size_t W = p->W, H = p->H, S = p->S;
+	const size_t wpr = (W + 31) / 32, words = wpr * H;
+	hipStream_t st = B.stream;
+	// (several groups run at the same time, each on its own controller thread: errors travel back as (code, text), only the caller touches ctx->err)
+#define BCHK(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { err = std::string(#call) + ": " + hipGetErrorString(e__); return COMPVHIP_E_HIP; } } while (0)
+	auto firstError = [&]() -> int {
+		for (size_t f = 0; f < G; ++f)
+			if (B.frames[f].code) { err = "frame " + std::to_string(f) + " of its group: " + B.frames[f].err; return B.frames[f].code; }
+		return COMPVHIP_OK;
+	};
+	if (hipSetDevice(ctx->device) != hipSuccess) { err = "hipSetDevice"; return COMPVHIP_E_HIP; }
+	auto guarded = [&](size_t f, const std::function<void(KhtBatchFrame&)>& body) {   // nothing may leave a pool thread (or an extern "C" entry point) as an exception
+		KhtBatchFrame& fr = B.frames[f];
+		if (fr.code) return;
+		try { body(fr); }
+		catch (const std::exception& ex) { fr.code = COMPVHIP_E_OUT_OF_MEMORY; fr.err = std::string("exception in a KHT stage: ") + ex.what(); }
+		catch (...) { fr.code = COMPVHIP_E_OUT_OF_MEMORY; fr.err = "exception in a KHT stage"; }
+	};
+	for (size_t f = 0; f < G; ++f) {
+		KhtBatchFrame& fr = B.frames[f];
+		fr.code = COMPVHIP_OK; fr.err.clear(); fr.nClusters = 0; fr.kernels.clear(); fr.params.clear(); fr.cells.clear(); fr.cellCount = 0; fr.out.clear(); fr.haveGS = false;
+		memset(fr.ms, 0, sizeof(fr.ms));
+	}
+
+	// ---- A. the edge maps leave the device as bit-mask rows (1/8 of the bytes over PCIe; the linker works on bits anyway): one kernel, one copy per frame ----
+	BCHK(launch_bytes_to_bits(d_edges, static_cast<int>(W), static_cast<int>(H), static_cast<int>(S), S * H, B.dBits, static_cast<int>(wpr), words, static_cast<int>(G), st));
+	for (size_t f = 0; f < G; ++f) {
+		BCHK(hipMemcpyAsync(B.hostBits + f * words, B.dBits + f * words, words * sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+		BCHK(hipEventRecord(B.ready[f], st));
+	}
+	pool.run(G, [&](size_t f) { guarded(f, [&](KhtBatchFrame& fr) {
+		const auto t0 = clk::now();
+		if (hipSetDevice(ctx->device) != hipSuccess || hipEventSynchronize(B.ready[f]) != hipSuccess) { fr.code = COMPVHIP_E_HIP; fr.err = "frame download"; return; }
+		khtPlaneFromWords(B.hostBits + f * words, wpr, W, H, fr.plane);
+		fr.most = khtPlaneCount(fr.plane);
+		fr.ms[0] += msSince(t0);
+	}); });
+	int rc = firstError();
+	if (rc) return rc;
+	size_t total = 0;
+	for (size_t f = 0; f < G; ++f) { B.frames[f].ptsOff = total; total += B.frames[f].most; }
+	if (total > 0x7fffffffull) { err = "too many edge pixels in the batch"; return COMPVHIP_E_INVALID_PARAMETER; }
+	BCHK(growPinned(B.linked, B.linkedCap, total + 1));
+	// ---- B. linking (Appendix A): sequential inside a frame, the frames in parallel; every frame's points go straight into its slice of the pinned arena ----
+	pool.run(G, [&](size_t f) { guarded(f, [&](KhtBatchFrame& fr) {
+		const auto t0 = clk::now();
+		fr.nPts = khtLink(fr.plane, clusterMinSize, B.linked + fr.ptsOff, fr.strings);
+		fr.ms[0] += msSince(t0);
+	}); });
+	rc = firstError();
+	if (rc) return rc;
+
+	// ---- C. cluster subdivision of ALL strings: one upload per frame slice, one launch, one download ----
+	auto tc = clk::now();
+	size_t nStrings = 0, slots = 0;
+	for (size_t f = 0; f < G; ++f) nStrings += B.frames[f].strings.size();
+	KhtBatchStrings tabS{};
+	tabS.frames = static_cast<int>(G);
+	if (nStrings) {
+		BCHK(growPinned(B.stringsHost, B.stringsHostCap, nStrings));
+		size_t si = 0;
+		for (size_t f = 0; f < G; ++f) {
+			KhtBatchFrame& fr = B.frames[f];
+			tabS.stringBegin[f] = static_cast<uint32_t>(si); tabS.clusterBase[f] = static_cast<uint32_t>(slots);
+			fr.slotBase = slots;
+			for (const KhtRange& r : fr.strings) {
+				KhtStringDesc& d = B.stringsHost[si++];
+				d.begin = static_cast<uint32_t>(fr.ptsOff + r.begin); d.end = static_cast<uint32_t>(fr.ptsOff + r.end); d.slot = static_cast<uint32_t>(slots);
+				slots += khtSubdivSlots(r.end - r.begin, clusterMinSize);
+			}
+			fr.slots = slots - fr.slotBase;
+		}
+		for (size_t f = G; f <= static_cast<size_t>(kKhtBatch); ++f) tabS.stringBegin[f] = static_cast<uint32_t>(nStrings);
+		tabS.stringBegin[G] = static_cast<uint32_t>(nStrings);
+		if (slots > 0xffffffffull) { err = "too many cluster slots in the batch"; return COMPVHIP_E_INVALID_PARAMETER; }
+		BCHK(growDevice(ctx, B.pts, B.ptsCap, total + 1));
+		if (B.stringsCap < nStrings) {
+			dfree(ctx, B.strings); dfree(ctx, B.counts32); B.stringsCap = 0;
+			const size_t n = nStrings + nStrings / 4 + 1024;
+			BCHK(dmalloc(ctx, &B.strings, n)); BCHK(dmalloc(ctx, &B.counts32, n)); B.stringsCap = n;
+		}
+		if (B.spansCap < slots) {
+			dfree(ctx, B.spans); dfree(ctx, B.scratch); dfree(ctx, B.stack); dfree(ctx, B.kernelsDev); B.spansCap = 0;
+			const size_t n = slots + slots / 4 + 1024;
+			BCHK(dmalloc(ctx, &B.spans, n)); BCHK(dmalloc(ctx, &B.scratch, n)); BCHK(dmalloc(ctx, &B.stack, n)); BCHK(dmalloc(ctx, &B.kernelsDev, n)); B.spansCap = n;
+		}
+		BCHK(growPinned(B.kernelsHost, B.kernelsHostCap, slots));
+		for (size_t f = 0; f < G; ++f) {
+			const KhtBatchFrame& fr = B.frames[f];
+			if (fr.nPts) BCHK(hipMemcpyAsync(B.pts + fr.ptsOff, B.linked + fr.ptsOff, fr.nPts * sizeof(KhtPoint), hipMemcpyHostToDevice, st));
+		}
+		BCHK(hipMemcpyAsync(B.strings, B.stringsHost, nStrings * sizeof(KhtStringDesc), hipMemcpyHostToDevice, st));
+		KhtSubdivArgs sv;
+		sv.pts = B.pts; sv.strings = B.strings; sv.nStrings = static_cast<int>(nStrings);
+		sv.minSize = static_cast<int>(std::min<size_t>(clusterMinSize, 0x7fffffff)); sv.minDev = clusterMinDeviation;
+		sv.scratch = B.scratch; sv.stack = B.stack; sv.counts = B.counts32; sv.clusters = B.spans; sv.total = B.totals; sv.flagIndex = kKhtBatch;
+		BCHK(hipMemsetAsync(B.totals, 0, (kKhtBatch + 1) * sizeof(uint32_t), st));
+		BCHK(launch_kht_subdivide(sv, tabS, st));
+		uint32_t tot[kKhtBatch + 1];
+		BCHK(hipMemcpyAsync(tot, B.totals, sizeof(tot), hipMemcpyDeviceToHost, st));
+		BCHK(hipStreamSynchronize(st));
+		if (tot[kKhtBatch]) { err = "cluster subdivision ran out of recursion slots"; return COMPVHIP_E_INVALID_STATE; }   // cannot happen: clusterMinSize >= 2 is enforced and khtSubdivSlots bounds the depth for it
+		for (size_t f = 0; f < G; ++f) B.frames[f].nClusters = B.frames[f].strings.empty() ? 0u : tot[f];
+	}
+	B.stageMs[1] += msSince(tc);
+
+	// ---- D. per-cluster statistics of ALL clusters: one launch, one download per frame slice; acos / hmax, prune, Gmin and the vote parameters on the pool ----
+	tc = clk::now();
+	{
+		KhtBatchStats tab{};
+		tab.frames = static_cast<int>(G);
+		bool any = false;
+		for (size_t f = 0; f < G; ++f) {
+			const KhtBatchFrame& fr = B.frames[f];
+			tab.clusterBase[f] = static_cast<uint32_t>(fr.slotBase); tab.n[f] = static_cast<int>(fr.nClusters); tab.simdEnd[f] = khtSimdEnd(fr.nClusters);
+			any = any || fr.nClusters;
+		}
+		if (any) {
+			KhtStatsArgs sa;
+			sa.pts = B.pts; sa.clusters = B.spans; sa.hw = static_cast<double>(W) * 0.5; sa.hh = static_cast<double>(H) * 0.5; sa.out = B.kernelsDev;
+			BCHK(launch_kht_stats(sa, tab, st));
+			for (size_t f = 0; f < G; ++f) {
+				const KhtBatchFrame& fr = B.frames[f];
+				if (fr.nClusters) BCHK(hipMemcpyAsync(B.kernelsHost + fr.slotBase, B.kernelsDev + fr.slotBase, fr.nClusters * sizeof(KhtKernel), hipMemcpyDeviceToHost, st));
+			}
+			BCHK(hipStreamSynchronize(st));
+		}
+	}
+	B.stageMs[2] += msSince(tc);
+	pool.run(G, [&](size_t f) { guarded(f, [&](KhtBatchFrame& fr) {
+		if (!fr.nClusters) return;
+		auto t0 = clk::now();
+		fr.kernels.assign(B.kernelsHost + fr.slotBase, B.kernelsHost + fr.slotBase + fr.nClusters);
+		khtFinishKernels(fr.kernels, fr.hmax);
+		fr.ms[2] += msSince(t0);
+		t0 = clk::now();
+		fr.GS = khtPruneAndScale(fr.kernels, fr.hmax, kernelMinHeight);
+		if (!fr.kernels.empty()) { fr.haveGS = true; khtVoteParams(ax, fr.kernels, fr.params); }
+		fr.ms[3] += msSince(t0);
+	}); });
+	rc = firstError();
+	if (rc) return rc;
+
+	// ---- E. Gaussian voting + smoothing / threshold of ALL frames' vote maps: one launch each, the cell counts, then the cells ----
+	tc = clk::now();
+	const int stride = static_cast<int>(alignUp(ax.rhoN + 2, 16));
+	const size_t mapElems = (ax.T + 2) * static_cast<size_t>(stride), cellCap = ax.T * ax.rhoN;
+	KhtBatchVote tabV{};
+	tabV.frames = static_cast<int>(G); tabV.mapElems = mapElems; tabV.cellCap = cellCap;
+	size_t nParams = 0;
+	for (size_t f = 0; f < G; ++f) {
+		KhtBatchFrame& fr = B.frames[f];
+		fr.paramsBase = nParams; nParams += fr.params.size();
+		tabV.paramsBase[f] = static_cast<uint32_t>(fr.paramsBase); tabV.nKernels[f] = static_cast<int>(fr.params.size()); tabV.gs[f] = fr.GS;
+	}
+	if (nParams) {
+		if (B.countsElems < mapElems * G) { dfree(ctx, B.counts); B.countsElems = 0; BCHK(dmalloc(ctx, &B.counts, mapElems * G)); B.countsElems = mapElems * G; }
+		if (B.cellsCap < cellCap * G) { dfree(ctx, B.cells); B.cellsCap = 0; BCHK(dmalloc(ctx, &B.cells, cellCap * G)); B.cellsCap = cellCap * G; }
+		BCHK(growPinned(B.paramsHost, B.paramsHostCap, nParams));
+		BCHK(growDevice(ctx, B.params, B.paramsCap, nParams));
+		for (size_t f = 0; f < G; ++f) { const KhtBatchFrame& fr = B.frames[f]; if (!fr.params.empty()) memcpy(B.paramsHost + fr.paramsBase, fr.params.data(), fr.params.size() * sizeof(KhtVoteParams)); }
+		BCHK(hipMemcpyAsync(B.params, B.paramsHost, nParams * sizeof(KhtVoteParams), hipMemcpyHostToDevice, st));
+		BCHK(hipMemsetAsync(B.counts, 0, mapElems * G * sizeof(int32_t), st));
+		BCHK(hipMemsetAsync(B.cellCount, 0, kKhtBatch * sizeof(int), st));
+		KhtGpuArgs a;
+		a.params = B.params; a.nKernels = 0; a.counts = B.counts; a.stride = stride;
+		a.rhoN = static_cast<int>(ax.rhoN); a.T = static_cast<int>(ax.T); a.dRho = ax.dRho; a.dThetaDeg = ax.dThetaDeg; a.gs = 1.0;
+		a.threshold = threshold; a.cells = B.cells; a.cellCount = B.cellCount; a.cellCap = static_cast<int>(cellCap);
+		BCHK(launch_kht_vote(a, tabV, st));
+		BCHK(launch_kht_peaks(a, tabV, st));
+		int cc[kKhtBatch];
+		BCHK(hipMemcpyAsync(cc, B.cellCount, sizeof(cc), hipMemcpyDeviceToHost, st));
+		BCHK(hipStreamSynchronize(st));
+		size_t nCells = 0;
+		for (size_t f = 0; f < G; ++f) {
+			KhtBatchFrame& fr = B.frames[f];
+			fr.cellCount = fr.params.empty() ? 0 : std::min<int>(cc[f], static_cast<int>(cellCap));
+			fr.cellOff = nCells; nCells += static_cast<size_t>(fr.cellCount);
+		}
+		if (nCells) {
+			BCHK(growPinned(B.cellsHost, B.cellsHostCap, nCells));
+			for (size_t f = 0; f < G; ++f) {
+				const KhtBatchFrame& fr = B.frames[f];
+				if (fr.cellCount) BCHK(hipMemcpyAsync(B.cellsHost + fr.cellOff, B.cells + f * cellCap, static_cast<size_t>(fr.cellCount) * sizeof(KhtCell), hipMemcpyDeviceToHost, st));
+			}
+			BCHK(hipStreamSynchronize(st));
+		}
+	}
+	B.stageMs[4] += msSince(tc);
+
+	// ---- F. sort + sweep with the visited map (order dependent, :1195-1247): per frame, on the pool ----
+	pool.run(G, [&](size_t f) { guarded(f, [&](KhtBatchFrame& fr) {
+		if (fr.haveGS && gs) gs[f] = fr.GS;
+		if (!fr.cellCount) { counts[f] = 0; return; }
+		const auto t0 = clk::now();
+		fr.cells.assign(B.cellsHost + fr.cellOff, B.cellsHost + fr.cellOff + fr.cellCount);
+		khtPeaks(ax, fr.cells, maxLines, fr.out, fr.peaks);
+		counts[f] = fr.out.size();
+		if (lines) khtCopyLines(fr.out, lines + f * cap, cap);
+		fr.ms[5] += msSince(t0);
+	}); });
+	rc = firstError();
+	if (rc) return rc;
+	for (size_t f = 0; f < G; ++f) {
+		const KhtBatchFrame& fr = B.frames[f];
+		B.stageMs[0] += fr.ms[0]; B.stageMs[2] += fr.ms[2]; B.stageMs[3] += fr.ms[3]; B.stageMs[5] += fr.ms[5];
+		if (fr.out.size() > cap) *overflow = true;
+	}
+#undef BCHK
+	return COMPVHIP_OK;
+}
+
 int compvhip_plan_houghkht(compvhip_plan* p, const uint8_t* d_edges, float rho, float thetaDeg, int threshold, int maxLines, double clusterMinDeviation,
                            size_t clusterMinSize, double kernelMinHeight, compvhip_line* lines, size_t cap, size_t* counts, double* gs, int hostThreads)
 {
@@ -1821,98 +2181,79 @@ int compvhip_plan_houghkht(compvhip_plan* p, const uint8_t* d_edges, float rho, 
 	HIPCHK(ctx, hipSetDevice(ctx->device));
 	unsigned hw = std::thread::hardware_concurrency();
 	if (!hw) hw = 4;
-	size_t T = hostThreads > 0 ? static_cast<size_t>(hostThreads) : std::min<size_t>(32, std::max<size_t>(1, hw / 2));   // measured at 4K x 32 frames: 8 / 16 / 32 workers 1.25 / 0.77 / 0.55 ms per frame
+	size_t T = hostThreads > 0 ? static_cast<size_t>(hostThreads) : std::min<size_t>(32, std::max<size_t>(1, hw / 2));
 	T = std::min(T, F);
-	// The producer of d_edges may still be running on the caller's stream; the workers use private streams: drain the device first (the call is
+	// The frames go through the stages in GROUPS of kKhtGroup, up to four groups at a time, each with its own controller thread, stream, buffers and share
+	// of the host threads: inside a group the stages are batched (one launch, one transfer per stage), and while one group is in a GPU stage the host
+	// threads of the others link or sweep.  (One group of 32 frames: every stage waits for the slowest frame and the GPU stages -- 100 MB over PCIe per
+	// 4K batch -- wait for all of them: 18-20 ms per batch against 10.9 ms for the thread-per-frame pipeline of round 4; measured)
+	const size_t nGroups = (F + kKhtGroup - 1) / kKhtGroup;
+	const size_t K = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(T / 4, 4), nGroups));   // controllers = groups in flight
+	// The producer of d_edges may still be running on the caller's stream; the groups use private streams: drain the device first (the call is
 	// synchronous and takes milliseconds -- the drain is not what bounds it)
 	HIPCHK(ctx, hipDeviceSynchronize());
-	const size_t wpr = (W + 31) / 32;   // mask words per row
-	while (p->khtWorkers.size() < T) {
-		KhtScratch* k = new (std::nothrow) KhtScratch();
-		if (!k) return fail(ctx, COMPVHIP_E_OUT_OF_MEMORY, "KHT worker");
-		if (hipStreamCreateWithFlags(&k->stream, hipStreamNonBlocking) != hipSuccess) { delete k; return fail(ctx, COMPVHIP_E_HIP, "KHT worker stream"); }
-		k->ownStream = true;
-		p->khtWorkers.push_back(k);   // only a worker that has its stream joins the pool
+	const size_t G0 = std::min<size_t>(F, kKhtGroup), words = ((W + 31) / 32) * H;
+	while (p->khtBatch.size() < K) {
+		KhtBatchState* b = new (std::nothrow) KhtBatchState();
+		if (!b) return fail(ctx, COMPVHIP_E_OUT_OF_MEMORY, "KHT batch state");
+		p->khtBatch.push_back(b);
 	}
-	for (size_t t = 0; t < T; ++t) {
-		KhtScratch& K = *p->khtWorkers[t];
-		if (K.hostBitsWords < wpr * H) {
-			if (K.hostBits) (void)hipHostFree(K.hostBits);
-			K.hostBits = nullptr; K.hostBitsWords = 0;
-			if (hipHostMalloc(reinterpret_cast<void**>(&K.hostBits), wpr * H * sizeof(uint32_t)) != hipSuccess) return fail(ctx, COMPVHIP_E_OUT_OF_MEMORY, "pinned frame buffer");
-			K.hostBitsWords = wpr * H;
+	for (size_t k = 0; k < K; ++k) {
+		KhtBatchState& B = *p->khtBatch[k];
+		if (!B.stream) HIPCHK(ctx, hipStreamCreateWithFlags(&B.stream, hipStreamNonBlocking));
+		if (B.bitsWords < words * G0) {
+			dfree(ctx, B.dBits); if (B.hostBits) (void)hipHostFree(B.hostBits);
+			B.hostBits = nullptr; B.bitsWords = 0;
+			HIPCHK(ctx, dmalloc(ctx, &B.dBits, words * G0));
+			if (hipHostMalloc(reinterpret_cast<void**>(&B.hostBits), words * G0 * sizeof(uint32_t)) != hipSuccess) return fail(ctx, COMPVHIP_E_OUT_OF_MEMORY, "pinned bit planes");
+			B.bitsWords = words * G0;
 		}
-		if (K.dBitsWords < wpr * H) {
-			dfree(ctx, K.dBits); K.dBitsWords = 0;
-			if (dmalloc(ctx, &K.dBits, wpr * H) != hipSuccess) return fail(ctx, COMPVHIP_E_OUT_OF_MEMORY, "device bit plane");
-			K.dBitsWords = wpr * H;
-		}
-		memset(K.stageMs, 0, sizeof(K.stageMs));
-		K.err.clear();
+		while (B.ready.size() < G0) { hipEvent_t e; HIPCHK(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming)); B.ready.push_back(e); }
+		if (!B.totals) HIPCHK(ctx, dmalloc(ctx, &B.totals, kKhtBatch + 1));
+		if (!B.cellCount) HIPCHK(ctx, dmalloc(ctx, &B.cellCount, kKhtBatch));
+		try { if (B.frames.size() < G0) B.frames.resize(G0); }
+		catch (...) { return fail(ctx, COMPVHIP_E_OUT_OF_MEMORY, "KHT batch state"); }
+		memset(B.stageMs, 0, sizeof(B.stageMs));
 	}
 	for (size_t f = 0; f < F; ++f) counts[f] = 0;
-	std::atomic<size_t> next{0};
-	std::vector<int> codes(T, COMPVHIP_OK);
-	std::vector<double> dlMs(T, 0.0);
-	std::atomic<int> overflow{0};
 	const auto wall0 = std::chrono::steady_clock::now();
-	std::vector<size_t> failedFrame(T, static_cast<size_t>(-1));
-	auto work = [&](size_t t) {
-		KhtScratch& K = *p->khtWorkers[t];
-		size_t f = static_cast<size_t>(-1);
+	std::atomic<size_t> nextGroup{0};
+	std::vector<int> codes(K, COMPVHIP_OK);
+	std::vector<std::string> errs(K);
+	std::vector<size_t> badGroup(K, 0);
+	std::atomic<int> overflowAny{0};
+	auto controller = [&](size_t k) {
 		try {
-			if (hipSetDevice(ctx->device) != hipSuccess) { codes[t] = COMPVHIP_E_HIP; K.err = "hipSetDevice"; return; }
-			std::vector<KhtLine> out;
+			const size_t mine = T / K + (k < T % K ? 1 : 0);   // the controller is one of its group's host threads
+			KhtPool pool(std::max<size_t>(1, mine));
 			for (;;) {
-				f = next.fetch_add(1);
-				if (f >= F) break;
-				const auto d0 = std::chrono::steady_clock::now();
-				// the frame's edge map leaves the device as bit-mask rows: 1/8 of the bytes over PCIe, and the linker works on bits anyway
-				hipError_t e = launch_bytes_to_bits(d_edges + f * S * H, static_cast<int>(W), static_cast<int>(H), static_cast<int>(S), S * H, K.dBits, static_cast<int>(wpr),
-				                                    wpr * H, 1, K.stream);
-				if (e == hipSuccess) e = hipMemcpyAsync(K.hostBits, K.dBits, wpr * H * sizeof(uint32_t), hipMemcpyDeviceToHost, K.stream);
-				if (e == hipSuccess) e = hipStreamSynchronize(K.stream);
-				if (e != hipSuccess) { codes[t] = COMPVHIP_E_HIP; failedFrame[t] = f; K.err = std::string("frame download: ") + hipGetErrorString(e); return; }
-				khtPlaneFromWords(K.hostBits, wpr, W, H, K.plane);
-				dlMs[t] += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - d0).count();
-				const int r = khtFrame(ctx, K, W, H, ax, threshold, maxLines, clusterMinDeviation, clusterMinSize, kernelMinHeight, out, gs ? gs + f : nullptr);
-				if (r) { codes[t] = r; failedFrame[t] = f; return; }
-				counts[f] = out.size();
-				if (lines) khtCopyLines(out, lines + f * cap, cap);
-				if (out.size() > cap) overflow.store(1);
+				const size_t g = nextGroup.fetch_add(1);
+				if (g >= nGroups) break;
+				const size_t g0 = g * kKhtGroup, G = std::min<size_t>(kKhtGroup, F - g0);
+				bool overflow = false;
+				const int r = khtBatchGroup(p, *p->khtBatch[k], pool, d_edges + g0 * S * H, G, ax, threshold, maxLines, clusterMinDeviation, clusterMinSize, kernelMinHeight,
+				                            lines ? lines + g0 * cap : nullptr, cap, counts + g0, gs ? gs + g0 : nullptr, &overflow, errs[k]);
+				if (overflow) overflowAny.store(1);
+				if (r) { codes[k] = r; badGroup[k] = g0; nextGroup.store(nGroups); break; }   // the other controllers finish the group they are in and stop
 			}
 		}
-		catch (const std::exception& ex) {   // nothing may leave an extern "C" entry point (or a std::thread) as an exception
-			codes[t] = COMPVHIP_E_OUT_OF_MEMORY; failedFrame[t] = f; K.err = std::string("exception in a KHT worker: ") + ex.what();
-		}
-		catch (...) {
-			codes[t] = COMPVHIP_E_OUT_OF_MEMORY; failedFrame[t] = f; K.err = "exception in a KHT worker";
-		}
+		catch (const std::exception& ex) { codes[k] = COMPVHIP_E_OUT_OF_MEMORY; errs[k] = std::string("exception in the batched KHT: ") + ex.what(); }   // nothing may leave a thread
+		catch (...) { codes[k] = COMPVHIP_E_OUT_OF_MEMORY; errs[k] = "exception in the batched KHT"; }                                                   // (or an extern "C" entry point) as an exception
 	};
-	if (T == 1) work(0);
-	else {
-		std::vector<std::thread> pool;
-		size_t started = 1;
-		try {
-			for (size_t t = 1; t < T; ++t, ++started) pool.emplace_back(work, t);
-		}
-		catch (...) {
-			// the system refused another thread: the workers that did start share the frames among themselves
-		}
-		work(0);
-		for (auto& th : pool) th.join();
-		(void)started;
+	{
+		std::vector<std::thread> ctl;
+		try { for (size_t k = 1; k < K; ++k) ctl.emplace_back(controller, k); }
+		catch (...) { /* the system refused a thread: the controllers that did start take all the groups */ }
+		controller(0);
+		for (std::thread& t : ctl) t.join();
 	}
 	p->khtWallMs = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
 	p->khtThreads = static_cast<int>(T);
 	memset(p->khtStageMs, 0, sizeof(p->khtStageMs));
-	for (size_t t = 0; t < T; ++t) for (int k = 0; k < 6; ++k) p->khtStageMs[k] += p->khtWorkers[t]->stageMs[k];
-	for (size_t t = 0; t < T; ++t)
-		if (codes[t]) {
-			const std::string msg = "frame " + (failedFrame[t] == static_cast<size_t>(-1) ? std::string("?") : std::to_string(failedFrame[t])) + ": " + p->khtWorkers[t]->err;
-			return fail(ctx, codes[t], msg.c_str());
-		}
-	if (overflow.load()) return fail(ctx, COMPVHIP_E_OUT_OF_BOUND, "line buffer too small");
+	for (size_t k = 0; k < K; ++k) for (int i = 0; i < 6; ++i) p->khtStageMs[i] += p->khtBatch[k]->stageMs[i];
+	for (size_t k = 0; k < K; ++k)
+		if (codes[k]) return fail(ctx, codes[k], ("frames from " + std::to_string(badGroup[k]) + ": " + errs[k]).c_str());
+	if (overflowAny.load()) return fail(ctx, COMPVHIP_E_OUT_OF_BOUND, "line buffer too small");
 	return COMPVHIP_OK;
 }
 

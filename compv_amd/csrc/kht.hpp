@@ -49,25 +49,31 @@ struct KhtPeaksWork {
 };
 void khtPeaks(const KhtAxes& ax, std::vector<KhtCell>& cells, int maxLines, std::vector<KhtLine>& lines, KhtPeaksWork& work);
 
-// GPU stages
+// GPU stages.  Every launch covers the frames of a BATCH (compvhip_plan_houghkht: one launch per stage for up to kKhtBatch frames instead of one per frame;
+// the host entry point is a batch of one): strings, clusters and kernels of the frames sit one behind the other in shared arrays, the per-frame tables
+// travel by value in the kernel arguments (blockIdx.y / .z = frame).
+constexpr int kKhtBatch = 32;      // frames a launch can cover (size of the by-value tables)
+constexpr int kKhtGroup = 8;       // frames compvhip_plan_houghkht puts through the stages together
+struct KhtBatchStrings { uint32_t stringBegin[kKhtBatch + 1]; uint32_t clusterBase[kKhtBatch]; int frames; };   // strings of frame f: [stringBegin[f], stringBegin[f + 1]); its clusters start at clusterBase[f]
+struct KhtBatchStats { uint32_t clusterBase[kKhtBatch]; int n[kKhtBatch]; int simdEnd[kKhtBatch]; int frames; };   // simdEnd: clusters [0, simdEnd) of the frame use the SIMD operation order of the kernel height
+struct KhtBatchVote { uint32_t paramsBase[kKhtBatch]; int nKernels[kKhtBatch]; double gs[kKhtBatch]; int frames; size_t mapElems, cellCap; };   // vote map / cell list of frame f at f * mapElems / f * cellCap
 struct KhtGpuArgs {
 	const KhtVoteParams* params; int nKernels;
-	int32_t* counts;          // (T+2) x stride, zeroed
+	int32_t* counts;          // [frames][(T+2) x stride], zeroed
 	int stride;               // >= rhoN + 2
 	int rhoN, T;
 	double dRho, dThetaDeg, gs;
 	int32_t threshold;
-	KhtCell* cells; int* cellCount; int cellCap;
+	KhtCell* cells; int* cellCount; int cellCap;   // [frames][cellCap], [frames]
 };
 // Algorithm 2, per-cluster statistics (kht_stats_kernel): one thread per cluster, float64, the reference's operation order
 struct KhtSpan { uint32_t begin, end; };
 struct KhtStatsArgs {
-	const KhtPoint* pts; const KhtSpan* clusters; int n;
-	int simdEnd;              // clusters [0, simdEnd) use the SIMD operation order of the kernel height, the rest the C order
+	const KhtPoint* pts; const KhtSpan* clusters;
 	double hw, hh;            // W/2, H/2
-	KhtKernel* out;           // .theta holds vx: acos() is taken by the host libm (khtFinishKernels)
+	KhtKernel* out;           // cluster order; .theta holds vx: acos() is taken by the host libm (khtFinishKernels)
 };
-hipError_t launch_kht_stats(const KhtStatsArgs& a, hipStream_t stream);
+hipError_t launch_kht_stats(const KhtStatsArgs& a, const KhtBatchStats& tab, hipStream_t stream);
 
 // clusters_find / clusters_subdivision (houghkht.cxx:762-832) on the GPU: one thread per string, explicit recursion stack
 struct KhtStringDesc { uint32_t begin, end, slot; }; // points [begin, end) of the string; slot = first cluster / stack slot of its private regions
@@ -78,13 +84,14 @@ struct KhtSubdivArgs {
 	KhtSpan* scratch;          // per-string cluster regions (capacity: see khtSubdivSlots)
 	KhtSubdivFrame* stack;     // per-string recursion stacks (same slot layout, + 2 frames per string)
 	uint32_t* counts;          // [nStrings] clusters found per string
-	KhtSpan* clusters;         // compacted, string order
-	uint32_t* total;           // [2]: clusters found in all strings; flag "a recursion ran out of stack slots" (zeroed by the caller)
+	KhtSpan* clusters;         // compacted, string order, frame f from clusterBase[f]
+	uint32_t* total;           // [frames + 1]: clusters found per frame; [frames] = flag "a recursion ran out of stack slots" (zeroed by the caller)
+	int flagIndex;             // = frames
 };
 // upper bound on the clusters (and on the recursion depth) of a string of `len` points
 __host__ __device__ inline size_t khtSubdivSlots(size_t len, size_t minSize) { const size_t m = minSize < 2 ? 2 : minSize; return (len > m ? (len - 1) / (m - 1) : 1) + 2; }
-hipError_t launch_kht_subdivide(const KhtSubdivArgs& a, hipStream_t stream);
-hipError_t launch_kht_vote(const KhtGpuArgs& a, hipStream_t stream);
-hipError_t launch_kht_peaks(const KhtGpuArgs& a, hipStream_t stream);
+hipError_t launch_kht_subdivide(const KhtSubdivArgs& a, const KhtBatchStrings& tab, hipStream_t stream);
+hipError_t launch_kht_vote(const KhtGpuArgs& a, const KhtBatchVote& tab, hipStream_t stream);
+hipError_t launch_kht_peaks(const KhtGpuArgs& a, const KhtBatchVote& tab, hipStream_t stream);
 
 } // namespace compvhip

@@ -105,7 +105,7 @@ __global__ __launch_bounds__(64) void kht_subdivide_kernel(KhtSubdivArgs a)
 			f.ratio = __ddiv_rn(length, (q < a.minDev) ? a.minDev : q); // length / std::max(maxDev / length, minDev), operand order included
 			f.keep = outCount; f.m = maxIndex;
 			const bool split = (maxIndex - s + 1) >= a.minSize && (e - maxIndex + 1) >= a.minSize && maxIndex > s;
-			if (split && sp >= maxDepth) a.total[1] = 1u;   // out of recursion slots (khtSubdivSlots bounds the depth for minSize >= 2): the call fails
+			if (split && sp >= maxDepth) a.total[a.flagIndex] = 1u;   // out of recursion slots (khtSubdivSlots bounds the depth for minSize >= 2): the call fails
 			if (split && sp < maxDepth) {
 				f.state = 1;
 				st[sp].s = s; st[sp].e = maxIndex; st[sp].state = 0; ++sp;
@@ -120,16 +120,19 @@ __global__ __launch_bounds__(64) void kht_subdivide_kernel(KhtSubdivArgs a)
 	if (lane == 0) a.counts[sidx] = (uint32_t)outCount;
 }
 
-// one workgroup: exclusive scan of the per-string counts, then the clusters are copied into one list in string order
-__global__ __launch_bounds__(1024) void kht_gather_clusters_kernel(KhtSubdivArgs a)
+// one workgroup per frame: exclusive scan of the per-string counts of the frame's strings, then its clusters are copied into one list in string order
+__global__ __launch_bounds__(1024) void kht_gather_clusters_kernel(KhtSubdivArgs a, KhtBatchStrings tab)
 {
 	__shared__ uint32_t s_part[1024];
 	__shared__ uint32_t s_carry;
+	const int f = blockIdx.x;
+	const int sb = (int)tab.stringBegin[f], se = (int)tab.stringBegin[f + 1];
+	KhtSpan* __restrict__ dst = a.clusters + tab.clusterBase[f];
 	if (threadIdx.x == 0) s_carry = 0;
 	__syncthreads();
-	for (int base = 0; base < a.nStrings; base += 1024) {
+	for (int base = sb; base < se; base += 1024) {
 		const int i = base + (int)threadIdx.x;
-		const uint32_t c = i < a.nStrings ? a.counts[i] : 0u;
+		const uint32_t c = i < se ? a.counts[i] : 0u;
 		s_part[threadIdx.x] = c;
 		__syncthreads();
 		for (int o = 1; o < 1024; o <<= 1) { // Hillis-Steele inclusive scan
@@ -139,15 +142,15 @@ __global__ __launch_bounds__(1024) void kht_gather_clusters_kernel(KhtSubdivArgs
 			__syncthreads();
 		}
 		const uint32_t off = s_carry + s_part[threadIdx.x] - c;
-		if (i < a.nStrings) {
+		if (i < se) {
 			const KhtSpan* __restrict__ src = a.scratch + a.strings[i].slot;
-			for (uint32_t k = 0; k < c; ++k) a.clusters[off + k] = src[k];
+			for (uint32_t k = 0; k < c; ++k) dst[off + k] = src[k];
 		}
 		__syncthreads();
 		if (threadIdx.x == 1023) s_carry += s_part[1023];
 		__syncthreads();
 	}
-	if (threadIdx.x == 0) *a.total = s_carry;
+	if (threadIdx.x == 0) a.total[f] = s_carry;
 }
 
 // CompVMathEigen<double>::find2x2 (base/math/compv_math_eigen.cxx:285-342), sort = norm = true
@@ -180,12 +183,13 @@ __device__ __forceinline__ void find2x2_dev(double a0, double a1, double a2, dou
 	}
 }
 
-__global__ __launch_bounds__(64) void kht_stats_kernel(KhtStatsArgs a)
+__global__ __launch_bounds__(64) void kht_stats_kernel(KhtStatsArgs a, KhtBatchStats tab)
 {
-	const int k = blockIdx.x * blockDim.x + threadIdx.x;
-	if (k >= a.n) return;
+	const int k = blockIdx.x * blockDim.x + threadIdx.x;   // cluster of frame blockIdx.y
+	const int f = blockIdx.y;
+	if (k >= tab.n[f]) return;
 	const double kRadToDeg = 180.0 / 3.14159265358979323846, kTwoPi = 2.0 * 3.14159265358979323846;
-	const KhtSpan c = a.clusters[k];
+	const KhtSpan c = a.clusters[tab.clusterBase[f] + k];
 	const KhtPoint* __restrict__ b = a.pts + c.begin;
 	const uint32_t cnt = c.end - c.begin;
 	const double nScale = __ddiv_rn(1.0, (double)cnt);
@@ -229,16 +233,19 @@ __global__ __launch_bounds__(64) void kht_stats_kernel(KhtStatsArgs a)
 	const double omr = 1.0 - (rr * rr);
 	// kernel height: SIMD operation order 1/((sqrt(1-r^2)*s)*2pi) for the clusters the reference's vector loop takes
 	// (intrin_avx.cxx:42-63, intrin_sse2.cxx:118-142), the C order 1/(2pi*s*sqrt(1-r^2)) for its remainder (:849-883)
-	const double h = (k < a.simdEnd) ? __ddiv_rn(1.0, (__dsqrt_rn(omr) * s) * kTwoPi) : __ddiv_rn(1.0, kTwoPi * s * __dsqrt_rn(omr));
+	const double h = (k < tab.simdEnd[f]) ? __ddiv_rn(1.0, (__dsqrt_rn(omr) * s) * kTwoPi) : __ddiv_rn(1.0, kTwoPi * s * __dsqrt_rn(omr));
 	K.sigmaRhoSquare = srs; K.sigmaRhoTimesTheta = srt; K.m2 = m2; K.sigmaThetaSquare = sts; K.h = h;
-	a.out[k] = K;
+	a.out[tab.clusterBase[f] + k] = K;
 }
 
-__global__ __launch_bounds__(64) void kht_vote_kernel(KhtGpuArgs a)
+__global__ __launch_bounds__(64) void kht_vote_kernel(KhtGpuArgs a, KhtBatchVote tab)
 {
-	const int id = blockIdx.x * blockDim.x + threadIdx.x;
-	if (id >= a.nKernels * 4) return;
-	const KhtVoteParams p = a.params[id >> 2];
+	const int id = blockIdx.x * blockDim.x + threadIdx.x;   // (kernel, quadrant) of frame blockIdx.y
+	const int f = blockIdx.y;
+	if (id >= tab.nKernels[f] * 4) return;
+	const KhtVoteParams p = a.params[tab.paramsBase[f] + (id >> 2)];
+	a.counts += (size_t)f * tab.mapElems;
+	a.gs = tab.gs[f];
 	const int quad = id & 3;
 	// the four quadrants (:1080-1083)
 	int incRhoIndex = (quad & 2) ? -1 : 1;
@@ -290,11 +297,13 @@ __device__ __forceinline__ int smooth3x3(const int32_t* c, int stride)
 	return t[-1] + (t[0] << 1) + t[1] + b[-1] + (b[0] << 1) + b[1] + (c[-1] << 1) + (c[0] << 2) + (c[1] << 1);
 }
 
-__global__ __launch_bounds__(256) void kht_peaks_kernel(KhtGpuArgs a, int sseCovEnd, int consumed, int remains, int simd)
+__global__ __launch_bounds__(256) void kht_peaks_kernel(KhtGpuArgs a, KhtBatchVote tab, int sseCovEnd, int consumed, int remains, int simd)
 {
 	const int ti = blockIdx.y + 1;                           // theta index 1 .. T-1 (:437)
 	const int c = blockIdx.x * blockDim.x + threadIdx.x + 1; // column 1 .. rhoN
-	if (ti >= a.T || c > a.rhoN) return;
+	const int f = blockIdx.z;
+	if (ti >= a.T || c > a.rhoN || tab.nKernels[f] <= 0) return;   // a frame without kernels has no votes (and the reference returns before this stage)
+	a.counts += (size_t)f * tab.mapElems; a.cells += (size_t)f * tab.cellCap; a.cellCount += f;
 	const int vs = a.rhoN + 2;
 	const int32_t* cell = a.counts + (size_t)ti * a.stride + c;
 	const int v = *cell;
@@ -315,30 +324,33 @@ __global__ __launch_bounds__(256) void kht_peaks_kernel(KhtGpuArgs a, int sseCov
 	}
 }
 
-hipError_t launch_kht_subdivide(const KhtSubdivArgs& a, hipStream_t stream)
+hipError_t launch_kht_subdivide(const KhtSubdivArgs& a, const KhtBatchStrings& tab, hipStream_t stream)
 {
-	if (a.nStrings <= 0) return hipSuccess;
+	if (a.nStrings <= 0 || tab.frames <= 0) return hipSuccess;
 	hipLaunchKernelGGL(kht_subdivide_kernel, dim3(a.nStrings), dim3(64), 0, stream, a);
-	hipLaunchKernelGGL(kht_gather_clusters_kernel, dim3(1), dim3(1024), 0, stream, a);
+	hipLaunchKernelGGL(kht_gather_clusters_kernel, dim3(tab.frames), dim3(1024), 0, stream, a, tab);
 	return hipGetLastError();
 }
 
-hipError_t launch_kht_stats(const KhtStatsArgs& a, hipStream_t stream)
+hipError_t launch_kht_stats(const KhtStatsArgs& a, const KhtBatchStats& tab, hipStream_t stream)
 {
-	if (a.n <= 0) return hipSuccess;
-	hipLaunchKernelGGL(kht_stats_kernel, dim3((a.n + 63) / 64), dim3(64), 0, stream, a);
+	int most = 0;
+	for (int f = 0; f < tab.frames; ++f) most = tab.n[f] > most ? tab.n[f] : most;
+	if (most <= 0) return hipSuccess;
+	hipLaunchKernelGGL(kht_stats_kernel, dim3((most + 63) / 64, tab.frames), dim3(64), 0, stream, a, tab);
 	return hipGetLastError();
 }
 
-hipError_t launch_kht_vote(const KhtGpuArgs& a, hipStream_t stream)
+hipError_t launch_kht_vote(const KhtGpuArgs& a, const KhtBatchVote& tab, hipStream_t stream)
 {
-	if (a.nKernels <= 0) return hipSuccess;
-	const int threads = a.nKernels * 4;
-	hipLaunchKernelGGL(kht_vote_kernel, dim3((threads + 63) / 64), dim3(64), 0, stream, a);
+	int most = 0;
+	for (int f = 0; f < tab.frames; ++f) most = tab.nKernels[f] > most ? tab.nKernels[f] : most;
+	if (most <= 0) return hipSuccess;
+	hipLaunchKernelGGL(kht_vote_kernel, dim3((most * 4 + 63) / 64, tab.frames), dim3(64), 0, stream, a, tab);
 	return hipGetLastError();
 }
 
-hipError_t launch_kht_peaks(const KhtGpuArgs& a, hipStream_t stream)
+hipError_t launch_kht_peaks(const KhtGpuArgs& a, const KhtBatchVote& tab, hipStream_t stream)
 {
 	// column coverage of the reference's scan (:1166-1187): SSE2 groups of 4 from column 1 while rho_index < rhoN-3, then a
 	// scalar remainder that starts at (rhoN & ~3) + 1
@@ -351,8 +363,8 @@ hipError_t launch_kht_peaks(const KhtGpuArgs& a, hipStream_t stream)
 		consumed = (a.rhoN & ~3) + 1;
 		remains = a.rhoN > consumed ? a.rhoN - consumed : 0;
 	}
-	dim3 grid((a.rhoN + 255) / 256, a.T > 1 ? a.T - 1 : 1);
-	hipLaunchKernelGGL(kht_peaks_kernel, grid, dim3(256), 0, stream, a, sseCovEnd, consumed, remains, simd);
+	dim3 grid((a.rhoN + 255) / 256, a.T > 1 ? a.T - 1 : 1, tab.frames);
+	hipLaunchKernelGGL(kht_peaks_kernel, grid, dim3(256), 0, stream, a, tab, sseCovEnd, consumed, remains, simd);
 	return hipGetLastError();
 }
 
