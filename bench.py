@@ -749,6 +749,10 @@ def main():
                 out["kht"] = kht_figure(capi, ctx, torch, lanes[0], blocks, W, H, F)
             except Exception as e:
                 out["kht"] = {"error": str(e)}
+            try:
+                out["kernels_extra"] = kernels_extra(capi, torch, lanes[0], blocks, W, H, F)
+            except Exception as e:
+                out["kernels_extra"] = {"error": str(e)}
         if world == 1 and not args.no_extras and (W, H) == (3840, 2160):
             try:
                 out["configs_extra"] = {"fhd_1920x1080": extra_config(torch, capi, sharding, ctx, dev, 1920, 1080, 32, 2, max(64, args.steps // 2), args.warmup,
@@ -766,6 +770,44 @@ def main():
     ctx.close()
     if dist_on:
         dist.destroy_process_group()
+
+
+def kernels_extra(capi, torch, lane, blocks, W, H, F):
+    """The kernels of the path that the benchmark step does not run: Canny with the 5x5 Sobel and the Sobel detector, one batch, HIP events
+    of the plan's timing API, priced like roofline_canny (1 B/px read for the fused Canny tile kernel, 3 B/px -- two reads, one write -- for the detector)."""
+    q = lane
+    plan, st = q["plan"], q["stream"].cuda_stream
+    px = F * W * H
+
+    def timed(call, n=8):
+        for _ in range(2):
+            call()
+        torch.cuda.synchronize()
+        plan.set_timing(1)
+        acc = {}
+        for _ in range(n):
+            call()
+            torch.cuda.synchronize()
+            for name, ms in plan.get_timing():
+                acc[name] = acc.get(name, 0.0) + ms
+        plan.set_timing(0)
+        return {k: v / n for k, v in acc.items()}
+
+    out = {}
+    # the 5x5 Sobel answers a step edge 12 x as strongly as the 3x3 one (16 * 3 against 4 * 1): thresholds scaled to the benchmark's edge density, and unscaled
+    for name, tl, th in (("canny5_same_edge_density", 12 * T_LOW, 12 * T_HIGH), ("canny5_benchmark_thresholds", T_LOW, T_HIGH)):
+        per = timed(lambda: plan.canny(blocks[0].data_ptr(), tl, th, q["edges"].data_ptr(), ksize=5, stream=st))
+        tile, res = per.get("canny_tile_kernel", 0.0), per.get("canny_resolve_kernel", 0.0)
+        out[name] = {"thresholds": [tl, th], "edge_pixels": int((q["edges"] != 0).sum().item()), "canny_tile_kernel_ms": round(tile, 4), "canny_resolve_kernel_ms": round(res, 4),
+                     "stage_ms": round(tile + res, 4), "roofline": {"bound": "hbm", "achieved": round(px / (tile * 1e-3) / 1e9, 1) if tile else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                                                    "frac": round(px / (tile * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if tile else None, "basis": "1 B/px read, tile kernel"}}
+    d_out = torch.empty_like(blocks[0])
+    per = timed(lambda: plan.edge_dete(blocks[0].data_ptr(), capi.OP_SOBEL, d_out.data_ptr(), st))
+    ms = sum(per.values())
+    out["edge_dete_sobel"] = {"ms": round(ms, 4), "kernels": {k: round(v, 4) for k, v in per.items()},
+                              "roofline": {"bound": "hbm", "achieved": round(3.0 * px / (ms * 1e-3) / 1e9, 1) if ms else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                                           "frac": round(3.0 * px / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms else None, "basis": "3 B/px: gmax pass read + output pass read + write"}}
+    return out
 
 
 def kht_figure(capi, ctx, torch, lane, blocks, W, H, F):

@@ -9,11 +9,9 @@
 //                        out u8 [H][So]  {0,0xff}      (written once, 1 B/px)
 //                        E,U bitmasks u32 [H][wb]      (1 bit/px each: E = edge so far, U = weak but unresolved)
 //
-// Kernel 1: the tile kernel -- gradient, NMS, weak / strong classification; writes E (edges so far), U (weak, unresolved) and the bytes of E.
-//   Kernel size 3: canny_swar_tile_kernel (canny_swar_kernels.hip).  Kernel size 5: canny5_tile_kernel below -- one wave per 512x64 tile
-//   streams rows through registers (stencil.hpp, Grad5State), applies the NMS rule to the *unsuppressed* g (gather/apply split of the
-//   reference), collects per-lane mask bytes into LDS rows (lane == row) and floods strong -> weak inside the tile with 512-bit
-//   carry-propagate adds + cross-lane row exchange; weak pixels the tile cannot resolve go to the U mask.
+// Kernel 1: the tile kernel -- gradient, NMS, weak / strong classification; writes E (strong seeds), U (weak, unresolved) and the bytes of E:
+//   canny_swar_tile_kernel (canny_swar_kernels.hip), kernel sizes 3 and 5.  (The first-generation kernel -- one wave per 512x64 tile, 32-bit
+//   arithmetic, dense NMS, 512-bit carry-chain flood inside the tile -- served kernel size 5 until round 5: 0.50 ms per 32 x 4K against 0.41.)
 // Kernel 2 (canny_resolve_kernel): the hysteresis, on the 1-bit masks only (0.25 B/px): one workgroup per 64-row band floods E into U
 //   (register-resident column sweeps); repeated (device flags, no data-dependent host work) until no band changes.  The
 //   fixed point "all pixels with g_nms > tLow 8-connected to a pixel with g_nms > tHigh" is unique, hence
@@ -26,278 +24,6 @@
 #include <type_traits>
 
 namespace compvhip {
-
-// ---------------------------------------------------------------------------------------------------------------
-// helpers for the lane==row 512-bit masks
-// ---------------------------------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t spread4(uint32_t nib)
-{
-	// bit j of the nibble -> bit 8*j
-	return __umul24(nib, 0x00204081u) & 0x01010101u;
-}
-
-// S |= every run of W that contains a bit of S, towards higher bit positions (512-bit carry chain)
-__device__ __forceinline__ void flood_up(const uint64_t (&W)[8], uint64_t (&S)[8])
-{
-	uint64_t carry = 0;
-#pragma unroll
-	for (int m = 0; m < 8; ++m) {
-		const uint64_t a = W[m];
-		const uint64_t b = S[m] & a;
-		const uint64_t t = a + b;
-		const uint64_t c1 = t < a;
-		const uint64_t t2 = t + carry;
-		const uint64_t c2 = t2 < t;
-		carry = c1 | c2;
-		S[m] |= a & ~t2;
-	}
-}
-
-__device__ __forceinline__ void flood_down(const uint64_t (&W)[8], uint64_t (&S)[8])
-{
-	uint64_t carry = 0;
-#pragma unroll
-	for (int m = 7; m >= 0; --m) {
-		const uint64_t a = __brevll(W[m]);
-		const uint64_t b = __brevll(S[m]) & a;
-		const uint64_t t = a + b;
-		const uint64_t c1 = t < a;
-		const uint64_t t2 = t + carry;
-		const uint64_t c2 = t2 < t;
-		carry = c1 | c2;
-		S[m] |= __brevll(a & ~t2);
-	}
-}
-
-// max(a, b, c) with c wave-uniform, as ONE v_max3_i32 that is always executed: written as volatile asm because the compiler
-// otherwise sinks the four neighbour maxima of the NMS into divergent branches on the direction class (s_and_saveexec /
-// s_cbranch_execz / s_or per pixel) -- more instructions than the work it skips, and the kernel is bound by instruction issue.
-__device__ __forceinline__ int max3i(int a, int b, int sc)
-{
-	int d;
-	asm volatile("v_max3_i32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "s"(sc));
-	return d;
-}
-
-// ---------------------------------------------------------------------------------------------------------------
-// Kernel 1
-// ---------------------------------------------------------------------------------------------------------------
-template <bool GAP>
-__global__ __launch_bounds__(kCannyWaves * 64) void canny5_tile_kernel(CannyArgs a)
-{
-	constexpr int KS = 5;
-	constexpr int R = KS / 2; // kernel radius = width of the zero OUTPUT border of the gradient
-	constexpr int kMaskPitch = 33; // 32 mask dwords per row + 1: lane==row reads are bank-conflict free
-	__shared__ uint32_t lds_masks[kCannyWaves][kTileH][kMaskPitch];
-
-	const int lane = threadIdx.x & 63;
-	const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-	int tileX, group;
-	if (!xcd_tile_map(blockIdx.x, a.tilesX, a.groups, tileX, group)) return;
-	const int frame = group / a.blockRows;
-	const int tileY = (group - frame * a.blockRows) * kCannyWaves + wave;
-	if (tileY >= a.tilesY) return; // whole wave
-
-	const int W = a.W, H = a.H, S = a.S;
-	const int x0 = tileX * kTileW + lane * kLanePx;
-	const int y0 = tileY * kTileH;
-	const uint8_t* __restrict__ in = a.in + (size_t)frame * a.inFrameStride;
-
-	int tLow = a.tLow, tHigh = a.tHigh;
-	if (a.thrDev) { const int2 t = a.thrDev[frame]; tLow = t.x; tHigh = t.y; }
-	tHigh = __builtin_amdgcn_readfirstlane(tHigh);
-	const int tLow1 = __builtin_amdgcn_readfirstlane(tLow) + 1;
-
-	// columns gi = 0..9 <-> x = x0-1+gi: g is forced to 0 outside [1, W-2] (zero OUTPUT border of the convolution,
-	// compv_math_convlt.h:181-209) -- only tiles touching column 0 or W-1.. need the per-column test.
-	const bool edgeTile = (tileX == 0) || ((tileX + 1) * kTileW + 1 >= W - R);
-	uint32_t colok = 0x3ffu;
-	if (edgeTile) {
-		colok = 0;
-#pragma unroll
-		for (int gi = 0; gi < 10; ++gi) {
-			const int x = x0 - 1 + gi;
-			if (x >= R && x <= W - 1 - R) colok |= 1u << gi;
-		}
-	}
-	// quirk Q3 column coverage of the NMS and of the seed scan: [1,simdEnd) U [cStart,W-1)
-	uint32_t cov = 0xffu;
-	if (GAP) {
-		cov = 0;
-#pragma unroll
-		for (int p = 0; p < 8; ++p) {
-			const int x = x0 + p;
-			if ((x >= 1 && x < a.simdEnd) || (x >= a.cStart && x < W - 1)) cov |= 1u << p;
-		}
-	}
-
-	// tiles whose first/last gradient rows fall on the image border rows (g forced to 0 there)
-	const bool vEdgeTile = (tileY == 0) || (y0 + kTileH + 1 >= H - R);
-
-	Grad5State st5;
-	st5.reset();
-	int gr[3][10];           // ring of the last three gradient-magnitude rows
-	int axr[2][8];           // ring of |gx| of the last two gradient rows (direction class is evaluated at NMS time)
-	bool ngr[2][8];          // ring of sign(gx^gy)
-#pragma unroll
-	for (int i = 0; i < 10; ++i) { gr[0][i] = 0; gr[1][i] = 0; gr[2][i] = 0; }
-#pragma unroll
-	for (int p = 0; p < 8; ++p) { axr[0][p] = axr[1][p] = 0; ngr[0][p] = ngr[1][p] = false; }
-
-	uint32_t* maskRows = &lds_masks[wave][0][0];
-
-	RowBytes nextRow = load_row(in + (size_t)min(max(y0 - 1 - R, 0), H - 1) * S, x0, S);
-
-	// One row step.  Input rows y0-1-R .. y0+kTileH+R are pushed; pushing row yin yields the gradient of row yc = yin-R
-	// and allows the NMS of row yo = yc-1.  PH = it mod 6 selects the ring slots at compile time (3x3 path).
-	auto step = [&](auto phase, int it) {
-		constexpr int PH = decltype(phase)::value;
-		constexpr int gNew = PH % 3, gMid = (PH + 2) % 3, gOld = (PH + 1) % 3;
-		constexpr int aNew = PH % 2, aMid = (PH + 1) % 2;
-		const int yin = y0 - 1 - R + it;
-		const RowBytes rb = nextRow;
-		// software prefetch: the next row's loads are in flight while this row is processed (a distance of two rows was measured:
-		// no gain -- the kernel is bound by instruction issue, not by load latency)
-		nextRow = load_row(in + (size_t)min(max(yin + 1, 0), H - 1) * S, x0, S);
-		int (&gD)[10] = gr[gNew];
-		const int (&gC)[10] = gr[gMid];
-		const int (&gU)[10] = gr[gOld];
-		st5.push(rb, gD, axr[aNew], ngr[aNew]);
-
-		const int yc = yin - R;
-		if (vEdgeTile) {
-			if (!((yc >= R) && (yc <= H - 1 - R))) {
-#pragma unroll
-				for (int gi = 0; gi < 10; ++gi) gD[gi] = 0;
-			}
-		}
-		if (edgeTile) {
-#pragma unroll
-			for (int gi = 0; gi < 10; ++gi) gD[gi] = ((colok >> gi) & 1u) ? gD[gi] : 0;
-		}
-
-		// NMS + classification of row yo = yc-1 (rows gU = yo-1, gC = yo, gD = yo+1)
-		const int rr = yc - 1 - y0;
-		if (rr >= 0 && rr < kTileH) {
-			// Per-lane mask bytes instead of wave ballots: bit p of accNW = "pixel p is NOT weak", of accH = "g > tHigh", collected
-			// with one v_alignbit per pixel from the sign of a difference (pixels are visited 7..0 so that pixel 0 ends in bit 0).
-			uint32_t accNW = 0, accH = 0;
-#pragma unroll
-			for (int p = 7; p >= 0; --p) {
-				const int gi = p + 1;
-				const int gc = gC[gi];
-				// direction class (constants canny_dete.h:58-61: tan(pi/8), tan(3pi/8) in Q16; 158217 = 27145 + 2^17)
-				const uint32_t ax = (uint32_t)axr[aMid][p];
-				const uint32_t ays = ((uint32_t)gc - ax) << 16;               // |gy| << 16
-				const uint32_t t1 = __umul24(ax, 27145u);
-				const bool k1 = ays < t1;
-				const bool k2 = ays < t1 + (ax << 17);
-				// neighbour maxima with tLow+1 folded in (v_max3): weak = g > tLow && g >= m  <=>  g >= max(m, tLow+1)
-				const int mh = max3i(gC[gi - 1], gC[gi + 1], tLow1);
-				const int mv = max3i(gU[gi], gD[gi], tLow1);
-				const int md1 = max3i(gU[gi - 1], gD[gi + 1], tLow1);
-				const int md2 = max3i(gD[gi - 1], gU[gi + 1], tLow1);
-				int m = k1 ? mh : (k2 ? (ngr[aMid][p] ? md2 : md1) : mv);
-				if (GAP) m = ((cov >> p) & 1u) ? m : tLow1; // outside the NMS coverage (quirk Q3): thresholded only
-				accNW = __builtin_amdgcn_alignbit(accNW, (uint32_t)(gc - m), 31);     // sign(g - max(m, tLow+1)) = not weak
-				accH = __builtin_amdgcn_alignbit(accH, (uint32_t)(tHigh - gc), 31);   // sign(tHigh - g) = g > tHigh
-			}
-			const uint32_t wbyte = ~accNW & 0xffu;
-			uint32_t sbyte = wbyte & accH;
-			if (GAP) sbyte &= cov; // seeds are only scanned inside the coverage
-			uint8_t* mrow = reinterpret_cast<uint8_t*>(maskRows + rr * kMaskPitch);
-			mrow[lane] = (uint8_t)wbyte;        // row rr: 64 weak bytes (512 px in pixel order) ...
-			mrow[64 + lane] = (uint8_t)sbyte;   // ... then 64 strong bytes
-		}
-	};
-
-	{
-		// 5x5: plain rolled loop; phase 0 every step (new -> slot 0, centre = slot 2, old = slot 1), then shift the windows
-		for (int it = 0; it < kTileH + 2 + 2 * R; ++it) {
-			step(std::integral_constant<int, 0>{}, it);
-#pragma unroll
-			for (int gi = 0; gi < 10; ++gi) { gr[1][gi] = gr[2][gi]; gr[2][gi] = gr[0][gi]; }
-#pragma unroll
-			for (int p = 0; p < 8; ++p) { axr[1][p] = axr[0][p]; ngr[1][p] = ngr[0][p]; }
-		}
-	}
-
-	// lane == row: fetch this lane's row of masks (rows beyond the image are all-zero: g was forced to 0 there).  The rows are
-	// already in pixel order: dword k of a row = pixels 32k .. 32k+31.
-	uint64_t Wm[8], Em[8];
-	{
-		const uint32_t* mr = maskRows + lane * kMaskPitch;
-#pragma unroll
-		for (int m = 0; m < 8; ++m) {
-			Wm[m] = (uint64_t)mr[2 * m] | ((uint64_t)mr[2 * m + 1] << 32);
-			Em[m] = (uint64_t)mr[16 + 2 * m] | ((uint64_t)mr[16 + 2 * m + 1] << 32);
-		}
-	}
-
-	// ---- lane == row: flood strong into weak inside the tile ----
-	for (;;) {
-		flood_up(Wm, Em);
-		flood_down(Wm, Em);
-		bool changed = false;
-		uint64_t nb[8];
-#pragma unroll
-		for (int m = 0; m < 8; ++m) {
-			uint64_t up = __shfl_up(Em[m], 1);
-			uint64_t dn = __shfl_down(Em[m], 1);
-			if (lane == 0) up = 0;
-			if (lane == 63) dn = 0;
-			nb[m] = up | dn;
-		}
-#pragma unroll
-		for (int m = 0; m < 8; ++m) {
-			uint64_t n3 = nb[m] | (nb[m] << 1) | (nb[m] >> 1);
-			if (m > 0) n3 |= nb[m - 1] >> 63;
-			if (m < 7) n3 |= nb[m + 1] << 63;
-			const uint64_t add = Wm[m] & n3 & ~Em[m];
-			Em[m] |= add;
-			changed |= (add != 0);
-		}
-		if (!__any(changed)) break;
-	}
-
-	// ---- outputs ----
-	const int yrow = y0 + lane;
-	if (yrow < H) {
-		uint32_t* __restrict__ eb = a.ebits + (size_t)frame * a.bitsFrameStride + (size_t)yrow * a.wb + tileX * 16;
-		uint32_t* __restrict__ ub = a.ubits + (size_t)frame * a.bitsFrameStride + (size_t)yrow * a.wb + tileX * 16;
-#pragma unroll
-		for (int q = 0; q < 4; ++q) {
-			uint4 e, u;
-			e.x = (uint32_t)Em[2 * q]; e.y = (uint32_t)(Em[2 * q] >> 32);
-			e.z = (uint32_t)Em[2 * q + 1]; e.w = (uint32_t)(Em[2 * q + 1] >> 32);
-			const uint64_t u0 = Wm[2 * q] & ~Em[2 * q], u1 = Wm[2 * q + 1] & ~Em[2 * q + 1];
-			u.x = (uint32_t)u0; u.y = (uint32_t)(u0 >> 32); u.z = (uint32_t)u1; u.w = (uint32_t)(u1 >> 32);
-			reinterpret_cast<uint4*>(eb)[q] = e;
-			reinterpret_cast<uint4*>(ub)[q] = u;
-		}
-	}
-	// bytes: transpose back to lane == 8-pixel column group through LDS (wave-private rows, no barrier needed
-	// beyond the wave's own program order)
-#pragma unroll
-	for (int m = 0; m < 8; ++m) {
-		lds_masks[wave][lane][2 * m] = (uint32_t)Em[m];
-		lds_masks[wave][lane][2 * m + 1] = (uint32_t)(Em[m] >> 32);
-	}
-	__builtin_amdgcn_wave_barrier();
-	__builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): LDS writes of this wave have landed
-	uint8_t* __restrict__ out = a.out + (size_t)frame * a.outFrameStride;
-	const uint8_t* lb = reinterpret_cast<const uint8_t*>(&lds_masks[wave][0][0]);
-	if (x0 + 8 <= a.So) {
-		const int rows = min(kTileH, H - y0);
-		for (int r = 0; r < rows; ++r) {
-			const uint32_t b = lb[r * kMaskPitch * 4 + lane];
-			uint2 o;
-			o.x = spread4(b & 0xfu) * 0xffu;
-			o.y = spread4(b >> 4) * 0xffu;
-			*reinterpret_cast<uint2*>(out + (size_t)(y0 + r) * a.So + x0) = o;
-		}
-	}
-}
 
 // ---------------------------------------------------------------------------------------------------------------
 // Kernel 2: cross-tile hysteresis on the bit masks.  One workgroup = one band of kBandH rows x up to kBandWords
@@ -520,19 +246,12 @@ __global__ void mean_thresholds_kernel(const unsigned int* __restrict__ sums, in
 // ---------------------------------------------------------------------------------------------------------------
 // launchers
 // ---------------------------------------------------------------------------------------------------------------
-// Kernel size 3 runs the SWAR + candidate-list kernel of canny_swar_kernels.hip; this file's register-ring kernel serves kernel size 5.
-// Both write E (edges so far), U (weak, unresolved) and the edge bytes of E; canny_resolve_kernel finishes the hysteresis.
+// The SWAR + candidate-list kernel of canny_swar_kernels.hip writes E (strong seeds), U (weak, unresolved) and the edge bytes of E for both kernel
+// sizes; canny_resolve_kernel does the hysteresis.
 hipError_t launch_canny_tiles(const CannyArgs& a0, int frames, bool gap, hipStream_t stream)
 {
-	if (a0.ksize == 3) return launch_canny_tiles_swar(a0, frames, gap, stream);
-	CannyArgs a = a0;
-	a.blockRows = (a.tilesY + kCannyWaves - 1) / kCannyWaves;
-	a.groups = a.blockRows * frames;
-	dim3 grid(8 * ((a.groups + 7) / 8) * a.tilesX);
-	dim3 block(kCannyWaves * 64);
-	if (gap) hipLaunchKernelGGL((canny5_tile_kernel<true>), grid, block, 0, stream, a);
-	else hipLaunchKernelGGL((canny5_tile_kernel<false>), grid, block, 0, stream, a);
-	return hipGetLastError();
+	if (a0.ksize != 3 && a0.ksize != 5) return hipErrorInvalidValue;
+	return launch_canny_tiles_swar(a0, frames, gap, stream);
 }
 
 size_t canny_resolve_dirty_bytes(int H, int wb, int frames)

@@ -104,9 +104,23 @@ __device__ __forceinline__ uint32_t nibble_bytes(uint32_t nib)
 } // namespace
 
 // ---------------------------------------------------------------------------------------------------------------
-template <bool GAP, int WAVES, int kSwRows>
-__global__ __launch_bounds__(WAVES * 64, 8) void canny_swar_tile_kernel(CannyArgs a)
+// KS = 3: the 3x3 Sobel (compv_features.h:124-127).  KS = 5: the 5x5 Sobel (vt {1,4,6,4,1}, hz {1,2,0,-2,-1}: compv_features.h:129-130) in the same structure --
+// round 5; rounds 1-4 ran kernel size 5 on the first-generation kernel (32-bit arithmetic, 8 px per lane, dense NMS, in-tile flood: 0.50 ms per 32 x 4K).
+// The packed arithmetic carries over because the 5x5 gradient is linear and small enough for biased u16 halves: per input row the horizontal derivative
+// H1 = I[x-2] + 2 I[x-1] - 2 I[x+1] - I[x+2] (+1024) and smooth H2 = I[x-2] + 4 I[x-1] + 6 I[x] + 4 I[x+1] + I[x+2] (<= 4080) of a pixel pair, kept for four
+// rows in registers (ring indexed by the row loop's phase); gx = (1,4,6,4,1) . H1 down the column (+16384), gy = H2[y-2] + 2 H2[y-1] - 2 H2[y+1] - H2[y+2]
+// (+16383), |.| by v_pk_max_u16 as before, g' = g + 32768 (g <= 24480), aux = |gx| in bits 0..13 and the sign flag in bit 14 -- the same conventions as
+// the 3x3 path with wider fields, so the candidate list, the NMS, the flush and the hysteresis hand-over are shared.
+template <bool GAP, int WAVES, int kSwRows, int KS>
+__global__ __launch_bounds__(WAVES * 64, (KS == 3 ? 8 : 7)) void canny_swar_tile_kernel(CannyArgs a)
 {
+	static_assert(KS == 3 || KS == 5, "Sobel kernel size");
+	constexpr int R = KS / 2;                                  // width of the zero OUTPUT border of the gradient
+	constexpr uint32_t kG = (KS == 3) ? 2048u : 32768u;         // bias of g' (per half)
+	constexpr uint32_t kGpk = kG | (kG << 16);
+	constexpr uint32_t kAxMask = (KS == 3) ? 0x3ffu : 0x3fffu;  // |gx| field of the aux word; the sign flag is the bit above it
+	constexpr uint32_t kFlag = kAxMask + 1u;
+	constexpr uint32_t kFlagPk = kFlag | (kFlag << 16);
 	// the g rings of all waves first (2048-byte aligned), then the rest of each wave's block
 	__shared__ __attribute__((aligned(2048))) uint8_t lds_all[WAVES * kLdsBytes];
 
@@ -128,18 +142,18 @@ __global__ __launch_bounds__(WAVES * 64, 8) void canny_swar_tile_kernel(CannyArg
 
 	int tLow = a.tLow, tHigh = a.tHigh;
 	if (a.thrDev) { const int2 t = a.thrDev[frame]; tLow = t.x; tHigh = t.y; }
-	tLow = min(__builtin_amdgcn_readfirstlane(tLow), 4000);   // g <= 2040: larger thresholds select nothing
-	tHigh = min(__builtin_amdgcn_readfirstlane(tHigh), 8000);
-	const int tLowQ = tLow + 2048, tHighQ = tHigh + 2048;      // thresholds on g' = g + 2048
+	tLow = min(__builtin_amdgcn_readfirstlane(tLow), KS == 3 ? 4000 : 32767);   // g <= 2040 (24480): larger thresholds select nothing
+	tHigh = min(__builtin_amdgcn_readfirstlane(tHigh), KS == 3 ? 8000 : 32767);
+	const int tLowQ = tLow + (int)kG, tHighQ = tHigh + (int)kG;                  // thresholds on g' = g + bias
 
-	// g is forced to 0 (g' = 2048) outside columns [1, W-2]: zero OUTPUT border of the convolution (compv_math_convlt.h:181-209)
-	const bool edgeTile = (xbase < 1) || (xbase + 256 > W - 1);
+	// g is forced to 0 (g' = bias) outside columns [R, W-1-R]: zero OUTPUT border of the convolution (compv_math_convlt.h:181-209)
+	const bool edgeTile = (xbase < R) || (xbase + 256 > W - R);
 	uint32_t okm[2] = { 0xffffffffu, 0xffffffffu };
 	if (edgeTile) {
 #pragma unroll
 		for (int k = 0; k < 2; ++k) {
 			const int xa = x0 + 2 * k, xb = xa + 1;
-			okm[k] = ((xa >= 1 && xa <= W - 2) ? 0x0000ffffu : 0u) | ((xb >= 1 && xb <= W - 2) ? 0xffff0000u : 0u);
+			okm[k] = ((xa >= R && xa <= W - 1 - R) ? 0x0000ffffu : 0u) | ((xb >= R && xb <= W - 1 - R) ? 0xffff0000u : 0u);
 		}
 	}
 	// lanes 0, 1, 62, 63 own no pixels (column halo): their candidate threshold is out of reach
@@ -147,7 +161,7 @@ __global__ __launch_bounds__(WAVES * 64, 8) void canny_swar_tile_kernel(CannyArg
 	uint32_t thrV = owner ? (uint32_t)tLowQ : 0xffffu;
 	asm volatile("" : "+v"(thrV));
 	// tiles whose gradient rows touch the image border rows (g forced to 0 there) or run past the image
-	const bool vEdgeTile = (tileY == 0) || (y0 + kSwRows + 1 >= H - 1);
+	const bool vEdgeTile = (tileY == 0) || (y0 + kSwRows + 1 >= H - R);
 	const bool borderTile = edgeTile || vEdgeTile;
 
 	// mask geometry: local bits 8..247 are global columns [240 t, 240 t + 240): the tile starts at half-word 15 t of a mask row, i.e.
@@ -174,9 +188,10 @@ __global__ __launch_bounds__(WAVES * 64, 8) void canny_swar_tile_kernel(CannyArg
 	};
 
 	// rolling state: two pixels per register, pairs k = (x0 + 2k, x0 + 2k + 1)
-	uint32_t P[2] = { 0, 0 };              // d[y-2] + 2 d[y-1]   (bias 765)
-	uint32_t dprev[2] = { 0, 0 };          // d[y-1]              (bias 255)
-	uint32_t hy[2][2] = { { 0, 0 }, { 0, 0 } }; // horizontal smooth of rows y-1 / y-2 (ring)
+	uint32_t P[2] = { 0, 0 };              // 3x3: d[y-2] + 2 d[y-1]   (bias 765)
+	uint32_t dprev[2] = { 0, 0 };          //      d[y-1]              (bias 255)
+	uint32_t hy[2][2] = { { 0, 0 }, { 0, 0 } }; //  horizontal smooth of rows y-1 / y-2 (ring)
+	uint32_t h1[4][2] = {}, h2[4][2] = {}; // 5x5: H1 + 1024 and H2 of the last four input rows (ring: the row pushed at step it sits in slot it & 3)
 
 	// per-lane constants of the sparse stage
 	const uint32_t lane8 = (uint32_t)lane * 8u;            // byte offset of the lane's 4 u16 inside a ring row
@@ -185,14 +200,40 @@ __global__ __launch_bounds__(WAVES * 64, 8) void canny_swar_tile_kernel(CannyArg
 	zero_nibbles();
 	uint32_t listCount = 0;                // entries in the candidate list (wave-uniform)
 
-	uint32_t k255 = 0x00ff00ffu, k4 = 0x00040004u, k3ff = 0x03ff03ffu, k1 = 0x00010001u;
-	asm volatile("" : "+s"(k255), "+s"(k4), "+s"(k3ff), "+s"(k1));
+	uint32_t k255 = 0x00ff00ffu, k4 = 0x00040004u, k3ff = 0x03ff03ffu, k1 = 0x00010001u, k3fff = 0x3fff3fffu;
+	asm volatile("" : "+s"(k255), "+s"(k4), "+s"(k3ff), "+s"(k1), "+s"(k3fff));
+	// 5x5, per input row and pixel pair: H1 + 1024 = (I[x-2] + 2 I[x-1]) + 1023 - (2 I[x+1] + I[x+2]) + 1 and H2 = (I[x-2] + I[x+2]) + 4 (I[x-1] + I[x] + I[x+1]) + 2 I[x]
+	// from the five pairs at distances -2 .. +2 (every sum stays below 2^16: no carry between the halves)
+	auto hz5 = [&](uint32_t m2, uint32_t m1, uint32_t c0, uint32_t p1, uint32_t p2, uint32_t& H1, uint32_t& H2) {
+		const uint32_t pl = lshl1_add(m1, m2);                 // I[x-2] + 2 I[x-1]      (<= 765)
+		const uint32_t pr = lshl1_add(p1, p2);                 // I[x+2] + 2 I[x+1]
+		H1 = add3(pl, pr ^ 0x03ff03ffu, k1);                    // pl + (1023 - pr) + 1
+		const uint32_t t = (m1 + p1) + c0;
+		uint32_t u; asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(u) : "v"(t), "v"(m2 + p2));   // 4 t + I[x-2] + I[x+2]
+		H2 = lshl1_add(c0, u);
+	};
 
 	// input rows are fetched TWO steps ahead (two register sets that alternate: the row loop is unrolled by four).  With one row in flight per
 	// wave the kernel ran 12 % slower once its stores shared the memory pipeline with the loads (tools/canny_lab, round 4)
+	constexpr int E = (KS == 5) ? 1 : 0;   // step it takes input row y0 - 2 + E + it and yields gradient row y0 + it - 3
 	uint32_t nb[2][3];
-	load(y0 - 2, nb[0][0], nb[0][1], nb[0][2]);
-	load(y0 - 1, nb[1][0], nb[1][1], nb[1][2]);
+	if constexpr (KS == 5) {
+		// two more input rows above the tile than the 3x3 path streams: y0 - 3 and y0 - 2 only feed the row ring (slots 2 and 3: steps "-2" and "-1")
+		uint32_t w[2][3];
+		load(y0 - 3, w[0][0], w[0][1], w[0][2]);
+		load(y0 - 2, w[1][0], w[1][1], w[1][2]);
+#pragma unroll
+		for (int q = 0; q < 2; ++q) {
+			const uint32_t m = w[q][0], l = w[q][1], r = w[q][2];
+			const uint32_t a0 = __builtin_amdgcn_perm(0u, m, 0x0c010c00u), a1 = __builtin_amdgcn_perm(0u, m, 0x0c030c02u);     // (p0,p1) (p2,p3)
+			const uint32_t am = __builtin_amdgcn_perm(0u, l, 0x0c030c02u), ap = __builtin_amdgcn_perm(0u, r, 0x0c010c00u);     // (p-2,p-1) (p4,p5)
+			const uint32_t o0 = __builtin_amdgcn_perm(m, l, 0x0c040c03u), o1 = __builtin_amdgcn_perm(0u, m, 0x0c020c01u), o2 = __builtin_amdgcn_perm(r, m, 0x0c040c03u);   // (p-1,p0) (p1,p2) (p3,p4)
+			hz5(am, o0, a0, o1, a1, h1[2 + q][0], h2[2 + q][0]);
+			hz5(a0, o1, a1, o2, ap, h1[2 + q][1], h2[2 + q][1]);
+		}
+	}
+	load(y0 - 2 + E, nb[0][0], nb[0][1], nb[0][2]);
+	load(y0 - 1 + E, nb[1][0], nb[1][1], nb[1][2]);
 
 	// One row step: push input row yin = y0 - 2 + it  ->  gradient row yc = yin - 1 = y0 + (it - 3)  ->  ring slot (it - 3) & 3.
 	// After the steps with odd it >= 5 the rows 2j, 2j + 1 (j = (it - 5) / 2) of the tile have all three g rows of their neighbourhood
@@ -202,7 +243,7 @@ __global__ __launch_bounds__(WAVES * 64, 8) void canny_swar_tile_kernel(CannyArg
 		constexpr bool NMS = decltype(with_nms)::value;
 		constexpr int sNew = (PH + 1) & 3;                    // ring slot of the gradient row produced now
 		constexpr int aNew = (PH + 1) & 1;                    // its aux slot = its row parity
-		const int yin = y0 - 2 + it;
+		const int yin = y0 - 2 + E + it;
 		const uint32_t m = nb[PH & 1][0], l = nb[PH & 1][1], r = nb[PH & 1][2];
 		load(yin + 2, nb[PH & 1][0], nb[PH & 1][1], nb[PH & 1][2]); // prefetch
 
@@ -215,6 +256,30 @@ __global__ __launch_bounds__(WAVES * 64, 8) void canny_swar_tile_kernel(CannyArg
 		L[2] = __builtin_amdgcn_perm(r, m, 0x0c040c03u);      // (p3, p4)
 		uint32_t gq[2], aux[2];
 		uint32_t (&hyTop)[2] = hy[PH & 1]; // hy of row yin-2; overwritten with hy of row yin
+		if constexpr (KS == 5) {
+			const uint32_t am = __builtin_amdgcn_perm(0u, l, 0x0c030c02u), ap = __builtin_amdgcn_perm(0u, r, 0x0c010c00u);   // (p-2, p-1), (p4, p5)
+			// the row pushed now goes to ring slot PH (= it & 3), which held input row yin - 4; the rows yin - 3, yin - 2, yin - 1 sit in slots PH + 1, + 2, + 3
+			constexpr int s4 = PH & 3, s3 = (PH + 1) & 3, s2 = (PH + 2) & 3, s1 = (PH + 3) & 3;
+			uint32_t n1[2], n2[2];
+			hz5(am, L[0], A[0], L[1], A[1], n1[0], n2[0]);
+			hz5(A[0], L[1], A[1], L[2], ap, n1[1], n2[1]);
+#pragma unroll
+			for (int k = 0; k < 2; ++k) {
+				// gx + 16384 = (1, 4, 6, 4, 1) . (H1 + 1024) down rows yin - 4 .. yin;  gy + 16383 = (H2[yin-4] + 2 H2[yin-3]) + 16383 - (2 H2[yin-1] + H2[yin])
+				const uint32_t t = (h1[s3][k] + h1[s1][k]) + h1[s2][k];
+				uint32_t u; asm("v_lshl_add_u32 %0, %1, 2, %2" : "=v"(u) : "v"(t), "v"(h1[s4][k] + n1[k]));
+				const uint32_t gxb = lshl1_add(h1[s2][k], u);
+				const uint32_t ptop = lshl1_add(h2[s3][k], h2[s4][k]), pbot = lshl1_add(h2[s1][k], n2[k]);
+				const uint32_t gyb = xad(pbot, k3fff, ptop);
+				h1[s4][k] = n1[k]; h2[s4][k] = n2[k];
+				const uint32_t mx = pk_max_u16(gxb, 0x80008000u - gxb);    // |gx| + 16384
+				const uint32_t my = pk_max_u16(gyb, 0x7ffe7ffeu - gyb);    // |gy| + 16383
+				gq[k] = add3(mx, my, k1);                                  // g + 32768
+				aux[k] = bfi(kFlagPk, gxb ^ gyb, mx);                      // bits 0..13 |gx|, bit 14 = ((gx ^ gy) < 0), gy = 0 reading as negative (see below)
+			}
+			(void)hyTop;
+		}
+		else {
 #pragma unroll
 		for (int k = 0; k < 2; ++k) {
 			const uint32_t Lk = L[k], Rk = L[k + 1], Ck = A[k];
@@ -232,12 +297,13 @@ __global__ __launch_bounds__(WAVES * 64, 8) void canny_swar_tile_kernel(CannyArg
 			// (or has g = 0) and the sign only selects between the two diagonals
 			aux[k] = bfi(kBias1k, gxb ^ gyb, mx);                      // bits 0..9 |gx|, bit 10 = ((gx ^ gy) < 0)
 		}
-		const int yc = yin - 1;
+		}
+		const int yc = yin - R;
 		if (borderTile) { // one wave-uniform test per row; interior tiles skip all of it (the empty asm keeps the compiler from turning the branch into selects)
 			asm volatile("" : "+v"(gq[0]), "+v"(gq[1]));
-			const uint32_t rowm = (yc >= 1 && yc <= H - 2) ? 0xffffffffu : 0u; // image border rows (and rows past the image): g = 0
+			const uint32_t rowm = (yc >= R && yc <= H - 1 - R) ? 0xffffffffu : 0u; // image border rows (and rows past the image): g = 0
 #pragma unroll
-			for (int k = 0; k < 2; ++k) gq[k] = bfi(okm[k] & rowm, gq[k], kBias2k);
+			for (int k = 0; k < 2; ++k) gq[k] = bfi(okm[k] & rowm, gq[k], kGpk);
 		}
 		*reinterpret_cast<uint2*>(ring + sNew * kRowB + lane8) = make_uint2(gq[0], gq[1]);
 
@@ -262,13 +328,13 @@ __global__ __launch_bounds__(WAVES * 64, 8) void canny_swar_tile_kernel(CannyArg
 					const uint32_t eD = (e + (uint32_t)(sA * kRowB + kRowB)) & (4u * kRowB - 1u);       // row below
 					const int gc = *reinterpret_cast<const uint16_t*>(ring + sA * kRowB + e);
 					const uint32_t au = *reinterpret_cast<const uint16_t*>(rest + kAux + e);
-					const uint32_t ax = au & 0x3ffu;
-					const uint32_t ays = (uint32_t)(gc - 2048 - (int)ax) << 16;      // |gy| << 16
+					const uint32_t ax = au & kAxMask;
+					const uint32_t ays = (uint32_t)(gc - (int)kG - (int)ax) << 16;   // |gy| << 16
 					// direction class (constants canny_dete.h:58-61: tan(pi/8), tan(3pi/8) in Q16; 158217 = 27145 + 2^17)
 					const uint32_t t1 = __umul24(ax, 27145u);
 					const bool k1 = ays < t1;
 					const bool k2 = ays < t1 + (ax << 17);
-					const bool dg = k2 && ((au & 0x400u) != 0);
+					const bool dg = k2 && ((au & kFlag) != 0);
 					// neighbours along the gradient: k1 left / right; k2 diagonal ((gx^gy) < 0: (y+1,x-1),(y-1,x+1), else (y-1,x-1),(y+1,x+1)); else up / down,
 					// i.e. (X - d, Y + d) with (X, Y, d) = (C, C, 2) | (D, U, 2) | (U, D, 2) | (U, D, 0)
 					uint32_t X = dg ? eD : eU, Y = dg ? eU : eD;
@@ -396,7 +462,7 @@ __global__ __launch_bounds__(WAVES * 64, 8) void canny_swar_tile_kernel(CannyArg
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-template <int kWaves, int kRows>
+template <int kWaves, int kRows, int KS>
 static hipError_t launch_swar(const CannyArgs& a0, int frames, bool gap, hipStream_t stream)
 {
 	CannyArgs a = a0;
@@ -406,8 +472,8 @@ static hipError_t launch_swar(const CannyArgs& a0, int frames, bool gap, hipStre
 	a.groups = a.blockRows * frames;
 	dim3 grid(8 * ((a.groups + 7) / 8) * a.tilesX);
 	dim3 block(kWaves * 64);
-	if (gap) hipLaunchKernelGGL((canny_swar_tile_kernel<true, kWaves, kRows>), grid, block, 0, stream, a);
-	else hipLaunchKernelGGL((canny_swar_tile_kernel<false, kWaves, kRows>), grid, block, 0, stream, a);
+	if (gap) hipLaunchKernelGGL((canny_swar_tile_kernel<true, kWaves, kRows, KS>), grid, block, 0, stream, a);
+	else hipLaunchKernelGGL((canny_swar_tile_kernel<false, kWaves, kRows, KS>), grid, block, 0, stream, a);
 	return hipGetLastError();
 }
 
@@ -417,7 +483,8 @@ hipError_t launch_canny_tiles_swar(const CannyArgs& a0, int frames, bool gap, hi
 	// frames.  Measured per 32 x 4K launch (same run): 128 rows 0.232 ms, 64 rows 0.202 ms, 32 rows 0.192 ms, 16 / 24 rows the same as 32 within 1 % -- the
 	// 4-row halo costs 12.5 % more gradient rows than at 64 rows, but twice as many, shorter waves balance the SIMDs better at the end of
 	// the launch (a tile's time follows its candidate count).
-	return launch_swar<1, SWAR_ROWS>(a0, frames, gap, stream);
+	if (a0.ksize == 5) return launch_swar<1, SWAR_ROWS, 5>(a0, frames, gap, stream);
+	return launch_swar<1, SWAR_ROWS, 3>(a0, frames, gap, stream);
 }
 
 } // namespace COMPVHIP_SWAR_NS

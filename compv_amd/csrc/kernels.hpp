@@ -9,7 +9,6 @@
 namespace compvhip {
 
 // ---- Canny ------------------------------------------------------------------------------------------------
-constexpr int kCannyWaves = 4;        // waves (= 512x64 tiles, stacked vertically) per workgroup
 constexpr int kBandH = 64;            // rows per resolve band
 constexpr int kBandWords = 64;        // 32-px words per resolve chunk (2048 columns): 0.056 ms per step at 4K, 0.075 ms with 128
 constexpr int kResolveThreads = 512;
