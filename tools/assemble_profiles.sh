@@ -14,4 +14,6 @@ python "$R/tools/pmc_summary.py" "$P/pmc_FETCH_SIZE" "$P/pmc_WRITE_SIZE" "$P/pmc
 python "$R/tools/pmc_summary.py" "$P/pmc_kht_FETCH_SIZE" "$P/pmc_kht_WRITE_SIZE" > "$O/kht_pmc_counters_per_dispatch.txt" 2>&1
 python "$R/tools/traffic_from_pmc.py" "$P" "$O/traffic.json" > /dev/null
 [ -f "$P/bench_default_run.json" ] && cp "$P/bench_default_run.json" "$O/bench_default_run.json"
+# what overlaps what with two batches in flight: from the kernel traces of the two runs above
+python "$R/tools/overlap_from_trace.py" "$P"/stats/runc/*_kernel_trace.csv "$P"/stats_inflight1/runc/*_kernel_trace.csv > "$O/two_lane_overlap_table.md" 2>&1 || true
 echo "profiles/$TAG assembled"

@@ -6,8 +6,8 @@ set -u
 R=${GRAFT_REPO_ROOT:-$PWD}; TAG=${1:-run}; O="$R/gpurun_out/prof_$TAG"
 mkdir -p "$O"
 cd /tmp && export TMPDIR=/tmp
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats" -- python "$R/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-extras > "$O/bench_under_rocprof.log" 2>&1
-timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats_inflight1" -- python "$R/bench.py" --steps 10 --warmup 3 --no-cpu-baseline --no-extras --inflight 1 > "$O/bench_inflight1_under_rocprof.log" 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats" -- python "$R/bench.py" --steps 24 --warmup 4 --reps 1 --no-cpu-baseline --no-extras > "$O/bench_under_rocprof.log" 2>&1
+timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats_inflight1" -- python "$R/bench.py" --steps 24 --warmup 4 --reps 1 --no-cpu-baseline --no-extras --inflight 1 > "$O/bench_inflight1_under_rocprof.log" 2>&1
 timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$O/stats_kht" -- python "$R/tools/kht_bench.py" 5 > "$O/kht_under_rocprof.log" 2>&1
 for c in FETCH_SIZE WRITE_SIZE; do
   timeout 300 rocprofv3 --kernel-trace --pmc $c --output-format csv -d "$O/pmc_$c" -- python "$R/tools/calib_traffic.py" > "$O/pmc_$c.log" 2>&1

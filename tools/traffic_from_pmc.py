@@ -80,6 +80,19 @@ def main(prof_dir, out):
             "hbm_read_bytes": int(2 * f * 1024), "hbm_write_bytes": int(w * 1024), "hbm_bytes": int((2 * f + w) * 1024)}
     json.dump(res, open(out, "w"), indent=1, sort_keys=True)
     print(json.dumps(res["kernels"], indent=1))
+    # the single-frame KHT call (tools/kht_bench.py under the same two passes): HBM bytes of its kernels per call -> kht_traffic.json (bench.py: kht.roofline.traffic)
+    kf = mean_counter(os.path.join(prof_dir, "pmc_kht_FETCH_SIZE"), "FETCH_SIZE")
+    kw = mean_counter(os.path.join(prof_dir, "pmc_kht_WRITE_SIZE"), "WRITE_SIZE")
+    kk = {}
+    for k in sorted(set(kf) | set(kw)):
+        if "kht_" not in k and "bytes_to_bits" not in k:
+            continue
+        f, w = kf.get(k, 0.0), kw.get(k, 0.0)
+        kk[k.replace("compvhip::", "").split("<")[0]] = {"hbm_read_bytes": int(2 * f * 1024), "hbm_write_bytes": int(w * 1024), "hbm_bytes": int((2 * f + w) * 1024)}
+    if kk:
+        kres = {"workload": "tools/kht_bench.py: compvhip_houghkht_u8 on one 3840x2160 Canny(59,119) edge map, threshold 100", "units": "bytes per call (one launch of each kernel)",
+                "so_sha256": so, "kernels": kk, "hbm_bytes_per_call": sum(v["hbm_bytes"] for v in kk.values())}
+        json.dump(kres, open(os.path.join(os.path.dirname(out), "kht_traffic.json"), "w"), indent=1, sort_keys=True)
 
 
 if __name__ == "__main__":
