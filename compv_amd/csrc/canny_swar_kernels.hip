@@ -1,6 +1,7 @@
-// canny_swar_kernels.hip -- fused Sobel 3x3 -> NMS -> weak / strong classification for gfx950 (the kernel-size-3 Canny tile kernel).
+// canny_swar_kernels.hip -- fused Sobel (3x3 or 5x5) -> NMS -> weak / strong classification for gfx950: the Canny tile kernel.  The text below describes the
+// 3x3 instance; what differs for 5x5 is said at the kernel's template.
 //
-// Replaces (behind compvhip_canny_u8 / compvhip_plan_canny / compvhip_plan_pipeline, kernel size 3):
+// Replaces (behind compvhip_canny_u8 / compvhip_plan_canny / compvhip_plan_pipeline):
 //   CompVEdgeDeteCanny::process            core/features/edges/compv_core_feature_canny_dete.cxx:123-331
 //   nms_gather / nms_apply                 ...canny_dete.cxx:334-462, row leaves :566-616,
 //   CompVCannyNMSGatherRow_16mpw_Intrin_AVX2  core/features/edges/intrin/x86/compv_core_feature_canny_dete_intrin_avx2.cxx:150-235

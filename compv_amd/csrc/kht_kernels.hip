@@ -4,7 +4,7 @@
 //                     deviation from the chord while a half scores a better length / deviation ratio.  One wave = one string: lane 0
 //                     runs the recursion on an explicit stack in global memory (depth <= the number of clusters the string can have;
 //                     float64 with __ddiv_rn / __dsqrt_rn), all 64 lanes scan the points for the largest integer deviation.
-//                     kht_gather_clusters_kernel puts the strings' clusters into one list, in string order.
+//                     kht_gather_clusters_kernel (one workgroup per frame of the batch) puts the strings' clusters into one list per frame, in string order.
 //   kht_stats_kernel  voting_Algorithm2_Kernels + CompVHoughKhtKernelHeight_* + CompVMathEigen<double>::find2x2 (:849-1026,
 //                     base/math/compv_math_eigen.cxx:285-342): centroid, covariance, closed-form eigenvectors, rho, Eq. 14 terms and
 //                     the kernel height of every cluster.  One thread = one cluster: the float64 sums run in the reference's

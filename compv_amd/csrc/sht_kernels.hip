@@ -11,13 +11,14 @@
 //   accumulator     u16 [T][accPitch]      THETA-major (the reference is int32 rho-major [R][192]); written exactly once, 16-byte stores,
 //                                          no global atomics
 //   NMS flag planes u8  [T/8][rows]        bit j of byte (group, row) = column 8 group + j survives the 3x3 test and the threshold
-//   line keys/cells u32 + u32 [lineCap]    key = frameTag | strength, value = cell (row*T + col), in (row, col) order; one STABLE descending
-//                                          radix sort over all frames orders them by strength
+//   line keys/cells u32 + u32 [lineCap]    key = frameTag | strength, value = cell (row*T + col), in (row, col) order, the frames' lines one behind the
+//                                          other; ordered by strength by sht_sort_kernels.hip (sized on the device) or, for max(W, H) > 4095, by one
+//                                          STABLE descending library radix sort over the slots in use
 //
 // Voting: rho = (x*cosQ[t] + y*sinQ[t]) >> 16 (int32, arithmetic shift), acc[barrier - rho][t]++ for every edge and
 // every t -- E*T scattered increments, the whole cost of the reference's SHT: sht_tiles_kernels.hip (lane = theta over image tiles).
-// This file: foreign edge maps -> bit masks, sht_nms_kernel / sht_count_kernel / sht_lines_kernel, the key sort, sht_decode_kernel,
-// sht_cartesian_kernel, the accumulator export.
+// This file: foreign edge maps -> bit masks, sht_nms_kernel / sht_count_kernel / sht_lines_kernel, the library key sort + sht_decode_kernel (the
+// fallback of sht_sort_kernels.hip), sht_cartesian_kernel, the accumulator export.
 #include "kernels.hpp"
 
 #include <cstring>
