@@ -919,6 +919,44 @@ def test_plan_small_line_capacity_with_many_candidates(hip_ctx, oracle):
             plan.close()
 
 
+def test_plan_line_sort_over_several_chunks_with_an_empty_frame(hip_ctx, oracle):
+    """The device-sized line sort (sht_sort_kernels.hip): a frame whose lines fill several 4096-line chunks (the last one partly), a frame without a
+    single line between two that have some, a line capacity that is no multiple of the chunk and a maxLines cut inside a chunk -- every list against
+    the oracle's canonical order, element by element."""
+    import torch
+    from compv_amd import capi
+    W, H, n = 1024, 768, 4
+    bars = np.full((H, W), 90, np.uint8)                              # nine bars: strengths up to the bars' height, where the noise frames 0 and 2 stay near the threshold
+    for b in range(9):
+        bars[40:H - 40, 60 + 100 * b:63 + 100 * b] = 200
+    frames = np.stack([synth_frame(W, H, 777), np.full((H, W), 90, np.uint8), synth_frame(W, H, 778), bars])
+    dev = torch.device("cuda:0")
+    d_in = torch.from_numpy(frames).to(dev)
+    d_edges = torch.empty_like(d_in)
+    exp = []
+    for f in range(n):
+        rc, e = oracle.canny(frames[f], 0.8, 1.6)
+        exp.append(oracle.sht(e, 1.0, 12))
+    assert len(exp[0]) > 2 * 4096 and len(exp[0]) % 4096 != 0 and len(exp[1]) == 0 and len(exp[3]) > 4096
+    for cap, max_lines in ((70000, 0), (10000, 0), (10000, 5000), (4096, 4097)):
+        d_lines = torch.zeros((n, cap, 5), dtype=torch.int32, device=dev)
+        d_counts = torch.zeros(n, dtype=torch.int32, device=dev)
+        plan = capi.Plan(hip_ctx, W, H, W, n, 1.0)
+        try:
+            plan.pipeline(d_in.data_ptr(), 0.8, 1.6, 12, max_lines, d_edges.data_ptr(), d_lines.data_ptr(), cap, d_counts.data_ptr())
+            torch.cuda.synchronize()
+            raw = d_lines.cpu().numpy().view(np.uint8).reshape(n, cap, 20)
+            counts = d_counts.cpu().numpy()
+            for f in range(n):
+                assert int(counts[f]) == len(exp[f]), (cap, max_lines, f)
+                keep = min(cap, max_lines, len(exp[f])) if max_lines > 0 else min(cap, len(exp[f]))
+                if len(exp[f]) <= max(cap, 65536):                # (beyond the key capacity the kept subset is arbitrary: include/compv_hip.h)
+                    rec = np.frombuffer(raw[f].tobytes(), dtype=capi.LINE_DTYPE)[:keep]
+                    assert _lines_tuple(rec) == _orc_tuple(exp[f][:keep]), (cap, max_lines, f)
+        finally:
+            plan.close()
+
+
 def test_houghsht_dense_local_maxima_past_the_lds_stage(hip_ctx, oracle):
     """sht_lines_kernel stages up to 512 (key, cell) pairs of a 64-row block in the LDS and stores denser blocks directly: a 2 % random
     edge map with threshold 1 has up to ~1600 local maxima per block (and blocks on both sides of the limit)."""
@@ -1177,6 +1215,38 @@ def test_bench_batches_match_the_reference_fixture(hip_ctx):
     finally:
         for q in lanes:
             q["plan"].close()
+
+
+def test_plan_houghkht_several_groups_in_flight(hip_ctx, oracle):
+    """compvhip_plan_houghkht puts its frames through the stages in groups of 8, up to four groups at a time (own controller thread, stream and buffers
+    each): 19 frames = groups of 8, 8 and 3 -- with 12 host threads three controllers, with 5 one, with 32 four -- every frame's line list (values and
+    order) and GS against the oracle; an empty frame sits in the middle of a group."""
+    import torch
+    from compv_amd import capi
+    W, H, F = 640, 480, 19
+    dev = torch.device("cuda:0")
+    frames = np.stack([synth_frame(W, H, 4000 + f) for f in range(F)])
+    frames[10] = 31
+    d_in = torch.from_numpy(frames).to(dev)
+    d_e = torch.empty_like(d_in)
+    plan = capi.Plan(hip_ctx, W, H, W, F, 1.0)
+    try:
+        plan.canny(d_in.data_ptr(), 59.0, 119.0, d_e.data_ptr())
+        torch.cuda.synchronize()
+        exp = []
+        for f in range(F):
+            rc, e = oracle.canny(frames[f], 59.0, 119.0)
+            exp.append(oracle.kht(e, 1.0, 1.0, 20))
+        assert sum(len(el) for el, _ in exp) > 0
+        for threads in (12, 5, 32):
+            lines, gs = plan.houghkht(d_e.data_ptr(), 1.0, 1.0, 20, threads=threads)
+            for f in range(F):
+                el, egs = exp[f]
+                assert _kht_tuple(lines[f]) == [(float(np.float32(l[0])), float(np.float32(l[1])), int(l[2])) for l in el], (threads, f)
+                assert (gs[f] == egs) if len(el) else (gs[f] is None), (threads, f)
+        assert len(lines[10]) == 0
+    finally:
+        plan.close()
 
 
 def test_plan_houghkht_batch(hip_ctx, oracle, golden):
