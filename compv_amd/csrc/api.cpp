@@ -156,7 +156,7 @@ struct compvhip_plan {
 	void* sortTemp = nullptr; size_t sortTempBytes = 0;
 	int strengthBits = 16, keyBits = 0;
 	// the line sort sized on the device (sht_sort_kernels.hip): used when a strength has at most 13 bits and a frame at most 32 chunks of keys
-	uint16_t* chunkHist = nullptr; uint32_t* chunkStart = nullptr; int sortChunks = 0; bool deviceSort = false;
+	uint16_t* chunkHist = nullptr; uint32_t* strengthStart = nullptr; int sortChunks = 0; bool deviceSort = false;
 	// voting over image tiles (planned at plan creation: the per-tile edge counters live in `counters`)
 	bool voteTiles = false;                      // the tile grid exists
 	ShtTileArgs vt = {};                         // geometry + device tables
@@ -542,7 +542,7 @@ int ensureLineCap(compvhip_plan* p, size_t cap)
 	compvhip_ctx* ctx = p->ctx;
 	cap = std::min(cap, p->R * p->T);
 	if (cap <= p->lineCap) return COMPVHIP_OK;
-	dfree(ctx, p->keysA); dfree(ctx, p->keysB); dfree(ctx, p->valsA); dfree(ctx, p->valsB); dfree(ctx, p->sortTemp); dfree(ctx, p->chunkHist); dfree(ctx, p->chunkStart);
+	dfree(ctx, p->keysA); dfree(ctx, p->keysB); dfree(ctx, p->valsA); dfree(ctx, p->valsB); dfree(ctx, p->sortTemp); dfree(ctx, p->chunkHist); dfree(ctx, p->strengthStart);
 	p->lineCap = 0; p->deviceSort = false;
 	HIPCHK(ctx, dmalloc(ctx, &p->keysA, cap * p->frames));
 	HIPCHK(ctx, dmalloc(ctx, &p->keysB, cap * p->frames));
@@ -558,7 +558,7 @@ int ensureLineCap(compvhip_plan* p, size_t cap)
 	p->sortChunks = static_cast<int>((cap + kShtSortChunk - 1) / kShtSortChunk);
 	if (p->strengthBits <= kShtSortMaxStrengthBits && p->sortChunks <= kShtSortMaxChunks) {
 		HIPCHK(ctx, dmalloc(ctx, &p->chunkHist, p->frames * static_cast<size_t>(p->sortChunks) << kShtSortMaxStrengthBits));
-		HIPCHK(ctx, dmalloc(ctx, &p->chunkStart, p->frames * static_cast<size_t>(p->sortChunks) << kShtSortMaxStrengthBits));
+		HIPCHK(ctx, dmalloc(ctx, &p->strengthStart, p->frames << kShtSortMaxStrengthBits));
 		p->deviceSort = true;
 	}
 	p->lineCap = cap;
@@ -933,7 +933,7 @@ void compvhip_plan_destroy(compvhip_plan* p)
 	dfree(ctx, p->cosT); dfree(ctx, p->invSinT);
 	dfree(ctx, p->dKt); dfree(ctx, p->dRowBase); dfree(ctx, p->partLo); dfree(ctx, p->partHi); dfree(ctx, p->colFlag);
 	dfree(ctx, p->sinQ); dfree(ctx, p->cosQ); dfree(ctx, p->edges); dfree(ctx, p->acc);
-	dfree(ctx, p->keysA); dfree(ctx, p->keysB); dfree(ctx, p->valsA); dfree(ctx, p->valsB); dfree(ctx, p->nmsFlags); dfree(ctx, p->chunkHist); dfree(ctx, p->chunkStart);
+	dfree(ctx, p->keysA); dfree(ctx, p->keysB); dfree(ctx, p->valsA); dfree(ctx, p->valsB); dfree(ctx, p->nmsFlags); dfree(ctx, p->chunkHist); dfree(ctx, p->strengthStart);
 	dfree(ctx, p->nmsRange); dfree(ctx, p->reach); dfree(ctx, p->sortTemp);
 	delete p;
 }
@@ -1140,7 +1140,7 @@ static int planShtImpl(compvhip_plan* p, const uint8_t* d_edges, int threshold, 
 		if (d_lines && lineCap) {
 			Stamp s(p, st, "sht_sort_lines");
 			ShtSortArgs q;
-			q.sortedKeys = p->keysB; q.sortedVals = p->valsB; q.chunkHist = p->chunkHist; q.chunkStart = p->chunkStart; q.chunks = p->sortChunks;
+			q.sortedKeys = p->keysB; q.sortedVals = p->valsB; q.chunkHist = p->chunkHist; q.strengthStart = p->strengthStart; q.chunks = p->sortChunks;
 			HIPCHK(ctx, launch_sht_sort_lines(a, q, frames, p->thetaStep, maxLines, d_lines, lineCap, st));
 		}
 		if (d_counts) HIPCHK(ctx, hipMemcpyAsync(d_counts, p->lineCounts, sizeof(int32_t) * frames, hipMemcpyDeviceToDevice, st));

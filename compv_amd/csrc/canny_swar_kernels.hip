@@ -48,7 +48,7 @@
 #define COMPVHIP_SWAR_NS compvhip
 #endif
 #ifndef SWAR_ROWS
-#define SWAR_ROWS 32
+#define SWAR_ROWS 24
 #endif
 
 namespace COMPVHIP_SWAR_NS {
@@ -480,10 +480,10 @@ static hipError_t launch_swar(const CannyArgs& a0, int frames, bool gap, hipStre
 
 hipError_t launch_canny_tiles_swar(const CannyArgs& a0, int frames, bool gap, hipStream_t stream)
 {
-	// One wave per workgroup (every LDS address of the kernel is lane * k + constant), 32 rows per wave tile: 68 704 workgroups for 32 4K
-	// frames.  Measured per 32 x 4K launch (same run): 128 rows 0.232 ms, 64 rows 0.202 ms, 32 rows 0.192 ms, 16 / 24 rows the same as 32 within 1 % -- the
-	// 4-row halo costs 12.5 % more gradient rows than at 64 rows, but twice as many, shorter waves balance the SIMDs better at the end of
-	// the launch (a tile's time follows its candidate count).
+	// One wave per workgroup (every LDS address of the kernel is lane * k + constant), 24 rows per wave tile.  Per 32 x 4K launch 128 / 64 / 32 rows took
+	// 0.232 / 0.202 / 0.192 ms (round 3), 24 .. 40 rows are within 1.5 % of each other there -- the 4-row halo costs more gradient rows on shorter tiles, but
+	// more, shorter waves balance the SIMDs better at the end of the launch (a tile's time follows its candidate count).  Smaller frames decide: 32 x 1080p is
+	// 8 704 waves of 32 rows on 8 192 wave slots -- 24 rows: 0.953 of the 32-row kernel at 1080p, 0.934 at 720p, 0.991 at 4K (tools/canny_lab, round 5).
 	if (a0.ksize == 5) return launch_swar<1, SWAR_ROWS, 5>(a0, frames, gap, stream);
 	return launch_swar<1, SWAR_ROWS, 3>(a0, frames, gap, stream);
 }

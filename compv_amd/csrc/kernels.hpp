@@ -163,7 +163,7 @@ struct ShtSortArgs {
 	uint32_t* sortedKeys;     // [frames * lineCap] per line of a sorted chunk: (inverted strength << 12) | rank inside its run of equal strengths
 	uint32_t* sortedVals;     // [frames * lineCap] its accumulator cell
 	uint16_t* chunkHist;      // [frames][chunks][8192] lines per inverted strength of a chunk (written whole by the chunks that have lines)
-	uint32_t* chunkStart;     // [frames][chunks][8192] first slot, in the frame's sorted line list, of the lines of a chunk with that inverted strength
+	uint32_t* strengthStart;  // [frames][8192] first slot of an inverted strength in the frame's sorted line list
 	int chunks;               // chunks per frame = ceil(lineCap / 4096)
 };
 hipError_t launch_sht_sort_lines(const ShtArgs& a, const ShtSortArgs& q, int frames, float thetaStep, int maxLines, void* lines /*compvhip_line*/, size_t outCap,

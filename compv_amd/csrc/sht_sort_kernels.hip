@@ -11,9 +11,8 @@
 // device: the three launches cover the capacity, a chunk without lines returns at once.
 //   1. sht_chunk_sort_kernel   one workgroup per chunk: stable sort of the chunk's keys in the LDS; per line its rank inside its run of equal strengths
 //                              (lower bound by binary search), the chunk's strength histogram (u16 [8192], written whole: nothing to clear)
-//   2. sht_strength_scan_kernel  one workgroup per frame: lines per strength over the frame's chunks, exclusive scan in descending strength order, and from
-//                              it the first slot of every (chunk, strength): start[strength] + the lines of that strength in the frame's earlier chunks
-//   3. sht_place_lines_kernel  one thread per line: slot = first slot of its (chunk, strength) + rank; the slot's
+//   2. sht_strength_scan_kernel  one workgroup per frame: lines per strength over the frame's chunks, exclusive scan in descending strength order
+//   3. sht_place_lines_kernel  one thread per line: slot = start[strength] + lines of that strength in the frame's earlier chunks + rank; the slot's
 //                              compvhip_line is written directly (rho, theta, strength, row, col: what sht_decode_kernel did behind the library sort)
 // Larger strengths (max(W, H) > 4095) or line capacities beyond 32 chunks per frame keep the library sort (sht_kernels.hip).
 #include "kernels.hpp"
@@ -218,25 +217,9 @@ __global__ __launch_bounds__(kSortThreads) void sht_strength_scan_kernel(ShtArgs
 #pragma unroll
 	for (int w = 0; w < kSortThreads / 64; ++w) before += (w < wave) ? s_wave[w] : 0u;
 	const uint32_t excl = before + incl - sum;
-	// first slot of (chunk, inverted strength) = first slot of the strength in the frame + its lines in the earlier chunks (the histograms are read a second time, from the L2)
-	uint32_t run[8];
-#pragma unroll
-	for (int u = 0; u < 8; ++u) run[u] = excl + tot[u];
-	uint4* __restrict__ out = reinterpret_cast<uint4*>(q.chunkStart + (size_t)frame * q.chunks * kBins) + 2 * t;
-	for (int c0 = 0; c0 < nch; c0 += 4) {
-		uint4 v[4];
-#pragma unroll
-		for (int u = 0; u < 4; ++u) v[u] = h[(size_t)min(c0 + u, nch - 1) * (kBins / 8)];
-#pragma unroll
-		for (int u = 0; u < 4; ++u) {
-			const int c = c0 + u;
-			if (c < nch) {
-				out[(size_t)c * (kBins / 4)] = make_uint4(run[0], run[1], run[2], run[3]);
-				out[(size_t)c * (kBins / 4) + 1] = make_uint4(run[4], run[5], run[6], run[7]);
-				add8(run, v[u]);
-			}
-		}
-	}
+	uint4* __restrict__ out = reinterpret_cast<uint4*>(q.strengthStart + (size_t)frame * kBins) + 2 * t;
+	out[0] = make_uint4(excl + tot[0], excl + tot[1], excl + tot[2], excl + tot[3]);
+	out[1] = make_uint4(excl + tot[4], excl + tot[5], excl + tot[6], excl + tot[7]);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -256,7 +239,17 @@ __global__ __launch_bounds__(256) void sht_place_lines_kernel(ShtArgs a, ShtSort
 	const uint32_t kv = q.sortedKeys[base + i];
 	const uint32_t inv = kv >> 12, rank = kv & 4095u;
 	const int c = (int)(i >> 12);
-	const size_t pos = (size_t)q.chunkStart[((size_t)frame * q.chunks + c) * kBins + inv] + rank;
+	// slot = first slot of the strength in the frame + its lines in the frame's earlier chunks + rank inside the chunk.  (Per-chunk starts written by the scan
+	// kernel instead: 15 MB more traffic from 32 workgroups, 20 + 16 us against 8 + 18 for this loop at 4K.)  Four histograms in flight, clamped loads.
+	size_t pos = (size_t)q.strengthStart[(size_t)frame * kBins + inv] + rank;
+	const uint16_t* __restrict__ h = q.chunkHist + (size_t)frame * q.chunks * kBins + inv;
+	for (int c0 = 0; c0 < c; c0 += 4) {
+		uint32_t v[4];
+#pragma unroll
+		for (int u = 0; u < 4; ++u) v[u] = h[(size_t)min(c0 + u, c) * kBins];   // chunk c itself is a valid address (its histogram exists): masked below
+#pragma unroll
+		for (int u = 0; u < 4; ++u) pos += (c0 + u < c) ? v[u] : 0u;
+	}
 	if (pos >= limit) return;
 	const uint32_t cell = q.sortedVals[base + i];
 	const int row = (int)(cell / (uint32_t)a.T), col = (int)(cell - (uint32_t)row * (uint32_t)a.T);

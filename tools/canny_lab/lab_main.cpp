@@ -1,6 +1,6 @@
 // canny_lab -- experiment harness (not part of the product): times variants of the kernel-size-3 Canny tile kernel on the benchmark's
 // 32 x 4K frames and compares their outputs (E / U masks, edge bytes) with variant 0 bit for bit.
-//   build: tools/canny_lab/build.sh      run: tools/canny_lab/canny_lab [frames] [reps]
+//   build: tools/canny_lab/build.sh      run: tools/canny_lab/canny_lab [frames] [reps] [W H]
 #include "../../compv_amd/csrc/kernels.hpp"
 #include <cstdio>
 #include <cstdlib>
@@ -30,9 +30,9 @@ static void synth(uint8_t* out, int W, int H, uint32_t seed)
 
 int main(int argc, char** argv)
 {
-	const int W = 3840, H = 2160, S = W;
 	const int frames = argc > 1 ? atoi(argv[1]) : 32;
 	const int reps = argc > 2 ? atoi(argv[2]) : 20;
+	const int W = argc > 4 ? atoi(argv[3]) : 3840, H = argc > 4 ? atoi(argv[4]) : 2160, S = W;   // canny_lab frames reps [W H]  (W % 8 == 0)
 	const int tilesX512 = (W + 511) / 512;
 	const int wb = tilesX512 * 16;
 	const size_t bitsStride = (size_t)wb * H;
@@ -58,8 +58,6 @@ int main(int argc, char** argv)
 		float ms; CK(hipEventElapsedTime(&ms, e0, e1));
 		printf("device copy of %zu MB: %.4f ms (%.2f TB/s read+write)\n", h.size() >> 20, ms / 10, 2.0 * h.size() / (ms / 10 * 1e-3) / 1e12);
 	}
-	const int rounds = argc > 3 ? atoi(argv[3]) : 3;
-	(void)rounds;
 	// pass 1: outputs of every variant against variant 0
 	for (int v = 0; v < nv; ++v) {
 		CK(hipMemset(dout, 0xAA, h.size())); CK(hipMemset(de, 0, bitsStride * frames * 4)); CK(hipMemset(du, 0, bitsStride * frames * 4));
