@@ -683,8 +683,15 @@ int validateCannyParams(compvhip_ctx* ctx, float tLow, float tHigh, int ksize, i
 
 // ==================================================================================================================
 namespace {
-// helper threads of ONE call: run(n, fn) executes fn(0) .. fn(n - 1), the frames handed out one at a time, the caller working along
+// helper threads of ONE call: run(n, fn) executes fn(0) .. fn(n - 1), the frames handed out one at a time, the caller working along.
+// Every run has its own Job object: a helper that is still leaving the previous job when the next one is posted only ever touches the counters of the
+// job it picked up (with shared counters it could take an index of the old job, compare it with the new job's size and run an item twice).
 class KhtPool {
+	struct Job {
+		const std::function<void(size_t)>* fn; size_t n;
+		std::atomic<size_t> next{0}, left;
+		Job(const std::function<void(size_t)>* f, size_t count) : fn(f), n(count), left(count) {}
+	};
 public:
 	explicit KhtPool(size_t threads)
 	{
@@ -700,40 +707,42 @@ public:
 	void run(size_t n, const std::function<void(size_t)>& fn)
 	{
 		if (!n) return;
-		{ std::lock_guard<std::mutex> g(m_); fn_ = &fn; n_ = n; next_.store(0); left_.store(n); ++gen_; }
+		std::shared_ptr<Job> job = std::make_shared<Job>(&fn, n);
+		{ std::lock_guard<std::mutex> g(m_); cur_ = job; ++gen_; }
 		cv_.notify_all();
-		work();
+		work(*job);
 		std::unique_lock<std::mutex> lk(m_);
-		done_.wait(lk, [this] { return left_.load() == 0; });
-		fn_ = nullptr;
+		done_.wait(lk, [&] { return job->left.load() == 0; });   // every item has RETURNED: fn may go out of scope
+		cur_.reset();
 	}
 private:
-	void work()
+	void work(Job& job)
 	{
 		for (;;) {
-			const size_t i = next_.fetch_add(1);
-			if (i >= n_) return;
-			(*fn_)(i);
-			if (left_.fetch_sub(1) == 1) { std::lock_guard<std::mutex> g(m_); done_.notify_all(); }
+			const size_t i = job.next.fetch_add(1);
+			if (i >= job.n) return;
+			(*job.fn)(i);
+			if (job.left.fetch_sub(1) == 1) { std::lock_guard<std::mutex> g(m_); done_.notify_all(); }
 		}
 	}
 	void loop()
 	{
 		unsigned long seen = 0;
 		for (;;) {
+			std::shared_ptr<Job> job;
 			{
 				std::unique_lock<std::mutex> lk(m_);
 				cv_.wait(lk, [&] { return gen_ != seen; });
 				seen = gen_;
 				if (quit_) return;
+				job = cur_;
 			}
-			work();
+			if (job) work(*job);
 		}
 	}
 	std::vector<std::thread> pool_;
 	std::mutex m_; std::condition_variable cv_, done_;
-	const std::function<void(size_t)>* fn_ = nullptr; size_t n_ = 0;
-	std::atomic<size_t> next_{0}, left_{0};
+	std::shared_ptr<Job> cur_;
 	unsigned long gen_ = 0; bool quit_ = false;
 };
 
@@ -2216,6 +2225,7 @@ int compvhip_plan_houghkht(compvhip_plan* p, const uint8_t* d_edges, float rho, 
 		memset(B.stageMs, 0, sizeof(B.stageMs));
 	}
 	for (size_t f = 0; f < F; ++f) counts[f] = 0;
+	try {   // nothing may leave an extern "C" entry point as an exception (the vectors below allocate)
 	const auto wall0 = std::chrono::steady_clock::now();
 	std::atomic<size_t> nextGroup{0};
 	std::vector<int> codes(K, COMPVHIP_OK);
@@ -2254,6 +2264,9 @@ int compvhip_plan_houghkht(compvhip_plan* p, const uint8_t* d_edges, float rho, 
 	for (size_t k = 0; k < K; ++k)
 		if (codes[k]) return fail(ctx, codes[k], ("frames from " + std::to_string(badGroup[k]) + ": " + errs[k]).c_str());
 	if (overflowAny.load()) return fail(ctx, COMPVHIP_E_OUT_OF_BOUND, "line buffer too small");
+	}
+	catch (const std::exception& ex) { return fail(ctx, COMPVHIP_E_OUT_OF_MEMORY, (std::string("exception in the batched KHT: ") + ex.what()).c_str()); }
+	catch (...) { return fail(ctx, COMPVHIP_E_OUT_OF_MEMORY, "exception in the batched KHT"); }
 	return COMPVHIP_OK;
 }
 
