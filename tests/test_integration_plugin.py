@@ -117,3 +117,24 @@ def test_cxx_multi_gpu_batch_driver_refuses_missing_peers():
     want = torch.cuda.device_count() + 1
     r = subprocess.run([MGB, "--devices", str(want), "--frames-per-device", "1", "--steps", "1"], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
     assert r.returncode == 3 and ("only %d HIP device" % (want - 1)) in r.stderr, (r.returncode, r.stderr[-500:])
+
+
+@pytest.mark.gpu
+def test_bench_refuses_a_rank_without_a_gpu():
+    """The first N > 1 bench run will be the driver's, unattended: a rank whose LOCAL_RANK has no GPU must end the job with a message that names both numbers
+    (on a node that does have the GPUs the same command is a normal two-rank run)."""
+    import json
+    import sys
+    import torch
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", "29621",
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--reps", "1", "--frames-per-gpu", "2", "--batches", "2",
+           "--width", "1280", "--height", "720", "--no-cpu-baseline", "--no-extras"]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    if torch.cuda.device_count() >= 2:
+        assert r.returncode == 0, r.stderr[-3000:]
+        res = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+        assert res["n_gpus"] == 2 and res["ranks_seen"] == [0, 1] and res["dist_backend"] == "nccl"
+    else:
+        assert r.returncode != 0
+        assert "wants cuda:1 but this node shows 1 GPU" in (r.stderr + r.stdout), r.stderr[-2000:]
