@@ -1,6 +1,7 @@
 """Randomised parity sweep of the DEVICE-RESIDENT plan API (GPU box): batches of random size / stride / content through compvhip_plan_pipeline
 (synchronous and asynchronous, kernel sizes 3 / 5, the three threshold modes, a line cut), compvhip_plan_houghkht with random knobs, and the host KHT
-entry point with random knobs -- every frame against the oracle.   python tools/fuzz_plan.py [cases] [seed]"""
+entry point with random knobs -- every frame against the oracle.   python tools/fuzz_plan.py [cases] [seed] [many]
+("many": batches of 9..40 small frames, KHT on every case with 0 / 8 / 32 host threads: several groups of 8 frames and several group controllers)"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -10,6 +11,7 @@ from oracle_bindings import Oracle, synth_frame
 
 cases = int(sys.argv[1]) if len(sys.argv) > 1 else 60
 rng = np.random.RandomState(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+many = len(sys.argv) > 3 and sys.argv[3] == "many"
 dev = torch.device("cuda", 0)
 ctx = capi.Context(0); orc = Oracle()
 bad = 0
@@ -25,9 +27,10 @@ def image(W, H):
 
 
 for k in range(cases):
-    big = rng.rand() < 0.15
+    big = (not many) and rng.rand() < 0.15
     W = int(rng.randint(1200, 4000)) if big else int(rng.randint(8, 1100)); H = int(rng.randint(300, 2200)) if big else int(rng.randint(8, 500))
-    S = (W + 7) // 8 * 8 + 8 * int(rng.randint(0, 3)); F = 1 if big else int(rng.randint(1, 5)); cap = 1 << 15
+    S = (W + 7) // 8 * 8 + 8 * int(rng.randint(0, 3)); F = 1 if big else int(rng.randint(9, 41)) if many else int(rng.randint(1, 5)); cap = 1 << 15
+    if many: W = int(rng.randint(40, 420)); H = int(rng.randint(40, 300)); S = (W + 7) // 8 * 8 + 8 * int(rng.randint(0, 3)); cap = 1 << 12
     frames = np.zeros((F, H, S), np.uint8)
     imgs = [synth_frame(W, H, int(rng.randint(1, 1 << 30))) if big else image(W, H) for _ in range(F)]   # big frames: structured content only (the ORACLE needs minutes on megapixels of noise)
     for f in range(F): frames[f, :, :W] = imgs[f]; frames[f, :, W:] = rng.randint(0, 256, (H, S - W))   # garbage in the stride padding
@@ -73,10 +76,10 @@ for k in range(cases):
                 gs_ = [int(l["strength"]) for l in got]; es_ = [l[2] for l in el[:n]]
                 if gs_ != es_: what.append("frame %d strongest lines: %d lines, got %r expected %r" % (f, len(el), gs_[:6], es_[:6]))
         # batched KHT on the edge maps just produced, random knobs
-        if not what and not big and rng.rand() < 0.5 and W >= 32 and H >= 32:
+        if not what and not big and (many or rng.rand() < 0.5) and W >= 32 and H >= 32:
             rho = float(rng.choice([1.0, 0.5])); kd = float(rng.choice([1.0, 0.5, 2.0])); kthr = int(rng.choice([1, 1, 50])); mdev = float(rng.choice([2.0, 0.5, 4.0]))
             msz = int(rng.choice([10, 2, 5, 25])); mh = float(rng.choice([0.002, 0.0, 0.05]))
-            lines, gss = plan.houghkht(d_e.data_ptr(), rho, kd, kthr, 0, mdev, msz, mh, threads=int(rng.choice([0, 1, 3])))
+            lines, gss = plan.houghkht(d_e.data_ptr(), rho, kd, kthr, 0, mdev, msz, mh, threads=int(rng.choice([0, 8, 32] if many else [0, 1, 3])))
             for f in range(F):
                 ek, gs_e = orc.kht(np.ascontiguousarray(exp_edges[f]), rho, kd, kthr, 0, mdev, msz, mh)
                 gt = [(float(l["rho"]), float(l["theta"]), int(l["strength"])) for l in lines[f]]
