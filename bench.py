@@ -1,7 +1,10 @@
 #!/usr/bin/env python
 """bench.py -- Mpixels/s of Sobel -> Canny -> HoughSHT on batches of synthetic 4K uint8 frames (BASELINE.json metric).
 
-    python bench.py --gpus N --steps K --warmup W          (N > 1: launched by torch.distributed.run, one rank per GPU)
+    python bench.py --gpus N --steps K --warmup W
+        N > 1: one rank per GPU.  Under a launcher (torch.distributed.run sets WORLD_SIZE / RANK / LOCAL_RANK) --gpus must equal the world size;
+        a BARE `python bench.py --gpus N` starts its own N ranks (torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+        --master-port <free>) and prints rank 0's JSON line as its only stdout line.
 
 One "step" = one pass of the whole hot path (compvhip_plan_pipeline_async: fused Sobel+NMS, hysteresis rounds, edge compaction, Hough
 voting, Hough NMS, line sort/decode) over ONE batch of FRAMES_PER_GPU frames already resident in HBM.  The job holds BASELINE config 4's
@@ -143,6 +146,15 @@ def host_cpu_budget():
     return out
 
 
+def effective_cpus():
+    """CPUs this process can really run on at once: min(affinity mask, cgroup quota)."""
+    b = host_cpu_budget()
+    n = b.get("sched_affinity") or b["logical_cpus"]
+    if b.get("cgroup_cpus"):
+        n = min(n, max(1, int(b["cgroup_cpus"])))
+    return int(n)
+
+
 def frame_parallel_baseline(W, H, threads_per_proc, cores, work_s=4.0, procs=None, task="pipeline"):
     """P processes x T threads over independent frames, all released together (barrier); every worker processes frames for work_s seconds."""
     import multiprocessing as mp
@@ -163,7 +175,9 @@ def frame_parallel_baseline(W, H, threads_per_proc, cores, work_s=4.0, procs=Non
         raise RuntimeError("frame-parallel worker failed: %s" % bad[0][1])
     span = max(r[1] for r in res) - min(r[0] for r in res)
     frames = sum(r[2] for r in res)
-    return {"value": round(frames * W * H / span / 1e6, 2), "unit": "Mpixels/s", "processes": procs, "threads_per_process": tt, "cores": procs * tt,
+    return {"value": round(frames * W * H / span / 1e6, 2), "unit": "Mpixels/s", "processes": procs, "threads_per_process": tt,
+            # cores = what the run could really occupy (a box shows 256 logical CPUs and grants a cgroup quota of 16): never the thread count alone
+            "cores": min(procs * tt, effective_cpus()), "threads": procs * tt, "logical_cpus": os.cpu_count() or 1,
             "frames": frames, "span_s": round(span, 3), "start_skew_s": round(max(r[0] for r in res) - min(r[0] for r in res), 4),
             "ms_per_frame": round(span * 1e3 / max(frames, 1), 3), "thread_ms_per_frame": round(span * 1e3 * procs * tt / max(frames, 1), 2),
             "note": "all workers released by one cross-process barrier after start-up, each processes frames for %.0f s; throughput = frames / (last finish - first start)" % work_s}
@@ -193,7 +207,7 @@ def cpu_baseline(W, H, budget_s=20.0):
         n = int(max(2, min(64, 0.5 * budget_s * 1000.0 / max(sweep[best], 1e-3))))
         frames = np.stack([synth_frame(W, H, 12345 + f) for f in range(n)])
         ms, edges, lines = ref.bench_pipeline(frames, T_LOW, T_HIGH, THETA_DEG, SHT_THRESHOLD)
-        out = {"value": round(n * W * H / (ms * 1e-3) / 1e6, 2), "unit": "Mpixels/s", "cores": ref.threads, "host_cpus": cores,
+        out = {"value": round(n * W * H / (ms * 1e-3) / 1e6, 2), "unit": "Mpixels/s", "cores": min(ref.threads, effective_cpus()), "threads": ref.threads, "host_cpus": cores,
                "kind": "reference",
                "sample": "%d frames %dx%d, CompV AVX2 intrinsics path (COMPV_ASM=0), %d threads (best of sweep), Canny(59,119)+SHT(1deg,100)" % (n, W, H, ref.threads),
                "ms_per_frame": round(ms / n, 3), "ms_per_frame_by_threads": sweep}
@@ -367,6 +381,43 @@ def extra_config(torch, capi, sharding, ctx, dev, W, H, F, NB, steps, warmup, re
             q["plan"].close()
 
 
+def free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def launch_argv(gpus, argv, port):
+    """The command a bare `python bench.py --gpus N ...` re-executes itself through: N ranks on this node, one per GPU."""
+    return [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(gpus), "--master-addr", "127.0.0.1",
+            "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+
+
+def self_launch(gpus, argv):
+    """Run the N ranks as children; stdout carries exactly what rank 0 printed (the ONE JSON line), everything else goes to stderr."""
+    import subprocess
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "1")
+    cmd = launch_argv(gpus, argv, free_port())
+    print("bench.py: --gpus %d without a launcher: starting %s" % (gpus, " ".join(cmd)), file=sys.stderr, flush=True)
+    p = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [l for l in p.stdout.splitlines() if l.strip()]
+    json_lines = [l for l in lines if l.lstrip().startswith("{")]
+    for l in lines:
+        if l not in json_lines:
+            print(l, file=sys.stderr)
+    if p.returncode != 0:
+        print("bench.py: the %d-rank launch exited with %d" % (gpus, p.returncode), file=sys.stderr)
+        return p.returncode or 1
+    if len(json_lines) != 1:
+        print("bench.py: expected ONE JSON line from rank 0, got %d" % len(json_lines), file=sys.stderr)
+        return 1
+    print(json_lines[0], flush=True)
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -396,10 +447,17 @@ def main():
     ap.add_argument("--dist-backend", default="nccl")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # a bare `python bench.py --gpus N`: start the N ranks ourselves (one process per GPU) and hand rank 0's JSON line through
+        raise SystemExit(self_launch(args.gpus, sys.argv[1:]))
+
     import torch
     from compv_amd import capi, sharding
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world and not (args.gpus == 1 and world == 1):
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%d -- the launcher's --nproc-per-node must equal --gpus "
+                         "(a bare `python bench.py --gpus N` starts its own N ranks)" % (args.gpus, world))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = 0 if args.shared_gpu else int(os.environ.get("LOCAL_RANK", "0"))
     dist_on = world > 1 or (args.force_dist and "RANK" in os.environ)
@@ -879,7 +937,7 @@ def kht_figure(capi, ctx, torch, lane, blocks, W, H, F):
                 ms, nl = ref.bench_kht(maps, 1.0, THETA_DEG, 1)
                 sweep[ref.threads] = round(ms / len(maps), 3)
             best = min(sweep, key=sweep.get)
-            cpu = {"ms_per_frame": sweep[best], "cores": best, "kind": "reference", "ms_per_frame_by_threads": sweep, "lines_4_frames": int(nl),
+            cpu = {"ms_per_frame": sweep[best], "cores": min(best, effective_cpus()), "threads": best, "kind": "reference", "ms_per_frame_by_threads": sweep, "lines_4_frames": int(nl),
                    "sample": "%d of the batch's %dx%d edge maps, CompVHoughKht::process (AVX2 / SSE intrinsics path, COMPV_ASM=0), best of the thread sweep; "
                              "single-frame LATENCY -- the throughput comparison at equal host resources is frame_parallel" % (len(maps), W, H)}
             # equal resources: P processes x 1 thread of the real CompVHoughKht::process on independent edge maps, behind one barrier

@@ -82,3 +82,33 @@ def test_block_rotation_of_a_world_of_eight_covers_config_4():
 def test_ranks_seen_single_process():
     from compv_amd import sharding
     assert sharding.ranks_seen(None) == [0]
+
+
+def test_bare_bench_gpus_8_builds_the_eight_rank_launch():
+    """`python bench.py --gpus 8` without a launcher must start 8 ranks itself.  The argv it re-executes through (no GPU needed):
+    torch.distributed.run, one node, 8 processes, rendezvous on 127.0.0.1 and a free port, every user argument forwarded unchanged."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_module", os.path.join(ROOT, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    user = ["--gpus", "8", "--steps", "64", "--warmup", "4", "--scatter"]
+    port = bench.free_port()
+    assert 1024 < port < 65536
+    argv = bench.launch_argv(8, user, port)
+    assert argv[0] == sys.executable and argv[1:3] == ["-m", "torch.distributed.run"]
+    assert "--nnodes=1" in argv
+    assert argv[argv.index("--nproc-per-node") + 1] == "8"
+    assert argv[argv.index("--master-addr") + 1] == "127.0.0.1"
+    assert argv[argv.index("--master-port") + 1] == str(port)
+    script = argv.index(os.path.join(ROOT, "bench.py"))
+    assert argv[script + 1:] == user                       # forwarded verbatim, --gpus 8 included (every rank checks it against WORLD_SIZE)
+
+
+def test_bench_refuses_a_world_that_is_not_gpus():
+    """A launcher started with --nproc-per-node 2 but `--gpus 4` on the command line is a mistake the JSON line would hide: non-zero exit naming both
+    numbers, before anything touches a GPU."""
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert r.returncode != 0 and "--gpus 4 but WORLD_SIZE=2" in r.stderr, r.stderr[-1000:]
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]

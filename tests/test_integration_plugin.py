@@ -88,6 +88,25 @@ def test_bench_two_ranks_on_one_gpu_gloo_host_staged(tmp_path):
     assert res["lines_last_step_all_ranks"] is not None and res["lines_frame0"] > 0
 
 
+@pytest.mark.gpu
+def test_bare_bench_gpus_2_starts_two_ranks_itself():
+    """NO launcher in the command.  `python bench.py --gpus 2 ...` must start its own two ranks (one GPU on a test box: --shared-gpu, gloo
+    carrying the scatter), print exactly ONE JSON line on stdout, and that line must say two ranks ran."""
+    import json
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--shared-gpu", "--dist-backend", "gloo", "--scatter", "--steps", "4", "--warmup", "2",
+           "--reps", "2", "--frames-per-gpu", "2", "--batches", "4", "--width", "1280", "--height", "720", "--no-cpu-baseline", "--no-extras"]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    out = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(out) == 1 and out[0].startswith("{"), r.stdout[-2000:]
+    res = json.loads(out[0])
+    assert res["n_gpus"] == 2 and res["ranks_seen"] == [0, 1] and res["n_ranks_seen"] == 2
+    assert res["dist_backend"] == "gloo" and res["value"] > 0
+
+
 MGB = os.path.join(ROOT, "integration", "_build", "multi_gpu_batch")
 
 
