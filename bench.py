@@ -841,6 +841,7 @@ def kernels_extra(capi, torch, lane, blocks, W, H, F):
         for _ in range(2):
             call()
         torch.cuda.synchronize()
+        before = plan.timing_mode
         plan.set_timing(1)
         acc = {}
         for _ in range(n):
@@ -848,24 +849,66 @@ def kernels_extra(capi, torch, lane, blocks, W, H, F):
             torch.cuda.synchronize()
             for name, ms in plan.get_timing():
                 acc[name] = acc.get(name, 0.0) + ms
-        plan.set_timing(0)
+        plan.set_timing(before)   # (whatever mode the caller had set)
         return {k: v / n for k, v in acc.items()}
 
     out = {}
+    # frame 0 of block 0 is (3840 x 2160, seed 12345) = fixture uhd_3840x2160 of tests/golden/golden.json (real CompV): what is timed here is also checked
+    gold = None
+    if (W, H) == (3840, 2160):
+        try:
+            gold = json.load(open(os.path.join(ROOT, "tests", "golden", "golden.json")))["uhd_3840x2160"]
+        except Exception:
+            gold = None
+    scratch = torch.empty_like(blocks[0])   # (never the lane's own edge maps)
+
+    def md5_frame0(t):
+        return hashlib.md5(np.ascontiguousarray(t[0].cpu().numpy()).tobytes()).hexdigest()
+
     # the 5x5 Sobel answers a step edge 12 x as strongly as the 3x3 one (16 * 3 against 4 * 1): thresholds scaled to the benchmark's edge density, and unscaled
-    for name, tl, th in (("canny5_same_edge_density", 12 * T_LOW, 12 * T_HIGH), ("canny5_benchmark_thresholds", T_LOW, T_HIGH)):
-        per = timed(lambda: plan.canny(blocks[0].data_ptr(), tl, th, q["edges"].data_ptr(), ksize=5, stream=st))
+    for name, tl, th, key in (("canny5_same_edge_density", 12 * T_LOW, 12 * T_HIGH, "canny5_x12"), ("canny5_benchmark_thresholds", T_LOW, T_HIGH, "canny5")):
+        per = timed(lambda: plan.canny(blocks[0].data_ptr(), tl, th, scratch.data_ptr(), ksize=5, stream=st))
         tile, res = per.get("canny_tile_kernel", 0.0), per.get("canny_resolve_kernel", 0.0)
-        out[name] = {"thresholds": [tl, th], "edge_pixels": int((q["edges"] != 0).sum().item()), "canny_tile_kernel_ms": round(tile, 4), "canny_resolve_kernel_ms": round(res, 4),
+        verified = "no fixture"
+        if gold is not None and key in gold:
+            g = gold[key]
+            got = (md5_frame0(scratch), int((scratch[0] != 0).sum().item()))
+            if (g["tLow"], g["tHigh"]) != (tl, th) or got != (g["md5"], g["edges"]):
+                raise RuntimeError("kernels_extra %s: frame 0 gives (md5 %s, %d edges), the reference fixture says (%s, %d)" % (name, got[0], got[1], g["md5"], g["edges"]))
+            verified = "frame 0 MD5 + edge count = tests/golden/golden.json uhd_3840x2160/%s (real CompV)" % key
+        out[name] = {"thresholds": [tl, th], "edge_pixels": int((scratch != 0).sum().item()), "verified": verified,
+                     "canny_tile_kernel_ms": round(tile, 4), "canny_resolve_kernel_ms": round(res, 4),
                      "stage_ms": round(tile + res, 4), "roofline": {"bound": "hbm", "achieved": round(px / (tile * 1e-3) / 1e9, 1) if tile else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                                                     "frac": round(px / (tile * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if tile else None, "basis": "1 B/px read, tile kernel"}}
-    d_out = torch.empty_like(blocks[0])
+    d_out = scratch
+    for opname, op, key in (("scharr", capi.OP_SCHARR, "scharr_md5"), ("prewitt", capi.OP_PREWITT, "prewitt_md5")):
+        if gold is not None and key in gold:
+            plan.edge_dete(blocks[0].data_ptr(), op, d_out.data_ptr(), st)
+            torch.cuda.synchronize()
+            if md5_frame0(d_out) != gold[key]:
+                raise RuntimeError("kernels_extra edge_dete %s: frame 0 differs from the reference fixture" % opname)
     per = timed(lambda: plan.edge_dete(blocks[0].data_ptr(), capi.OP_SOBEL, d_out.data_ptr(), st))
     ms = sum(per.values())
-    out["edge_dete_sobel"] = {"ms": round(ms, 4), "kernels": {k: round(v, 4) for k, v in per.items()},
+    verified = "no fixture"
+    if gold is not None:
+        if md5_frame0(d_out) != gold["sobel_md5"]:
+            raise RuntimeError("kernels_extra edge_dete sobel: frame 0 differs from the reference fixture")
+        verified = "frame 0 MD5 (Sobel timed; Scharr, Prewitt run once) = tests/golden/golden.json uhd_3840x2160 (real CompV)"
+    out["edge_dete_sobel"] = {"ms": round(ms, 4), "kernels": {k: round(v, 4) for k, v in per.items()}, "verified": verified,
                               "roofline": {"bound": "hbm", "achieved": round(3.0 * px / (ms * 1e-3) / 1e9, 1) if ms else None, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                            "frac": round(3.0 * px / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4) if ms else None, "basis": "3 B/px: gmax pass read + output pass read + write"}}
     return out
+
+
+def kht_list_hash(lines):
+    """tests/golden/make_golden_batch.py::kht_list_hash over a LINE_DTYPE array (order-dependent)."""
+    rb = lines["rho"].astype(np.float32).view(np.uint32).tolist()
+    tb = lines["theta"].astype(np.float32).view(np.uint32).tolist()
+    st = lines["strength"].astype(np.int64).tolist()
+    h = 0
+    for r, t, sv in zip(rb, tb, st):
+        h = (h * 1000003 + r * 7919 + t * 31337 + (sv & M64)) & M64
+    return h
 
 
 def kht_figure(capi, ctx, torch, lane, blocks, W, H, F):
@@ -884,6 +927,23 @@ def kht_figure(capi, ctx, torch, lane, blocks, W, H, F):
         dts.append(time.perf_counter() - t0)
     dt = sorted(dts)[len(dts) // 2]
     stages = q["plan"].houghkht_stage_ms()
+    kht_verified = "no fixture"
+    fixture = os.path.join(ROOT, "tests", "golden", "golden_batch_kht.json")
+    if (W, H) == (3840, 2160) and os.path.exists(fixture):
+        # every frame of the timed call against the real CompV KHT (tests/golden/make_golden_batch.py kht): count, strength sum, GS, and the list IN ORDER
+        gk = json.load(open(fixture))
+        recs = {g["seed"]: g for g in gk["frames"]}
+        checked = 0
+        for f in range(F):
+            g = recs.get(12345 + f)
+            if g is None:
+                continue
+            l, gs = res[0][f], res[1][f]
+            got = (len(l), int(l["strength"].astype(np.int64).sum()), repr(gs), "%016x" % kht_list_hash(l))
+            if got != (g["lines"], g["sum_strength"], g["gs"], g["list_hash"]):
+                raise RuntimeError("kht_figure: frame %d gives %s, the reference fixture says %s" % (f, got, (g["lines"], g["sum_strength"], g["gs"], g["list_hash"])))
+            checked += 1
+        kht_verified = {"frames_checked": checked, "against": "tests/golden/golden_batch_kht.json (real CompV): line count, strength sum, GS, ordered list hash"}
     # the same call with fewer host threads (the default above is min(32, hardware threads / 2)): how much of the figure is the host pool
     by_threads = {}
     for nt in (1, 8, 16, 32):
@@ -952,6 +1012,7 @@ def kht_figure(capi, ctx, torch, lane, blocks, W, H, F):
         cpu = {"error": str(e)}
     nthreads = stages.get("threads") or 0
     return {"ms_per_frame": round(dt * 1e3 / F, 3), "ms_per_frame_calls": [round(d * 1e3 / F, 3) for d in dts], "frames": F, "lines_frame0": int(len(res[0][0])),
+            "verified": kht_verified,
             "thread_ms_per_frame": round(dt * 1e3 / F * nthreads, 2) if nthreads else None,
             "ms_per_frame_by_host_threads": by_threads,
             "roofline": roof,

@@ -293,6 +293,7 @@ class Plan:
         ctx._chk(self.lib.compvhip_plan_create(ctx.h, W, H, S, frames, theta_deg, C.byref(h)))
         self.h = h
         self.W, self.H, self.S, self.frames = W, H, S, frames
+        self.timing_mode = 0
 
     def close(self):
         if self.h:
@@ -385,6 +386,7 @@ class Plan:
     def set_timing(self, mode=1):
         """0/False = off, 1/True = HIP events around every kernel, 2 = only around the two roofline kernels."""
         self.ctx._chk(self.lib.compvhip_plan_set_timing(self.h, int(mode)))
+        self.timing_mode = int(mode)
 
     def get_timing(self, cap=256):
         names = (C.c_char_p * cap)()

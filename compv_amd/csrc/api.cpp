@@ -1155,6 +1155,8 @@ static int planShtImpl(compvhip_plan* p, const uint8_t* d_edges, int threshold, 
 		if (d_counts) HIPCHK(ctx, hipMemcpyAsync(d_counts, p->lineCounts, sizeof(int32_t) * frames, hipMemcpyDeviceToDevice, st));
 		return COMPVHIP_OK;
 	}
+	// Invariant of the library-sort fallback: nothing reads keysB / valsB beyond lineTotal (the decode kernel stops at the clamped per-frame counts), so the
+	// slots [sortN, capAll) are neither sorted nor cleared and may hold a previous step's pairs.
 	if (sortN == kSortExact) {
 		HIPCHK(ctx, hipMemcpyAsync(p->hTotals, p->lineTotal, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
 		HIPCHK(ctx, hipStreamSynchronize(st));
@@ -1283,17 +1285,18 @@ static int runStepAsync(compvhip_plan* p, const StepParams& sp, hipStream_t st, 
 	if (p->timeline.size() > kMaxTimeline) timelineClear(p);
 	int rc = enqueueStep(p, sp, st, false);
 	if (rc) return rc;
-	// the sorted range: the largest total of the plan's recent steps + 1/16 + 4096 slots (nothing seen yet: everything)
+	// (capacities first: ensureLineCap may grow the key buffers and reset recentN -- totals clamped to the old capacity predict nothing)
+	rc = ensureSht(p);
+	if (rc) return rc;
+	rc = ensureLineCap(p, std::max(sp.lineCap, kMinLineCap));
+	if (rc) return rc;
+	// the sorted range: the largest total of the plan's recent steps + 1/16 + 4096 slots (nothing seen yet, or just reset: everything)
 	size_t sortN = kSortAll;
 	if (p->recentN > 0) {
 		unsigned int m = 0;
 		for (int i = 0; i < std::min(p->recentN, 8); ++i) m = std::max(m, p->recentTotals[i]);
 		sortN = static_cast<size_t>(m) + (m >> 4) + 4096;
 	}
-	rc = ensureSht(p);
-	if (rc) return rc;
-	rc = ensureLineCap(p, std::max(sp.lineCap, kMinLineCap));
-	if (rc) return rc;
 	if (p->deviceSort) sortN = kSortAll;   // sized on the device: no prediction to check
 	sortN = std::min(sortN, p->lineCap * p->frames);
 	rc = enqueueStepTail(p, sp, st, sortN);
@@ -1969,10 +1972,11 @@ static int khtBatchGroup(compvhip_plan* p, KhtBatchState& B, KhtPool& pool, cons
 	const size_t wpr = (W + 31) / 32, words = wpr * H;
 	hipStream_t st = B.stream;
 	// (several groups run at the same time, each on its own controller thread: errors travel back as (code, text), only the caller touches ctx->err)
-#define BCHK(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { err = std::string(#call) + ": " + hipGetErrorString(e__); return COMPVHIP_E_HIP; } } while (0)
+// (an early return must not leave asynchronous copies in flight towards this frame's stack arrays or the pinned state: drain the stream first, result ignored)
+#define BCHK(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { err = std::string(#call) + ": " + hipGetErrorString(e__); (void)hipStreamSynchronize(st); return COMPVHIP_E_HIP; } } while (0)
 	auto firstError = [&]() -> int {
 		for (size_t f = 0; f < G; ++f)
-			if (B.frames[f].code) { err = "frame " + std::to_string(f) + " of its group: " + B.frames[f].err; return B.frames[f].code; }
+			if (B.frames[f].code) { err = "frame " + std::to_string(f) + " of its group: " + B.frames[f].err; (void)hipStreamSynchronize(st); return B.frames[f].code; }
 		return COMPVHIP_OK;
 	};
 	if (hipSetDevice(ctx->device) != hipSuccess) { err = "hipSetDevice"; return COMPVHIP_E_HIP; }

@@ -266,7 +266,12 @@ COMPVHIP_API int compvhip_plan_pipeline(compvhip_plan* plan, const uint8_t* d_in
  * flight may share output buffers (a caller that only consumes the newest result): every step enqueued after a replayed one is then replayed too
  * when it is waited for, in enqueue order, so after compvhip_plan_wait(t) the buffers of step t always hold step t's results.  Wait for the tickets
  * of a plan in the order they were issued.  Results of step t are only guaranteed to still be there until the next step that shares its buffers
- * starts -- give steps their own buffers to read them later. */
+ * starts -- give steps their own buffers to read them later.
+ * A second replay cause exists only on the library-sort fallback (max(W, H) > 4095, or more than 32 chunks of 4096 lines per frame): there the step
+ * sorts a PREDICTED range of the line keys -- the largest line total of the plan's last 8 steps + 1/16 + 4096 -- and compvhip_plan_wait replays the
+ * step when its real total exceeded the prediction.  Content whose line count jumps from step to step therefore replays often on such plans, and each
+ * replay drains the stream and cascades to the later tickets that share output buffers; plans on the device-sized sort (every size up to 4095 x 4095
+ * with at most 131 072 lines per frame, i.e. all BASELINE configurations) never replay for this reason. */
 COMPVHIP_API int compvhip_plan_pipeline_async(compvhip_plan* plan, const uint8_t* d_in, float tLow, float tHigh,
                                               int threshold, int maxLines, uint8_t* d_edges,
                                               compvhip_line* d_lines, size_t lineCap, int32_t* d_counts, void* stream, int* ticket);

@@ -105,6 +105,20 @@ int refshim_sobel(const uint8_t* in, size_t W, size_t H, size_t S, uint8_t* out,
 	return 0;
 }
 
+// Any of the three gradient detectors. op: 0 = COMPV_SOBEL_ID, 2 = COMPV_SCHARR_ID, 3 = COMPV_PREWITT_ID (the ids of include/compv_hip.h).
+int refshim_edge_dete(const uint8_t* in, size_t W, size_t H, size_t S, int op, uint8_t* out, size_t So)
+{
+	CompVMatPtr img, edges;
+	if (COMPV_ERROR_CODE_IS_NOK(toMat(in, W, H, S, &img))) return -1;
+	CompVEdgeDetePtr dete;
+	const int id = op == 0 ? COMPV_SOBEL_ID : (op == 2 ? COMPV_SCHARR_ID : (op == 3 ? COMPV_PREWITT_ID : -1));
+	if (id < 0) return -4;
+	if (COMPV_ERROR_CODE_IS_NOK(CompVEdgeDete::newObj(&dete, id))) return -2;
+	if (COMPV_ERROR_CODE_IS_NOK(dete->process(img, &edges))) return -3;
+	fromMat(edges, out, So);
+	return 0;
+}
+
 // Canny. thresholdType: 0 = COMPARE_TO_GRADIENT (default), 1 = PERCENT_OF_MEAN
 int refshim_canny(const uint8_t* in, size_t W, size_t H, size_t S, float tLow, float tHigh, int ksize, int thresholdType, uint8_t* out, size_t So)
 {

@@ -35,6 +35,8 @@ CASES = [
 ]
 
 
+FULL_SIZE_EXTRAS = ("hd_1280x720", "fhd_1920x1080", "uhd_3840x2160")
+
 KHT_CASES = ("small_320x240", "q3_641x480", "ragged_333x77", "hd_1280x720", "fhd_1920x1080", "uhd_3840x2160", "dense_1282x720")
 
 
@@ -52,6 +54,16 @@ def main():
         m = {"W": W, "H": H, "seed": seed, "tLow": tl, "tHigh": th, "threshold_type": typ,
              "input_md5": md5_rows(img), "sobel_md5": md5_rows(sob), "canny_md5": md5_rows(can),
              "canny_edges": int((can != 0).sum())}
+        if name in FULL_SIZE_EXTRAS:
+            # the packed 5x5 Canny kernel and the Scharr / Prewitt detectors at the sizes the bench times them
+            # (5x5 thresholds: the 3x3 pair, and x 12 = the 5x5 kernel's gain on a step edge, the bench's "same edge density" point)
+            for tag, (l5, h5) in (("canny5", (tl, th)), ("canny5_x12", (tl * 12.0, th * 12.0))):
+                rc5, can5 = ref.canny(img, l5, h5, 5, 0)
+                assert rc5 == 0
+                m[tag] = {"tLow": l5, "tHigh": h5, "md5": md5_rows(can5), "edges": int((can5 != 0).sum())}
+            m["scharr_md5"] = md5_rows(ref.edge_dete(img, 2))
+            m["prewitt_md5"] = md5_rows(ref.edge_dete(img, 3))
+            assert md5_rows(ref.edge_dete(img, 0)) == m["sobel_md5"]
         if store:
             arrays[name + "/sobel"] = sob
             arrays[name + "/canny_bits"] = np.packbits(can != 0, axis=1)

@@ -4,6 +4,8 @@ one thread: the multi-threaded gradient of the reference races, DESIGN.md sectio
 
     python tests/golden/make_golden_batch.py            (about a minute)  -> golden_batch.json
     python tests/golden/make_golden_batch.py fhd        (1920 x 1080, 64 frames: bench.py's configs_extra)  -> golden_batch_fhd.json
+    python tests/golden/make_golden_batch.py kht        (BASELINE config 5 on the first resident batch: 32 frames of 3840 x 2160, seeds 12345 .. 12376,
+                                                         CompVHoughKht rho 1, theta 1 deg, threshold 1 on the reference's Canny maps)  -> golden_batch_kht.json
 
 Per frame: MD5 of the edge map (rows of W bytes), number of edge pixels, number of lines, sum of their strengths and an
 order-independent 64-bit hash of the line set (the reference leaves the order of equal-strength lines to an unstable sort):
@@ -38,7 +40,39 @@ def line_hash(rho, col, strength):
         return int(v.sum(dtype=np.uint64)) & M64
 
 
+def kht_main():
+    """Per frame: number of KHT lines, sum of their strengths, gs (repr: every digit) and an ORDER-DEPENDENT hash of the list (the KHT list's order
+    is part of the parity contract): h = (h * 1000003 + bits(rho f32) * 7919 + bits(theta f32) * 31337 + strength) mod 2^64 over the lines in order."""
+    ref = RefShim(1)
+    assert ref.avx2, "goldens must come from the AVX2 intrinsics path"
+    frames = []
+    for f in range(32):
+        img = synth_frame(3840, 2160, FIRST_SEED + f)
+        rc, can = ref.canny(img, T_LOW, T_HIGH, 3, 0)
+        assert rc == 0
+        kl, gs = ref.kht(can, 1.0, THETA_DEG, 1)
+        frames.append({"seed": FIRST_SEED + f, "canny_md5": md5_rows(can), "lines": len(kl), "sum_strength": int(sum(l[2] for l in kl)), "gs": repr(gs),
+                       "list_hash": "%016x" % kht_list_hash([l[0] for l in kl], [l[1] for l in kl], [l[2] for l in kl])})
+        print(f, frames[-1], flush=True)
+    out = {"W": 3840, "H": 2160, "tLow": T_LOW, "tHigh": T_HIGH, "rho": 1.0, "theta_deg": THETA_DEG, "threshold": 1, "first_seed": FIRST_SEED,
+           "source": "CompV (oracle/_ref, AVX2 intrinsics, 1 thread)", "frames": frames}
+    with open(os.path.join(HERE, "golden_batch_kht.json"), "w") as fh:
+        json.dump(out, fh, indent=0, sort_keys=True)
+
+
+def kht_list_hash(rho, theta, strength):
+    rb = np.asarray(rho, np.float32).view(np.uint32).astype(np.uint64)
+    tb = np.asarray(theta, np.float32).view(np.uint32).astype(np.uint64)
+    st = np.asarray(strength, np.int64).astype(np.uint64)
+    h = 0
+    for r, t, s in zip(rb.tolist(), tb.tolist(), st.tolist()):
+        h = (h * 1000003 + r * 7919 + t * 31337 + s) & M64
+    return h
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "kht":
+        return kht_main()
     ref = RefShim(1)
     assert ref.avx2, "goldens must come from the AVX2 intrinsics path"
     step = np.float32(THETA_DEG) * (np.float32(3.1415926535897932384626433) / np.float32(180.0))

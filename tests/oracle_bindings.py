@@ -389,6 +389,8 @@ class RefShim:
         L.refshim_init.argtypes = [C.c_int]
         L.refshim_sobel.argtypes = [C.c_void_p, sz, sz, sz, C.c_void_p, sz]
         L.refshim_canny.argtypes = [C.c_void_p, sz, sz, sz, C.c_float, C.c_float, C.c_int, C.c_int, C.c_void_p, sz]
+        if hasattr(L, "refshim_edge_dete"):
+            L.refshim_edge_dete.argtypes = [C.c_void_p, sz, sz, sz, C.c_int, C.c_void_p, sz]
         L.refshim_sht.argtypes = [C.c_void_p, sz, sz, sz, C.c_float, sz, C.c_int, C.c_void_p, sz, C.c_void_p]
         L.refshim_kht.argtypes = [C.c_void_p, sz, sz, sz, C.c_float, C.c_float, sz, C.c_int, C.c_void_p, sz, C.c_void_p, C.c_void_p]
         L.refshim_sht_acc.argtypes = [C.c_void_p, sz, sz, sz, C.c_void_p, C.c_void_p, sz, C.c_void_p, sz]
@@ -464,6 +466,13 @@ class RefShim:
         H, W = img.shape
         out = np.zeros((H, W), np.uint8)
         assert self.lib.refshim_sobel(_p(img), W, H, img.strides[0], _p(out), W) == 0
+        return out
+
+    def edge_dete(self, img, op=0):
+        """op: 0 Sobel, 2 Scharr, 3 Prewitt (include/compv_hip.h ids)"""
+        H, W = img.shape
+        out = np.zeros((H, W), np.uint8)
+        assert self.lib.refshim_edge_dete(_p(img), W, H, img.strides[0], op, _p(out), W) == 0
         return out
 
     def canny(self, img, fLow, fHigh, ksize=3, typ=0):

@@ -344,6 +344,81 @@ def test_golden(hip_ctx, golden, name):
         assert (got == exp).all()
 
 
+@pytest.mark.parametrize("name", ["hd_1280x720", "fhd_1920x1080", "uhd_3840x2160"])
+def test_golden_5x5_canny_and_detectors_full_size(hip_ctx, golden, name):
+    """the packed 5x5 Canny kernel (canny_swar_tile_kernel<.., KS = 5>) and the Scharr / Prewitt detectors at 720p / 1080p / 4K against
+    MD5s + edge counts recorded from the compiled reference (tests/golden/make_golden.py: FULL_SIZE_EXTRAS), at the benchmark's thresholds (36 % of the
+    pixels are edges under a 5x5 gradient: the sparse stage is dense) and at thresholds x 12 (the benchmark's edge density)."""
+    from compv_amd import capi
+    meta, _ = golden
+    m = meta[name]
+    img = synth_frame(m["W"], m["H"], m["seed"])
+    for key in ("canny5", "canny5_x12"):
+        g = m[key]
+        can = hip_ctx.canny(img, g["tLow"], g["tHigh"], ksize=5)
+        assert md5_rows(can) == g["md5"], (name, key)
+        assert int((can != 0).sum()) == g["edges"]
+    assert md5_rows(hip_ctx.edge_dete(img, capi.OP_SCHARR)) == m["scharr_md5"]
+    assert md5_rows(hip_ctx.edge_dete(img, capi.OP_PREWITT)) == m["prewitt_md5"]
+
+
+def test_plan_canny_5x5_batch_full_size(hip_ctx, golden):
+    """The plan entry the bench's kernels_extra times (compvhip_plan_canny, ksize 5) on a batch of 4K frames: frame 0 = the reference fixture, every frame's
+    edge count differs from frame 0's (distinct seeds) and repeats exactly on a second run."""
+    import torch
+    from compv_amd import capi
+    meta, _ = golden
+    m = meta["uhd_3840x2160"]
+    W, H, F = m["W"], m["H"], 3
+    dev = torch.device("cuda:0")
+    frames = np.stack([synth_frame(W, H, m["seed"] + f) for f in range(F)])
+    d_in = torch.from_numpy(frames).to(dev)
+    d_e = torch.empty_like(d_in)
+    plan = capi.Plan(hip_ctx, W, H, W, F, 1.0)
+    try:
+        for key in ("canny5_x12", "canny5"):
+            g = m[key]
+            plan.canny(d_in.data_ptr(), g["tLow"], g["tHigh"], d_e.data_ptr(), ksize=5)
+            torch.cuda.synchronize()
+            e = d_e.cpu().numpy()
+            assert md5_rows(e[0]) == g["md5"] and int((e[0] != 0).sum()) == g["edges"], key
+            plan.canny(d_in.data_ptr(), g["tLow"], g["tHigh"], d_e.data_ptr(), ksize=5)
+            torch.cuda.synchronize()
+            assert (d_e.cpu().numpy() == e).all()
+    finally:
+        plan.close()
+
+
+def test_plan_houghkht_batch_uhd_against_the_reference_fixture(hip_ctx):
+    """What bench.py's kht figure times: compvhip_plan_houghkht on 4K edge maps of the benchmark's first frames, every frame against
+    tests/golden/golden_batch_kht.json (real CompV: line count, strength sum, GS to the last digit, order-dependent hash of the list)."""
+    import json
+    import torch
+    from compv_amd import capi
+    gk = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "golden_batch_kht.json")))
+    W, H, F = gk["W"], gk["H"], 9                       # two groups of 8 -> the group pipeline is exercised
+    dev = torch.device("cuda:0")
+    frames = np.stack([synth_frame(W, H, gk["first_seed"] + f) for f in range(F)])
+    d_in = torch.from_numpy(frames).to(dev)
+    d_e = torch.empty_like(d_in)
+    plan = capi.Plan(hip_ctx, W, H, W, F, 1.0)
+    try:
+        plan.canny(d_in.data_ptr(), gk["tLow"], gk["tHigh"], d_e.data_ptr())
+        torch.cuda.synchronize()
+        e = d_e.cpu().numpy()
+        lines, gs = plan.houghkht(d_e.data_ptr(), gk["rho"], gk["theta_deg"], gk["threshold"])
+        for f in range(F):
+            g = gk["frames"][f]
+            assert md5_rows(e[f]) == g["canny_md5"]
+            l = lines[f]
+            h = 0
+            for r, t, sv in zip(l["rho"].astype(np.float32).view(np.uint32).tolist(), l["theta"].astype(np.float32).view(np.uint32).tolist(), l["strength"].astype(np.int64).tolist()):
+                h = (h * 1000003 + r * 7919 + t * 31337 + sv) & ((1 << 64) - 1)
+            assert (len(l), int(l["strength"].astype(np.int64).sum()), repr(gs[f]), "%016x" % h) == (g["lines"], g["sum_strength"], g["gs"], g["list_hash"]), f
+    finally:
+        plan.close()
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # device-resident batched plan (what bench.py times) at BASELINE sizes, via torch device memory
 # ---------------------------------------------------------------------------------------------------------------

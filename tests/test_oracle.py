@@ -88,6 +88,21 @@ def test_golden_uhd(oracle, golden):
     assert sum(l[2] for l in lines) == m["sht"]["sum_strength"]
 
 
+@pytest.mark.parametrize("name", ["hd_1280x720", "fhd_1920x1080", "uhd_3840x2160"])
+def test_golden_5x5_canny_and_detectors_full_size(oracle, golden, name):
+    """The restatement against the compiled reference's 5x5 Canny MD5s / edge counts and its Scharr / Prewitt detector MD5s at the bench's sizes
+    (tests/golden/make_golden.py: FULL_SIZE_EXTRAS)."""
+    meta, _ = golden
+    m = meta[name]
+    img = synth_frame(m["W"], m["H"], m["seed"])
+    for key in ("canny5", "canny5_x12"):
+        g = m[key]
+        rc, can = oracle.canny(img, g["tLow"], g["tHigh"], 5)
+        assert rc == 0 and md5_rows(can) == g["md5"] and int((can != 0).sum()) == g["edges"], (name, key)
+    assert md5_rows(oracle.edge_dete(img, 2)[0]) == m["scharr_md5"]
+    assert md5_rows(oracle.edge_dete(img, 3)[0]) == m["prewitt_md5"]
+
+
 def test_thresholds(oracle):
     # compv_core_feature_canny_dete.cxx:251-266
     assert oracle.canny_thresholds(59.0, 119.0) == (0, 59, 119)
