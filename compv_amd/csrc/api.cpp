@@ -300,6 +300,19 @@ void shtTables(float thetaDeg, size_t T, std::vector<int32_t>& sinQ, std::vector
 // 32 x 12 x 1208 partial-window rows) and the cheapest is taken: 7 x 4 instead of 4 x 3 tiles for one 4K frame, 0.349 -> 0.320 ms per compvhip_houghsht_u8
 // call.  Measured and NOT done: the same model for batches (round 4: 32 x 1080p on 4 x 2 instead of 2 x 2 tiles = three full rounds of the 256 CUs instead
 // of one and a half: no change, that step is bound by the launch chain; 32 x 720p on 4 x 2 instead of 2 x 1: 0.180 against 0.170 ms per step).
+// Lab knob (like COMPVHIP_RESOLVE_WRAP): COMPVHIP_VOTE_MAX_WINDOW=<rows> caps a voting workgroup's window below the 1264 rows the LDS holds, i.e. forces a
+// finer tile grid that leaves LDS free beside a voting workgroup (co-residency experiments, profiles/r06/coresidency.md).  Results are identical for any
+// grid (tests/test_gpu_parity.py::test_vote_window_knob_is_bit_exact); unset = the product's choice.
+static size_t voteMaxWindow()
+{
+	static const size_t v = [] {
+		const char* e = getenv("COMPVHIP_VOTE_MAX_WINDOW");
+		const long n = e ? atol(e) : 0;
+		return (n >= 64 && n <= kShtMaxWindow) ? static_cast<size_t>(n) : static_cast<size_t>(kShtMaxWindow);
+	}();
+	return v;
+}
+
 static bool voteGridTables(size_t W, size_t H, const std::vector<int32_t>& sinQ, const std::vector<int32_t>& cosQ, int split, int& nx, int& ny, int& TW, int& TH, long long& worst,
                            std::vector<int32_t>* kt, std::vector<int32_t>* rowBase)
 {
@@ -340,7 +353,7 @@ static bool voteGridTables(size_t W, size_t H, const std::vector<int32_t>& sinQ,
 			}
 		}
 	}
-	return alignUp(static_cast<size_t>(worst), 16) <= static_cast<size_t>(kShtMaxWindow) && TW <= 1280 &&
+	return alignUp(static_cast<size_t>(worst), 16) <= voteMaxWindow() && TW <= 1280 &&
 	       static_cast<long long>(TW - 1) * 65535 + static_cast<long long>(TH - 1) * 65535 < 0x7f000000LL;
 }
 

@@ -109,12 +109,12 @@ struct ShtArgs {
 	uint32_t* lineVals;       // [frames * lineCap] their accumulator cells: row * T + col
 	uint8_t* nmsFlags;        // [frames][nmsGroups][nmsRows] NMS survivors: bit j of byte (group, row) = column 8 group + j
 	int nmsRows;              // rows of a flag plane
-	int* blockCounts;         // [frames][lineBlocks] NMS survivors per 64 accumulator rows (one row block of sht_lines_kernel); written by sht_count_kernel
+	int* blockCounts;         // [frames][lineBlocks] NMS survivors per 64 accumulator rows (one row block of sht_lines_kernel); accumulated by sht_nms_kernel (zeroed per step)
 	int lineBlocks;
 	const int2* nmsRange;     // [nmsGroups] accumulator rows [x, y) the windows of the group's columns (+ one either side) can reach, widened by one row
 	int nmsGroups;            // groups of 8 theta columns
 	int* lineCounts;          // per frame
-	int* frameTotals;         // [frames * kFrameSlot] NMS survivors per frame, one counter per 128-byte line (sht_count_kernel adds its row blocks, zeroed per step)
+	int* frameTotals;         // [frames * kFrameSlot] NMS survivors per frame, one counter per 128-byte line (sht_nms_kernel adds its row blocks, zeroed per step)
 	unsigned int* lineTotal;  // sum over the frames of min(survivors, lineCap) = the key slots in use (written by sht_lines_kernel)
 	size_t sortN;             // key slots the sort will cover: sht_lines_kernel zeroes [lineTotal, sortN) (0: nothing to pad -- the sort is sized after the fact)
 	size_t bitsFrameStride, edgeCap, accFrameStride, lineCap;

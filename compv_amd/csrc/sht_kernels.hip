@@ -17,7 +17,7 @@
 //
 // Voting: rho = (x*cosQ[t] + y*sinQ[t]) >> 16 (int32, arithmetic shift), acc[barrier - rho][t]++ for every edge and
 // every t -- E*T scattered increments, the whole cost of the reference's SHT: sht_tiles_kernels.hip (lane = theta over image tiles).
-// This file: foreign edge maps -> bit masks, sht_nms_kernel / sht_count_kernel / sht_lines_kernel, the library key sort + sht_decode_kernel (the
+// This file: foreign edge maps -> bit masks, sht_nms_kernel / sht_lines_kernel, the library key sort + sht_decode_kernel (the
 // fallback of sht_sort_kernels.hip), sht_cartesian_kernel, the accumulator export.
 #include "kernels.hpp"
 
@@ -61,46 +61,59 @@ __global__ __launch_bounds__(256) void bytes_to_bits_kernel(const uint8_t* __res
 
 // ---------------------------------------------------------------------------------------------------------------
 // NMS + threshold -> (key, value) pairs in DETERMINISTIC order (accumulator rows, then columns, ascending: nms_apply's own order,
-// houghsht.cxx:546-562), so that the sort only has to order by strength.  Three kernels:
+// houghsht.cxx:546-562), so that the sort only has to order by strength.  Two kernels:
 //   sht_nms_kernel    3x3 test of 8 theta columns x 8 rho rows per thread straight from registers; the survivors leave as one flag byte per
-//                     (row, column group): flag planes [frame][column group][row], 8-byte coalesced stores, no atomics;
+//                     (row, column group): flag planes [frame][column group][row], 8-byte coalesced stores; the survivors per 64 rows are
+//                     added to blockCounts[] (one atomic per row block and column group), the wave's total to the frame's total;
 //   sht_lines_kernel  a workgroup (one wave, lane = row) owns 64 COMPLETE accumulator rows (all theta columns), so its survivors occupy one contiguous
 //                     range of the frame's key / value arrays: the rows' survivors are counted and prefix-summed in the wave, the range's
-//                     start is the sum of the earlier blocks' survivor counts (sht_count_kernel: one wave per row block, no atomics), key = frameTag | strength and value = cell (row * T + col) are put in place in
+//                     start is the sum of the earlier blocks' survivor counts (blockCounts[], accumulated by the NMS), key = frameTag | strength and value = cell (row * T + col) are put in place in
 //                     the LDS and stored coalesced; every block zeroes a slice of the frame's unused key slots.
-//   sht_count_kernel  survivors per 64 rows (one wave per row block);
-//                     (Measured and dropped: a decoupled look-back chain instead of sht_count_kernel -- every block waits for atomic round
-//                     trips to the L2: 27 us of that kernel's 42; one atomicAdd per NMS thread instead of sht_count_kernel -- 184 adds on
-//                     every counter: +30 us in the NMS; the NMS inside this kernel too -- no flag planes, no second read of the strengths: 0.106 ms
+//   (rounds 3-5 had a sht_count_kernel between the two -- survivors per 64 rows re-counted from the flag planes, one wave per row block; since round 6 the
+//                     NMS counts as it goes.)
+//                     (Measured and dropped: a decoupled look-back chain instead of the block counts -- every block waits for atomic round
+//                     trips to the L2: 27 us of that kernel's 42; one atomicAdd per NMS thread -- 184 adds on
+//                     every counter: +30 us in the NMS; the NMS inside the lines kernel too -- no flag planes, no second read of the strengths: 0.106 ms
 //                     against 0.021 + 0.03: at 150 VGPRs four 3-wave workgroups fit a CU, and load -> test -> barrier -> scan -> look-back ->
 //                     barrier -> emit is one latency chain per workgroup.)
 // A stable descending radix sort of the (key, value) pairs then gives frame-major, strength-descending, (row, col)-ascending order with
 // frameBits + strengthBits key bits (18 at 4K x 32 frames: two 10-bit onesweep passes; the unique 40-bit keys of rounds 1-2, which carried
 // the cell because the slots were handed out by atomics in arrival order, took four).
 // ---------------------------------------------------------------------------------------------------------------
-constexpr int kNmsThreads = 128;
-constexpr int kNmsCols = 8;                  // theta columns per block
-constexpr int kNmsRows = kNmsThreads * 8;    // rho rows per block: 8 per thread
+constexpr int kNmsCols = 8;                  // theta columns per thread
+constexpr int kNmsRows = 1024;               // granularity of a flag plane's row count (sht_nms_rows)
+constexpr int kNmsBlkRows = 64;              // rows of one row block of sht_lines_kernel: their survivor counts come out of this pass
+constexpr int kNmsWaves = 2;                 // waves per workgroup
+constexpr int kNmsWgRows = 512;              // rho rows per wave: 8 rows per lane, i.e. 8 row blocks of 64
 
-// One block owns kNmsCols theta columns x kNmsRows rho rows of the theta-major accumulator; a thread 8 consecutive rows of all columns
-// (+ one column either side): ten 16-byte coalesced loads straight into registers (each accumulator cell is read (kNmsCols+2)/kNmsCols
-// times), the rows above / below its eight with two 2-byte loads per column (lines its neighbours fetch anyway): no LDS tile, no
-// barrier -- the waves of the launch are independent and hide each other's load latency (the LDS-tiled version of rounds 1-2 ran
-// load -> barrier -> compute per block at 3.5 waves per SIMD: 45 us for 87 MB).
-// A thread's survivors are one byte per row (bit j = column c0 + j).
-__global__ __launch_bounds__(kNmsThreads) void sht_nms_kernel(ShtArgs a)
+// A thread owns 8 theta columns x 8 consecutive rho rows of the theta-major accumulator (+ one column / row either side): ten 16-byte coalesced loads
+// straight into registers (each accumulator cell is read (kNmsCols+2)/kNmsCols times), the rows above / below its eight with two 2-byte loads per column
+// (lines its neighbours fetch anyway): no LDS tile -- the LDS-tiled version of rounds 1-2 ran load -> barrier -> compute per block at 3.5 waves per SIMD:
+// 45 us for 87 MB.  A thread's survivors are one byte per row (bit j = column c0 + j).
+// Round 6: the survivors of a 64-row block (= 8 lanes) are summed with three lane shuffles and ADDED to blockCounts[] by the octet's first lane (one
+// atomic per row block and column group: 23 per counter at T = 180, only where there are survivors), the wave's total to the frame total:
+// sht_count_kernel (a second pass over the flag planes, 6.6 us + a launch) is gone for +0.4 us here.  Measured on the way, per 32 x 4K launch, against
+// 22.6 (NMS) + 6.6 (count): a workgroup = 64 rows x all column groups, 8 lanes per column, plain stores: 34.5 us; 512 rows x all column groups, a wave
+// looping over three column groups: 34.7 us (a third of the loads in flight); 8 column groups x 512 rows per workgroup, counts summed in the LDS, 3 atomics
+// per counter: 26.5 us (the barrier keeps eight waves' registers until the slowest is done); this shape: 23.0 us.  Round 3's "+30 us" was one atomic per
+// THREAD (184 per counter, 32 counters per 128-byte line).
+__global__ __launch_bounds__(kNmsWaves * 64) void sht_nms_kernel(ShtArgs a)
 {
 	const int frame = blockIdx.z;
-	const int c0 = blockIdx.y * kNmsCols;
-	const int base = blockIdx.x * kNmsRows;
-	const int t = threadIdx.x;
-	// Two thirds of the accumulator's cells lie outside every tile's rho window of their theta (no pixel of the image maps there): they are
-	// never written, stay zero, and their flag bytes (zeroed when the plan was made) are never written either.
-	const int2 reach = a.nmsRange[blockIdx.y];
-	if (base >= reach.y || base + kNmsRows <= reach.x) return; // uniform
+	const int cg = blockIdx.y;
+	const int lane = threadIdx.x & 63;
+	const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+	const int base = ((int)blockIdx.x * kNmsWaves + wave) * kNmsWgRows;
+	const int r0 = base + lane * 8;
 	const uint16_t* __restrict__ acc = a.acc + (size_t)frame * a.accFrameStride;
 	const size_t p = a.accPitch;
-	const int r0 = base + t * 8;
+	uint32_t survivors = 0;                      // of this lane's 8 rows
+	{
+	// Two thirds of the accumulator's cells lie outside every tile's rho window of their theta (no pixel of the image maps there): they are
+	// never written, stay zero, and their flag bytes (zeroed when the plan was made) are never written either.
+	const int2 reach = a.nmsRange[cg];
+	if (!(base >= reach.y || base + kNmsWgRows <= reach.x)) {   // wave-uniform
+	const int c0 = cg * kNmsCols;
 	// All 30 loads of a thread are unconditional (clamped addresses, invalid cells zeroed afterwards), so they are in flight together.
 	const int rc = min(r0, a.accPitch - 8);                       // accPitch is a multiple of 64 rows
 	const int ru = min(max(r0 - 1, 0), a.accPitch - 1), rd = min(r0 + 8, a.accPitch - 1);
@@ -176,9 +189,23 @@ __global__ __launch_bounds__(kNmsThreads) void sht_nms_kernel(ShtArgs a)
 #pragma unroll
 		for (int k = 0; k < 10; ++k) mid[k] = nxt[k];
 	}
-	// flag plane of this column group: rows base + 8 t .. + 7, one 8-byte store per thread (a wave writes 512 consecutive bytes)
-	uint8_t* __restrict__ plane = a.nmsFlags + ((size_t)frame * a.nmsGroups + blockIdx.y) * a.nmsRows;
-	*reinterpret_cast<uint2*>(plane + base + t * 8) = make_uint2(flags[0], flags[1]);
+	// flag plane of this column group: rows r0 .. r0 + 7, one 8-byte store per thread (a wave writes 512 consecutive bytes)
+	uint8_t* __restrict__ plane = a.nmsFlags + ((size_t)frame * a.nmsGroups + cg) * a.nmsRows;
+	*reinterpret_cast<uint2*>(plane + r0) = make_uint2(flags[0], flags[1]);
+	survivors = (uint32_t)(__popc(flags[0]) + __popc(flags[1]));
+	}
+	}
+	// survivors per 64-row block (8 lanes each): what sht_count_kernel used to re-count from the flag planes
+	uint32_t cnt = survivors;
+#pragma unroll
+	for (int o = 1; o < 8; o <<= 1) cnt += __shfl_xor(cnt, o);
+	const int nblk = (a.R + kNmsBlkRows - 1) / kNmsBlkRows;
+	const int blk = (base >> 6) + (lane >> 3);
+	if ((lane & 7) == 0 && cnt && blk < nblk) atomicAdd(a.blockCounts + frame * nblk + blk, (int)cnt);   // one add per column group: 23 per counter at T = 180; zeroed per step
+	uint32_t tot = cnt;
+#pragma unroll
+	for (int o = 8; o < 64; o <<= 1) tot += __shfl_xor(tot, o);
+	if (lane == 0 && tot) atomicAdd(a.frameTotals + (size_t)frame * kFrameSlot, (int)tot);   // the frame's total: where the NEXT frame's lines start (dense key array)
 }
 
 constexpr int kLnRows = 64;               // rows per workgroup = lanes of its one wave
@@ -196,30 +223,6 @@ __device__ __forceinline__ void sht_load_flags(const uint8_t* __restrict__ plane
 	for (int i = 0; i < 32; ++i) b[i] = (cg0 + i < groups) ? b[i] : 0u;
 #pragma unroll
 	for (int i = 0; i < 8; ++i) fw[i] = b[4 * i] | (b[4 * i + 1] << 8) | (b[4 * i + 2] << 16) | (b[4 * i + 3] << 24);
-}
-
-// survivors per 64 accumulator rows: blockCounts[frame][row block] (one wave per row block, same placement as sht_lines_kernel)
-__global__ __launch_bounds__(kLnRows) void sht_count_kernel(ShtArgs a)
-{
-	const int nblk = (a.R + kLnRows - 1) / kLnRows;
-	const int xcd = blockIdx.x & 7, kk = blockIdx.x >> 3;
-	const int frame = (kk / nblk) * 8 + xcd, blk = kk % nblk;
-	if (frame >= a.frames) return; // uniform
-	const int lane = threadIdx.x, groups = a.nmsGroups;
-	const uint8_t* __restrict__ planes = a.nmsFlags + (size_t)frame * groups * a.nmsRows + blk * kLnRows + lane;
-	uint32_t cnt = 0;
-	for (int cg0 = 0; cg0 < groups; cg0 += 32) {
-		uint32_t fw[8];
-		sht_load_flags(planes, a.nmsRows, groups, cg0, fw);
-#pragma unroll
-		for (int i = 0; i < 8; ++i) cnt += (uint32_t)__popc(fw[i]);
-	}
-#pragma unroll
-	for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o);
-	if (lane == 0) {
-		a.blockCounts[frame * nblk + blk] = (int)cnt;
-		if (cnt) atomicAdd(a.frameTotals + (size_t)frame * kFrameSlot, (int)cnt);   // the frame's total: where the NEXT frame's lines start (dense key array)
-	}
 }
 
 // One WAVE per 64 complete accumulator rows, lane = row: no barriers, every workgroup of the launch resident at once (the version with
@@ -260,7 +263,7 @@ __global__ __launch_bounds__(kLnRows) void sht_lines_kernel(ShtArgs a)
 		if (lane >= o) incl += n;
 	}
 	const uint32_t total = __shfl(incl, 63);
-	// 2. the block's first slot = the survivors of the frame's earlier row blocks (sht_count_kernel): a few independent loads and a
+	// 2. the block's first slot = the survivors of the frame's earlier row blocks (blockCounts[] of sht_nms_kernel): a few independent loads and a
 	// wave reduction.  (A decoupled look-back chain over the blocks -- no counters, status words written by this kernel -- cost 27 us of this
 	// kernel's 42: every block waits for atomic round trips to the L2.)
 	const int* __restrict__ bc = a.blockCounts + (size_t)frame * nblk;
@@ -449,10 +452,11 @@ int sht_lines_blocks(int R) { return (R + kLnRows - 1) / kLnRows; }
 
 hipError_t launch_sht_lines(const ShtArgs& a, int frames, hipStream_t stream)
 {
-	dim3 ngrid((a.R + kNmsRows - 1) / kNmsRows, (a.T + kNmsCols - 1) / kNmsCols, frames);
-	hipLaunchKernelGGL(sht_nms_kernel, ngrid, dim3(kNmsThreads), 0, stream, a);
 	const int nblk = sht_lines_blocks(a.R);
-	hipLaunchKernelGGL(sht_count_kernel, dim3((unsigned)(8 * ((frames + 7) / 8) * nblk)), dim3(kLnRows), 0, stream, a);
+	static_assert(kNmsBlkRows == kLnRows, "the NMS counts the survivors of the row blocks sht_lines_kernel owns");
+	static_assert(kNmsRows % kNmsWgRows == 0 && kNmsWgRows % kNmsBlkRows == 0, "flag planes hold whole NMS waves; a wave holds whole row blocks");
+	dim3 ngrid((a.R + kNmsWaves * kNmsWgRows - 1) / (kNmsWaves * kNmsWgRows), (a.T + kNmsCols - 1) / kNmsCols, frames);
+	hipLaunchKernelGGL(sht_nms_kernel, ngrid, dim3(kNmsWaves * 64), 0, stream, a);
 	hipLaunchKernelGGL(sht_lines_kernel, dim3((unsigned)(8 * ((frames + 7) / 8) * nblk)), dim3(kLnRows), 0, stream, a);
 	return hipGetLastError();
 }
