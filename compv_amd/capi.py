@@ -412,6 +412,16 @@ def houghkht_link(edges, min_size=10):
     return xy[:npts.value].copy(), ends[:nstr.value].copy()
 
 
+def houghsht_vote_grid(W, H, theta_deg=1.0, frames=1):
+    """(nx, ny, window rows) of the voting kernel's image-tile grid for a plan of `frames` W x H frames (compvhip_houghsht_vote_grid)."""
+    lib = load()
+    nx = C.c_int(0); ny = C.c_int(0); rw = C.c_int(0)
+    rc = lib.compvhip_houghsht_vote_grid(W, H, theta_deg, frames, C.byref(nx), C.byref(ny), C.byref(rw))
+    if rc:
+        raise CompvHipError(rc, "compvhip_houghsht_vote_grid")
+    return nx.value, ny.value, rw.value
+
+
 def houghkht_dims(W, H, rho=1.0, theta_deg=1.0):
     """(T, rhoN) of the KHT vote map for a W x H image (compvhip_houghkht_dims)."""
     lib = load()

@@ -303,14 +303,11 @@ void shtTables(float thetaDeg, size_t T, std::vector<int32_t>& sinQ, std::vector
 // Lab knob (like COMPVHIP_RESOLVE_WRAP): COMPVHIP_VOTE_MAX_WINDOW=<rows> caps a voting workgroup's window below the 1264 rows the LDS holds, i.e. forces a
 // finer tile grid that leaves LDS free beside a voting workgroup (co-residency experiments, profiles/r06/coresidency.md).  Results are identical for any
 // grid (tests/test_gpu_parity.py::test_vote_window_knob_is_bit_exact); unset = the product's choice.
-static size_t voteMaxWindow()
+static size_t voteMaxWindow()   // read whenever a plan is made: one process can hold plans on different grids (tools/coresidency/grid_ab.py)
 {
-	static const size_t v = [] {
-		const char* e = getenv("COMPVHIP_VOTE_MAX_WINDOW");
-		const long n = e ? atol(e) : 0;
-		return (n >= 64 && n <= kShtMaxWindow) ? static_cast<size_t>(n) : static_cast<size_t>(kShtMaxWindow);
-	}();
-	return v;
+	const char* e = getenv("COMPVHIP_VOTE_MAX_WINDOW");
+	const long n = e ? atol(e) : 0;
+	return (n >= 64 && n <= kShtMaxWindow) ? static_cast<size_t>(n) : static_cast<size_t>(kShtMaxWindow);
 }
 
 static bool voteGridTables(size_t W, size_t H, const std::vector<int32_t>& sinQ, const std::vector<int32_t>& cosQ, int split, int& nx, int& ny, int& TW, int& TH, long long& worst,

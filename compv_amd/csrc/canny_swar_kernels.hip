@@ -31,10 +31,15 @@
 // per-tile prologue (lane = row, both sides packed in one register), whole mask dwords and 256-byte aligned edge rows -- bit-exact and 5 % SLOWER
 // (profiles/r05/canny_lab_swar256.txt, commit 7eabbb1): the prologue's 144 single-dword gather loads per tile cost 14 % of the kernel, more than the
 // halo lanes (6 %) and the 2-byte stores (8 %) together.  The halo lanes stay.
+// Round 6 (VERDICT r5 #3 i): kernel size 3 loads every input dword ONCE -- one buffer load per lane and row, three rows ahead -- and takes the byte either side
+// of a lane's four pixels from the neighbour lanes' dwords through a two-row exchange buffer in the LDS (ds_write_b32 + 2 ds_read_u8 per row, one step before
+// use): a third of the vector-memory requests, bit-exact, 0.989 of the three-loads kernel on 32 x 4K frames, 1.017 on 32 x 1080p -- the launcher takes it for
+// launches of at least four rounds of the chip's wave slots (the bound of ANY load-path change -- neighbours faked -- is 0.948: the kernel is bound by VALU issue,
+// profiles/r06/canny_lab_r06.txt).
 // A wave owns 240 output columns x kSwRows rows, 4 pixels per lane: lanes 0, 1 and 62, 63 compute the gradient of the 8 columns either
 // side of the tile (the NMS of columns 0 and 239 needs one of them; two lanes per side keep the tile's bit masks half-word aligned:
 // 240 = 15 half-words) but own no pixels.  Every input byte is fetched once per tile (+ 4/64 row halo, + 16/240 column halo).
-// 4 pixels per lane: <= 64 VGPRs and 4.6 KB of LDS per wave put 8 waves on every SIMD (one wave issues an instruction only every
+// 4 pixels per lane: <= 64 VGPRs and 4.9 KB of LDS per wave put 8 waves on every SIMD (one wave issues an instruction only every
 // ~8.7 cycles whatever its type, so the issue rate of a SIMD is resident waves / 8.7 until a pipe saturates).
 #include "stencil.hpp"
 #include "kernels.hpp"
@@ -65,7 +70,10 @@ constexpr int kAux = 4 * kRowB;              // aux ring, 2 rows: row r lives in
 constexpr int kList = kAux + 2 * kRowB;      // candidate list of a row pair: <= 480 u16 entries
 constexpr int kNib = kList + 1024;           // result nibbles, 4 rows x 64 bytes: byte l of a row = lane l's four pixels, U flags (weak, not strong) in bits 0..3, E flags (strong) in 4..7
 constexpr int kNibRowB = 64;
-constexpr int kLdsBytes = kNib + 4 * kNibRowB + 64;   // 4416 B per wave (the flush reads up to 8 bytes past the last row)
+// kernel size 3 (round 6): the neighbour lanes' pixels travel through the LDS -- a wave loads every input dword ONCE and publishes it in a two-row exchange
+// buffer (256 B per row); kernel size 5 keeps its three loads per row and does not touch the buffer
+constexpr int kXch = kNib + 4 * kNibRowB + 64;         // (the flush reads up to 8 bytes past the last nibble row)
+constexpr int kLdsBytes = kXch + 2 * 256 + 8;          // 4936 B per wave: 32 waves x 5120 (512-byte granules) = the CU's 160 KB
 
 constexpr uint32_t kBias1k = 0x04000400u;    // +1024 per half: gx, gy
 constexpr uint32_t kBias2k = 0x08000800u;    // +2048 per half: g' = g + 2048 (and "2 * bias" of the absolute value)
@@ -112,9 +120,11 @@ __device__ __forceinline__ uint32_t nibble_bytes(uint32_t nib)
 // rows in registers (ring indexed by the row loop's phase); gx = (1,4,6,4,1) . H1 down the column (+16384), gy = H2[y-2] + 2 H2[y-1] - 2 H2[y+1] - H2[y+2]
 // (+16383), |.| by v_pk_max_u16 as before, g' = g + 32768 (g <= 24480), aux = |gx| in bits 0..13 and the sign flag in bit 14 -- the same conventions as
 // the 3x3 path with wider fields, so the candidate list, the NMS, the flush and the hysteresis hand-over are shared.
-template <bool GAP, int WAVES, int kSwRows, int KS>
+// XCH: the LDS exchange path of the input rows (kernel size 3 only; chosen by the launcher for launches that oversubscribe the wave slots).
+template <bool GAP, int WAVES, int kSwRows, int KS, bool XCH>
 __global__ __launch_bounds__(WAVES * 64, (KS == 3 ? 8 : 7)) void canny_swar_tile_kernel(CannyArgs a)
 {
+	static_assert(!XCH || KS == 3, "the exchange path is the 3x3 kernel's");
 	static_assert(KS == 3 || KS == 5, "Sobel kernel size");
 	constexpr int R = KS / 2;                                  // width of the zero OUTPUT border of the gradient
 	constexpr uint32_t kG = (KS == 3) ? 2048u : 32768u;         // bias of g' (per half)
@@ -218,6 +228,23 @@ __global__ __launch_bounds__(WAVES * 64, (KS == 3 ? 8 : 7)) void canny_swar_tile
 	// wave the kernel ran 12 % slower once its stores shared the memory pipeline with the loads (tools/canny_lab, round 4)
 	constexpr int E = (KS == 5) ? 1 : 0;   // step it takes input row y0 - 2 + E + it and yields gradient row y0 + it - 3
 	uint32_t nb[2][3];
+	constexpr bool kXchLR = XCH;
+	// kXchLR: ONE load per lane and input row, three rows ahead (ring mq); the byte either side of a lane's four pixels comes from the neighbour lanes'
+	// dwords through a two-row exchange buffer in the LDS, fetched one step before the row is used (lanes 0 / 63 read a byte beside the buffer: their
+	// outermost columns feed nothing)
+	uint32_t mq[4] = { 0, 0, 0, 0 }, lrq[2][2] = { { 0, 0 }, { 0, 0 } };
+	auto loadm = [&](int y, uint32_t& m) {
+		const int so = min(max(y, 0), H - 1) * S;
+		m = __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)xm, so, 0);
+	};
+	auto exchange = [&](int slot, uint32_t m, uint32_t& lb, uint32_t& rb) {
+		uint8_t* const xb = rest + kXch + slot * 256 + lane * 4;
+		*reinterpret_cast<uint32_t*>(xb) = m;
+		__builtin_amdgcn_wave_barrier();
+		lb = *(xb - 1);
+		rb = *(xb + 4);
+		__builtin_amdgcn_wave_barrier();
+	};
 	if constexpr (KS == 5) {
 		// two more input rows above the tile than the 3x3 path streams: y0 - 3 and y0 - 2 only feed the row ring (slots 2 and 3: steps "-2" and "-1")
 		uint32_t w[2][3];
@@ -233,8 +260,14 @@ __global__ __launch_bounds__(WAVES * 64, (KS == 3 ? 8 : 7)) void canny_swar_tile
 			hz5(a0, o1, a1, o2, ap, h1[2 + q][1], h2[2 + q][1]);
 		}
 	}
-	load(y0 - 2 + E, nb[0][0], nb[0][1], nb[0][2]);
-	load(y0 - 1 + E, nb[1][0], nb[1][1], nb[1][2]);
+	if constexpr (kXchLR) {
+		loadm(y0 - 2, mq[0]); loadm(y0 - 1, mq[1]); loadm(y0, mq[2]);
+		exchange(0, mq[0], lrq[0][0], lrq[0][1]);
+	}
+	else {
+		load(y0 - 2 + E, nb[0][0], nb[0][1], nb[0][2]);
+		load(y0 - 1 + E, nb[1][0], nb[1][1], nb[1][2]);
+	}
 
 	// One row step: push input row yin = y0 - 2 + it  ->  gradient row yc = yin - 1 = y0 + (it - 3)  ->  ring slot (it - 3) & 3.
 	// After the steps with odd it >= 5 the rows 2j, 2j + 1 (j = (it - 5) / 2) of the tile have all three g rows of their neighbourhood
@@ -245,14 +278,22 @@ __global__ __launch_bounds__(WAVES * 64, (KS == 3 ? 8 : 7)) void canny_swar_tile
 		constexpr int sNew = (PH + 1) & 3;                    // ring slot of the gradient row produced now
 		constexpr int aNew = (PH + 1) & 1;                    // its aux slot = its row parity
 		const int yin = y0 - 2 + E + it;
-		const uint32_t m = nb[PH & 1][0], l = nb[PH & 1][1], r = nb[PH & 1][2];
-		load(yin + 2, nb[PH & 1][0], nb[PH & 1][1], nb[PH & 1][2]); // prefetch
+		uint32_t m, l, r;
+		if constexpr (kXchLR) {
+			m = mq[PH]; l = lrq[PH & 1][0]; r = lrq[PH & 1][1];               // l, r: ONE byte each here (p-1, p4), zero-extended
+			loadm(yin + 3, mq[(PH + 3) & 3]);                                  // prefetch, three rows ahead
+			exchange((PH + 1) & 1, mq[(PH + 1) & 3], lrq[(PH + 1) & 1][0], lrq[(PH + 1) & 1][1]);   // the next row's neighbours
+		}
+		else {
+			m = nb[PH & 1][0]; l = nb[PH & 1][1]; r = nb[PH & 1][2];
+			load(yin + 2, nb[PH & 1][0], nb[PH & 1][1], nb[PH & 1][2]); // prefetch
+		}
 
 		// ---- dense stage: packed pairs straight from the raw dwords (one v_perm each) ----
 		uint32_t A[2], L[3];
 		A[0] = __builtin_amdgcn_perm(0u, m, 0x0c010c00u);     // (p0, p1)
 		A[1] = __builtin_amdgcn_perm(0u, m, 0x0c030c02u);     // (p2, p3)
-		L[0] = __builtin_amdgcn_perm(m, l, 0x0c040c03u);      // (p-1, p0)
+		L[0] = __builtin_amdgcn_perm(m, l, kXchLR ? 0x0c040c00u : 0x0c040c03u);      // (p-1, p0)
 		L[1] = __builtin_amdgcn_perm(0u, m, 0x0c020c01u);     // (p1, p2)
 		L[2] = __builtin_amdgcn_perm(r, m, 0x0c040c03u);      // (p3, p4)
 		uint32_t gq[2], aux[2];
@@ -473,8 +514,24 @@ static hipError_t launch_swar(const CannyArgs& a0, int frames, bool gap, hipStre
 	a.groups = a.blockRows * frames;
 	dim3 grid(8 * ((a.groups + 7) / 8) * a.tilesX);
 	dim3 block(kWaves * 64);
-	if (gap) hipLaunchKernelGGL((canny_swar_tile_kernel<true, kWaves, kRows, KS>), grid, block, 0, stream, a);
-	else hipLaunchKernelGGL((canny_swar_tile_kernel<false, kWaves, kRows, KS>), grid, block, 0, stream, a);
+	// Input rows through the LDS exchange buffer (one load per lane and row) when the launch is several times the chip's 8192 wave slots -- then the kernel runs at
+	// its throughput and a third of the vector-memory requests is worth 1 % (32 x 4K: 46 080 waves, 0.989 of the three-loads kernel) --; smaller launches are a few
+	// rounds of latency chains, which the exchange lengthens (32 x 1080p: 11 520 waves, 1.017).  tools/canny_lab forces either path.
+	bool xch = (KS == 3) && (long long)a.groups * a.tilesX >= 4 * 8192;
+#if defined(SWAR_NO_LDS_LR)
+	xch = false;
+#elif defined(SWAR_FORCE_LDS_LR)
+	xch = (KS == 3);
+#endif
+	if constexpr (KS == 3) {
+		if (xch) {
+			if (gap) hipLaunchKernelGGL((canny_swar_tile_kernel<true, kWaves, kRows, KS, true>), grid, block, 0, stream, a);
+			else hipLaunchKernelGGL((canny_swar_tile_kernel<false, kWaves, kRows, KS, true>), grid, block, 0, stream, a);
+			return hipGetLastError();
+		}
+	}
+	if (gap) hipLaunchKernelGGL((canny_swar_tile_kernel<true, kWaves, kRows, KS, false>), grid, block, 0, stream, a);
+	else hipLaunchKernelGGL((canny_swar_tile_kernel<false, kWaves, kRows, KS, false>), grid, block, 0, stream, a);
 	return hipGetLastError();
 }
 
