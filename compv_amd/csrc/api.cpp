@@ -12,11 +12,15 @@
 #include <atomic>
 #include <chrono>
 #include <condition_variable>
+#include <deque>
 #include <functional>
 #include <mutex>
 #include <thread>
 
 #include <hip/hip_runtime.h>
+#if defined(__linux__)
+#include <sched.h>
+#endif
 
 #include <algorithm>
 #include <cmath>
@@ -84,6 +88,7 @@ struct KhtBatchState {
 	KhtVoteParams* params = nullptr; size_t paramsCap = 0; KhtVoteParams* paramsHost = nullptr; size_t paramsHostCap = 0;
 	KhtCell* cells = nullptr; size_t cellsCap = 0; int* cellCount = nullptr; KhtCell* cellsHost = nullptr; size_t cellsHostCap = 0;
 	std::vector<KhtBatchFrame> frames;
+	hipEvent_t syncEv = nullptr;   // blocking-sync event: a controller that waits for a GPU stage SLEEPS (hipStreamSynchronize spins on a CPU of the quota the workers need)
 	double stageMs[6] = {};   // of the groups this state handled in the current call
 };
 
@@ -164,6 +169,7 @@ struct compvhip_plan {
 	int32_t* dKt = nullptr; int32_t* dRowBase = nullptr; uint8_t* partLo = nullptr; uint8_t* partHi = nullptr; uint8_t* colFlag = nullptr; int* tileCounts = nullptr;
 	// batched KHT (compvhip_plan_houghkht): one scratch set + stream per worker thread, stage clocks of the last call
 	std::vector<KhtBatchState*> khtBatch;        // device / pinned buffers and per-frame host state of the batched call: one per group of frames in flight
+	std::vector<std::unique_ptr<KhtPeaksWork>> khtWork;   // sort + sweep workspace (axes, 1.6 MB visited map at 4K) of WORKER w: it stays in that core's cache from frame to frame
 	double khtStageMs[6] = {}; double khtWallMs = 0.0; int khtThreads = 0;
 	// asynchronous steps (compvhip_plan_pipeline_async / compvhip_plan_wait)
 	// seq: enqueue order; replay: an EARLIER step of the plan was replayed after this one ran -- its outputs may have been overwritten
@@ -228,6 +234,7 @@ void khtBatchFree(compvhip_ctx* ctx, KhtBatchState* b)
 	if (b->paramsHost) (void)hipHostFree(b->paramsHost);
 	if (b->cellsHost) (void)hipHostFree(b->cellsHost);
 	for (hipEvent_t e : b->ready) (void)hipEventDestroy(e);
+	if (b->syncEv) (void)hipEventDestroy(b->syncEv);
 	if (b->stream) (void)hipStreamDestroy(b->stream);
 	delete b;
 }
@@ -693,68 +700,108 @@ int validateCannyParams(compvhip_ctx* ctx, float tLow, float tHigh, int ksize, i
 
 // ==================================================================================================================
 namespace {
-// helper threads of ONE call: run(n, fn) executes fn(0) .. fn(n - 1), the frames handed out one at a time, the caller working along.
-// Every run has its own Job object: a helper that is still leaving the previous job when the next one is posted only ever touches the counters of the
-// job it picked up (with shared counters it could take an index of the old job, compare it with the new job's size and run an item twice).
+// The host workers of ONE compvhip_plan_houghkht call, shared by the controllers of all groups in flight: run(n, fn) queues fn(0) .. fn(n - 1) and blocks until
+// every item has returned; the workers take items from the OLDEST job that still has some, so while one group waits for a GPU stage its controller sleeps
+// and the workers link / sweep the frames of the other groups.  (Rounds 4-5 gave every controller a private pool of threads / controllers workers: all
+// groups reached their GPU stages together and the workers of a waiting group idled -- 0.46 ms per 4K frame at 16 threads against 0.30 here.)
+// The callers do not work along: `threads` workers are what runs, whatever the number of controllers.
+thread_local int t_khtWorker = -1;   // index of the pool worker running the current item (-1: not a pool worker)
 class KhtPool {
 	struct Job {
-		const std::function<void(size_t)>* fn; size_t n;
-		std::atomic<size_t> next{0}, left;
-		Job(const std::function<void(size_t)>* f, size_t count) : fn(f), n(count), left(count) {}
+		const std::function<void(size_t)>* fn; size_t n, next = 0;   // next: guarded by the pool's mutex
+		std::atomic<size_t> left; char tag;
+		Job(const std::function<void(size_t)>* f, size_t count, char t) : fn(f), n(count), left(count), tag(t) {}
 	};
+	struct Span { int worker; char tag; double t0, t1; };
 public:
 	explicit KhtPool(size_t threads)
 	{
-		try { for (size_t t = 1; t < threads; ++t) pool_.emplace_back([this] { loop(); }); }
-		catch (...) { /* the system refused another thread: the ones that started (and the caller) share the work */ }
+		trace_ = getenv("COMPVHIP_KHT_TRACE") != nullptr;   // lab: one line per item on stderr when the pool goes (worker, stage tag, start, end in ms)
+		born_ = std::chrono::steady_clock::now();
+		try { for (size_t t = 0; t < std::max<size_t>(1, threads); ++t) pool_.emplace_back([this, t] { t_khtWorker = static_cast<int>(t); loop(); }); }
+		catch (...) { /* the system refused another thread: the ones that started share the work (none at all: run() works itself) */ }
 	}
 	~KhtPool()
 	{
-		{ std::lock_guard<std::mutex> g(m_); quit_ = true; ++gen_; }
+		{ std::lock_guard<std::mutex> g(m_); quit_ = true; }
 		cv_.notify_all();
 		for (std::thread& t : pool_) t.join();
+		if (trace_) for (const Span& sp : spans_) fprintf(stderr, "khtpool w%02d %c %8.3f %8.3f\n", sp.worker, sp.tag, sp.t0, sp.t1);
 	}
-	void run(size_t n, const std::function<void(size_t)>& fn)
+	size_t workers() const { return pool_.size(); }
+	void run(size_t n, const std::function<void(size_t)>& fn, char tag = '?')
 	{
 		if (!n) return;
-		std::shared_ptr<Job> job = std::make_shared<Job>(&fn, n);
-		{ std::lock_guard<std::mutex> g(m_); cur_ = job; ++gen_; }
+		if (pool_.empty()) { for (size_t i = 0; i < n; ++i) fn(i); return; }
+		std::shared_ptr<Job> job = std::make_shared<Job>(&fn, n, tag);
+		{
+			// later stages first (S > K > L > P): a group that is nearly through leaves before the next one starts, and the short K items never queue behind 3 ms links
+			std::lock_guard<std::mutex> g(m_);
+			auto it = jobs_.begin();
+			while (it != jobs_.end() && prio((*it)->tag) >= prio(tag)) ++it;
+			jobs_.insert(it, job);
+		}
 		cv_.notify_all();
-		work(*job);
 		std::unique_lock<std::mutex> lk(m_);
 		done_.wait(lk, [&] { return job->left.load() == 0; });   // every item has RETURNED: fn may go out of scope
-		cur_.reset();
 	}
 private:
-	void work(Job& job)
-	{
-		for (;;) {
-			const size_t i = job.next.fetch_add(1);
-			if (i >= job.n) return;
-			(*job.fn)(i);
-			if (job.left.fetch_sub(1) == 1) { std::lock_guard<std::mutex> g(m_); done_.notify_all(); }
-		}
-	}
+	static int prio(char tag) { return tag == 'S' ? 3 : tag == 'K' ? 2 : tag == 'L' ? 1 : 0; }
 	void loop()
 	{
-		unsigned long seen = 0;
 		for (;;) {
-			std::shared_ptr<Job> job;
+			std::shared_ptr<Job> job; size_t i = 0;
 			{
 				std::unique_lock<std::mutex> lk(m_);
-				cv_.wait(lk, [&] { return gen_ != seen; });
-				seen = gen_;
-				if (quit_) return;
-				job = cur_;
+				cv_.wait(lk, [&] { return quit_ || !jobs_.empty(); });
+				if (jobs_.empty()) return;   // quit_
+				job = jobs_.front();
+				i = job->next++;
+				if (job->next >= job->n) jobs_.pop_front();
 			}
-			if (job) work(*job);
+			const auto t0 = std::chrono::steady_clock::now();
+			(*job->fn)(i);
+			if (trace_) {
+				const auto t1 = std::chrono::steady_clock::now();
+				std::lock_guard<std::mutex> g(m_);
+				spans_.push_back({ t_khtWorker, job->tag, std::chrono::duration<double, std::milli>(t0 - born_).count(), std::chrono::duration<double, std::milli>(t1 - born_).count() });
+			}
+			if (job->left.fetch_sub(1) == 1) { std::lock_guard<std::mutex> g(m_); done_.notify_all(); }
 		}
 	}
+	bool trace_ = false; std::chrono::steady_clock::time_point born_; std::vector<Span> spans_;
 	std::vector<std::thread> pool_;
 	std::mutex m_; std::condition_variable cv_, done_;
-	std::shared_ptr<Job> cur_;
-	unsigned long gen_ = 0; bool quit_ = false;
+	std::deque<std::shared_ptr<Job>> jobs_;
+	bool quit_ = false;
 };
+
+// CPUs this process may really use at once: min(affinity mask, cgroup CPU quota) -- a container can show 256 logical CPUs and own 16 (cpu.max "1600000 100000");
+// twice as many busy threads as the quota only makes the kernel throttle all of them (round 5: 32 threads on a 16-CPU quota, sort + sweep 0.69 -> 1.97 ms per frame)
+size_t hostCpuBudget()
+{
+	size_t n = std::thread::hardware_concurrency();
+	if (!n) n = 4;
+#if defined(__linux__)
+	cpu_set_t set;
+	if (sched_getaffinity(0, sizeof(set), &set) == 0) { const int c = CPU_COUNT(&set); if (c > 0) n = std::min<size_t>(n, static_cast<size_t>(c)); }
+	if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {               // cgroup v2: "<quota|max> <period>"
+		char q[64] = {}; long long period = 0;
+		if (fscanf(f, "%63s %lld", q, &period) == 2 && strcmp(q, "max") != 0 && period > 0) {
+			const long long quota = atoll(q);
+			if (quota > 0) n = std::min<size_t>(n, static_cast<size_t>(std::max<long long>(1, quota / period)));
+		}
+		fclose(f);
+	}
+	else {
+		long long quota = -1, period = 0;
+		if (FILE* fq = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(fq, "%lld", &quota) != 1) quota = -1; fclose(fq); }
+		if (FILE* fp = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(fp, "%lld", &period) != 1) period = 0; fclose(fp); }
+		if (quota > 0 && period > 0) n = std::min<size_t>(n, static_cast<size_t>(std::max<long long>(1, quota / period)));
+	}
+#endif
+	return std::max<size_t>(1, n);
+}
 
 template <typename T>
 hipError_t growPinned(T*& ptr, size_t& cap, size_t want)
@@ -1981,6 +2028,10 @@ static int khtBatchGroup(compvhip_plan* p, KhtBatchState& B, KhtPool& pool, cons
 	const size_t W = p->W, H = p->H, S = p->S;
 	const size_t wpr = (W + 31) / 32, words = wpr * H;
 	hipStream_t st = B.stream;
+	auto sleepSync = [&]() -> hipError_t {   // the stream's work so far, waited for without spinning
+		hipError_t e = hipEventRecord(B.syncEv, st);
+		return e != hipSuccess ? e : hipEventSynchronize(B.syncEv);
+	};
 	// (several groups run at the same time, each on its own controller thread: errors travel back as (code, text), only the caller touches ctx->err)
 // (an early return must not leave asynchronous copies in flight towards this frame's stack arrays or the pinned state: drain the stream first, result ignored)
 #define BCHK(call) do { hipError_t e__ = (call); if (e__ != hipSuccess) { err = std::string(#call) + ": " + hipGetErrorString(e__); (void)hipStreamSynchronize(st); return COMPVHIP_E_HIP; } } while (0)
@@ -2015,7 +2066,7 @@ static int khtBatchGroup(compvhip_plan* p, KhtBatchState& B, KhtPool& pool, cons
 		khtPlaneFromWords(B.hostBits + f * words, wpr, W, H, fr.plane);
 		fr.most = khtPlaneCount(fr.plane);
 		fr.ms[0] += msSince(t0);
-	}); });
+	}); }, 'P');
 	int rc = firstError();
 	if (rc) return rc;
 	size_t total = 0;
@@ -2023,11 +2074,15 @@ static int khtBatchGroup(compvhip_plan* p, KhtBatchState& B, KhtPool& pool, cons
 	if (total > 0x7fffffffull) { err = "too many edge pixels in the batch"; return COMPVHIP_E_INVALID_PARAMETER; }
 	BCHK(growPinned(B.linked, B.linkedCap, total + 1));
 	// ---- B. linking (Appendix A): sequential inside a frame, the frames in parallel; every frame's points go straight into its slice of the pinned arena ----
-	pool.run(G, [&](size_t f) { guarded(f, [&](KhtBatchFrame& fr) {
+	// (longest first: the items are milliseconds long and few, the last ones decide when the group moves on)
+	std::vector<size_t> byWork(G);
+	for (size_t f = 0; f < G; ++f) byWork[f] = f;
+	std::sort(byWork.begin(), byWork.end(), [&](size_t a, size_t b) { return B.frames[a].most > B.frames[b].most; });
+	pool.run(G, [&](size_t i) { const size_t f = byWork[i]; guarded(f, [&](KhtBatchFrame& fr) {
 		const auto t0 = clk::now();
 		fr.nPts = khtLink(fr.plane, clusterMinSize, B.linked + fr.ptsOff, fr.strings);
 		fr.ms[0] += msSince(t0);
-	}); });
+	}); }, 'L');
 	rc = firstError();
 	if (rc) return rc;
 
@@ -2079,7 +2134,7 @@ static int khtBatchGroup(compvhip_plan* p, KhtBatchState& B, KhtPool& pool, cons
 		BCHK(launch_kht_subdivide(sv, tabS, st));
 		uint32_t tot[kKhtBatch + 1];
 		BCHK(hipMemcpyAsync(tot, B.totals, sizeof(tot), hipMemcpyDeviceToHost, st));
-		BCHK(hipStreamSynchronize(st));
+		BCHK(sleepSync());
 		if (tot[kKhtBatch]) { err = "cluster subdivision ran out of recursion slots"; return COMPVHIP_E_INVALID_STATE; }   // cannot happen: clusterMinSize >= 2 is enforced and khtSubdivSlots bounds the depth for it
 		for (size_t f = 0; f < G; ++f) B.frames[f].nClusters = B.frames[f].strings.empty() ? 0u : tot[f];
 	}
@@ -2104,7 +2159,7 @@ static int khtBatchGroup(compvhip_plan* p, KhtBatchState& B, KhtPool& pool, cons
 				const KhtBatchFrame& fr = B.frames[f];
 				if (fr.nClusters) BCHK(hipMemcpyAsync(B.kernelsHost + fr.slotBase, B.kernelsDev + fr.slotBase, fr.nClusters * sizeof(KhtKernel), hipMemcpyDeviceToHost, st));
 			}
-			BCHK(hipStreamSynchronize(st));
+			BCHK(sleepSync());
 		}
 	}
 	B.stageMs[2] += msSince(tc);
@@ -2118,7 +2173,7 @@ static int khtBatchGroup(compvhip_plan* p, KhtBatchState& B, KhtPool& pool, cons
 		fr.GS = khtPruneAndScale(fr.kernels, fr.hmax, kernelMinHeight);
 		if (!fr.kernels.empty()) { fr.haveGS = true; khtVoteParams(ax, fr.kernels, fr.params); }
 		fr.ms[3] += msSince(t0);
-	}); });
+	}); }, 'K');
 	rc = firstError();
 	if (rc) return rc;
 
@@ -2151,7 +2206,7 @@ static int khtBatchGroup(compvhip_plan* p, KhtBatchState& B, KhtPool& pool, cons
 		BCHK(launch_kht_peaks(a, tabV, st));
 		int cc[kKhtBatch];
 		BCHK(hipMemcpyAsync(cc, B.cellCount, sizeof(cc), hipMemcpyDeviceToHost, st));
-		BCHK(hipStreamSynchronize(st));
+		BCHK(sleepSync());
 		size_t nCells = 0;
 		for (size_t f = 0; f < G; ++f) {
 			KhtBatchFrame& fr = B.frames[f];
@@ -2164,22 +2219,27 @@ static int khtBatchGroup(compvhip_plan* p, KhtBatchState& B, KhtPool& pool, cons
 				const KhtBatchFrame& fr = B.frames[f];
 				if (fr.cellCount) BCHK(hipMemcpyAsync(B.cellsHost + fr.cellOff, B.cells + f * cellCap, static_cast<size_t>(fr.cellCount) * sizeof(KhtCell), hipMemcpyDeviceToHost, st));
 			}
-			BCHK(hipStreamSynchronize(st));
+			BCHK(sleepSync());
 		}
 	}
 	B.stageMs[4] += msSince(tc);
 
 	// ---- F. sort + sweep with the visited map (order dependent, :1195-1247): per frame, on the pool ----
-	pool.run(G, [&](size_t f) { guarded(f, [&](KhtBatchFrame& fr) {
+	for (size_t f = 0; f < G; ++f) byWork[f] = f;
+	std::sort(byWork.begin(), byWork.end(), [&](size_t a, size_t b) { return B.frames[a].cellCount > B.frames[b].cellCount; });
+	pool.run(G, [&](size_t i) { const size_t f = byWork[i]; guarded(f, [&](KhtBatchFrame& fr) {
 		if (fr.haveGS && gs) gs[f] = fr.GS;
 		if (!fr.cellCount) { counts[f] = 0; return; }
 		const auto t0 = clk::now();
 		fr.cells.assign(B.cellsHost + fr.cellOff, B.cellsHost + fr.cellOff + fr.cellCount);
-		khtPeaks(ax, fr.cells, maxLines, fr.out, fr.peaks);
+		// the WORKER's workspace, not the frame's: 32 frames x 1.6 MB of visited maps cycled through the caches (sort + sweep 0.69 ms for a frame alone, 1.9 in a batch)
+		const int w = t_khtWorker;
+		KhtPeaksWork& wk = (w >= 0 && static_cast<size_t>(w) < p->khtWork.size() && p->khtWork[w]) ? *p->khtWork[w] : fr.peaks;
+		khtPeaks(ax, fr.cells, maxLines, fr.out, wk);
 		counts[f] = fr.out.size();
 		if (lines) khtCopyLines(fr.out, lines + f * cap, cap);
 		fr.ms[5] += msSince(t0);
-	}); });
+	}); }, 'S');
 	rc = firstError();
 	if (rc) return rc;
 	for (size_t f = 0; f < G; ++f) {
@@ -2204,18 +2264,23 @@ int compvhip_plan_houghkht(compvhip_plan* p, const uint8_t* d_edges, float rho, 
 	HIPCHK(ctx, hipSetDevice(ctx->device));
 	unsigned hw = std::thread::hardware_concurrency();
 	if (!hw) hw = 4;
-	size_t T = hostThreads > 0 ? static_cast<size_t>(hostThreads) : std::min<size_t>(32, std::max<size_t>(1, hw / 2));
+	// default: what the host really grants (affinity mask, cgroup quota), at most 32, at most half the hardware threads
+	size_t T = hostThreads > 0 ? static_cast<size_t>(hostThreads) : std::min<size_t>(std::min<size_t>(32, hostCpuBudget()), std::max<size_t>(1, hw / 2));
 	T = std::min(T, F);
 	// The frames go through the stages in GROUPS of kKhtGroup, up to four groups at a time, each with its own controller thread, stream, buffers and share
 	// of the host threads: inside a group the stages are batched (one launch, one transfer per stage), and while one group is in a GPU stage the host
 	// threads of the others link or sweep.  (One group of 32 frames: every stage waits for the slowest frame and the GPU stages -- 100 MB over PCIe per
 	// 4K batch -- wait for all of them: 18-20 ms per batch against 10.9 ms for the thread-per-frame pipeline of round 4; measured)
-	const size_t nGroups = (F + kKhtGroup - 1) / kKhtGroup;
-	const size_t K = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(T / 4, 4), nGroups));   // controllers = groups in flight
+	size_t group = kKhtGroup;
+	if (const char* e = getenv("COMPVHIP_KHT_GROUP")) { const long v = atol(e); if (v >= 1 && v <= kKhtBatch) group = static_cast<size_t>(v); }   // lab knob
+	const size_t nGroups = (F + group - 1) / group;
+	// controllers = groups in flight.  A controller only enqueues GPU work, sleeps on it and posts its group's host stages to the shared workers, so there are
+	// enough of them to keep the workers fed while some groups are on the GPU: all groups of a 32-frame batch, two groups per four workers otherwise.
+	const size_t K = std::max<size_t>(1, std::min<size_t>(std::min<size_t>(std::max<size_t>(2, T / 2), kKhtMaxInFlight), nGroups));
 	// The producer of d_edges may still be running on the caller's stream; the groups use private streams: drain the device first (the call is
 	// synchronous and takes milliseconds -- the drain is not what bounds it)
 	HIPCHK(ctx, hipDeviceSynchronize());
-	const size_t G0 = std::min<size_t>(F, kKhtGroup), words = ((W + 31) / 32) * H;
+	const size_t G0 = std::min<size_t>(F, group), words = ((W + 31) / 32) * H;
 	while (p->khtBatch.size() < K) {
 		KhtBatchState* b = new (std::nothrow) KhtBatchState();
 		if (!b) return fail(ctx, COMPVHIP_E_OUT_OF_MEMORY, "KHT batch state");
@@ -2224,6 +2289,7 @@ int compvhip_plan_houghkht(compvhip_plan* p, const uint8_t* d_edges, float rho, 
 	for (size_t k = 0; k < K; ++k) {
 		KhtBatchState& B = *p->khtBatch[k];
 		if (!B.stream) HIPCHK(ctx, hipStreamCreateWithFlags(&B.stream, hipStreamNonBlocking));
+		if (!B.syncEv) HIPCHK(ctx, hipEventCreateWithFlags(&B.syncEv, hipEventBlockingSync | hipEventDisableTiming));
 		if (B.bitsWords < words * G0) {
 			dfree(ctx, B.dBits); if (B.hostBits) (void)hipHostFree(B.hostBits);
 			B.hostBits = nullptr; B.bitsWords = 0;
@@ -2246,14 +2312,14 @@ int compvhip_plan_houghkht(compvhip_plan* p, const uint8_t* d_edges, float rho, 
 	std::vector<std::string> errs(K);
 	std::vector<size_t> badGroup(K, 0);
 	std::atomic<int> overflowAny{0};
+	while (p->khtWork.size() < T) p->khtWork.emplace_back(new KhtPeaksWork());
+	KhtPool pool(T);   // the workers of this call, shared by every group in flight
 	auto controller = [&](size_t k) {
 		try {
-			const size_t mine = T / K + (k < T % K ? 1 : 0);   // the controller is one of its group's host threads
-			KhtPool pool(std::max<size_t>(1, mine));
 			for (;;) {
 				const size_t g = nextGroup.fetch_add(1);
 				if (g >= nGroups) break;
-				const size_t g0 = g * kKhtGroup, G = std::min<size_t>(kKhtGroup, F - g0);
+				const size_t g0 = g * group, G = std::min<size_t>(group, F - g0);
 				bool overflow = false;
 				const int r = khtBatchGroup(p, *p->khtBatch[k], pool, d_edges + g0 * S * H, G, ax, threshold, maxLines, clusterMinDeviation, clusterMinSize, kernelMinHeight,
 				                            lines ? lines + g0 * cap : nullptr, cap, counts + g0, gs ? gs + g0 : nullptr, &overflow, errs[k]);

@@ -54,6 +54,7 @@ void khtPeaks(const KhtAxes& ax, std::vector<KhtCell>& cells, int maxLines, std:
 // travel by value in the kernel arguments (blockIdx.y / .z = frame).
 constexpr int kKhtBatch = 32;      // frames a launch can cover (size of the by-value tables)
 constexpr int kKhtGroup = 8;       // frames compvhip_plan_houghkht puts through the stages together
+constexpr int kKhtMaxInFlight = 8; // groups in flight at most (controllers: own stream, buffers and bit planes each)
 struct KhtBatchStrings { uint32_t stringBegin[kKhtBatch + 1]; uint32_t clusterBase[kKhtBatch]; int frames; };   // strings of frame f: [stringBegin[f], stringBegin[f + 1]); its clusters start at clusterBase[f]
 struct KhtBatchStats { uint32_t clusterBase[kKhtBatch]; int n[kKhtBatch]; int simdEnd[kKhtBatch]; int frames; };   // simdEnd: clusters [0, simdEnd) of the frame use the SIMD operation order of the kernel height
 struct KhtBatchVote { uint32_t paramsBase[kKhtBatch]; int nKernels[kKhtBatch]; double gs[kKhtBatch]; int frames; size_t mapElems, cellCap; };   // vote map / cell list of frame f at f * mapElems / f * cellCap
