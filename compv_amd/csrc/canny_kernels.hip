@@ -109,6 +109,23 @@ __global__ __launch_bounds__(kResolveThreads) void canny_resolve_kernel(ResolveA
 	const int r0 = grp * rpg;
 	const int n = (grp < nGroups) ? max(min(rpg, rows - r0), 0) : 0;  // rows of this thread
 	uint32_t u[kResolveRows], e[kResolveRows + 2];
+	const uint32_t ewInv = (1u << 19) / (uint32_t)ew + 1u;   // i / ew == (i * ewInv) >> 19 for every i < 66 * 66, 3 <= ew <= 66 (verified exhaustively)
+	// The band's E words with their halo go to the LDS: up to nine words per thread, loaded unconditionally from clamped addresses and masked afterwards
+	// (`if (inside) v = gE[...]` made every word wait for the one before), and ISSUED TOGETHER WITH the thread's U words: the test "anything unresolved in
+	// this band?" needs the U words only, but nearly every band of a real frame passes it, and two memory latencies one after the other per workgroup
+	// cost 1.6 us per launch (round 6: 59 -> 54 us for the three rounds of a 32 x 4K step).
+	const int nE = (rows + 2) * ew;
+	constexpr int kEPer = (66 * 66 + kResolveThreads - 1) / kResolveThreads;   // 9: (kBandH + 2) x (kBandWords + 2) words over the workgroup
+	uint32_t ev[kEPer];
+#pragma unroll
+	for (int q = 0; q < kEPer; ++q) {
+		const int i = min(tid + q * kResolveThreads, nE - 1);
+		const int r = (int)(((uint32_t)i * ewInv) >> 19), c = i - r * ew;
+		const int y = y0 - 1 + r, w = w0 - 1 + c;
+		const bool ok = (y >= 0 && y < a.H && w >= 0 && w < wb);
+		ev[q] = gE[(size_t)min(max(y, 0), a.H - 1) * wb + min(max(w, 0), wb - 1)];
+		if (!ok) ev[q] = 0u;
+	}
 	int haveU = 0;
 #pragma unroll
 	for (int j = 0; j < kResolveRows; ++j) {
@@ -116,25 +133,10 @@ __global__ __launch_bounds__(kResolveThreads) void canny_resolve_kernel(ResolveA
 		haveU |= (u[j] != 0);
 	}
 	if (!__syncthreads_or(haveU)) { if (tid == 0) *mine = 0; return; }  // nothing unresolved in this band
-	const uint32_t ewInv = (1u << 19) / (uint32_t)ew + 1u;   // i / ew == (i * ewInv) >> 19 for every i < 66 * 66, 3 <= ew <= 66 (verified exhaustively)
-	// (three words per thread and step, loaded unconditionally from clamped addresses and masked afterwards: the loads of a step are in
-	// flight together; `if (inside) v = gE[...]` made every word of the ~9 per thread wait for the one before)
-	const int nE = (rows + 2) * ew;
-	for (int i0 = tid; i0 < nE; i0 += 3 * kResolveThreads) {
-		uint32_t v[3]; bool ok[3];
 #pragma unroll
-		for (int q = 0; q < 3; ++q) {
-			const int i = min(i0 + q * kResolveThreads, nE - 1);
-			const int r = (int)(((uint32_t)i * ewInv) >> 19), c = i - r * ew;
-			const int y = y0 - 1 + r, w = w0 - 1 + c;
-			ok[q] = (y >= 0 && y < a.H && w >= 0 && w < wb);
-			v[q] = gE[(size_t)min(max(y, 0), a.H - 1) * wb + min(max(w, 0), wb - 1)];
-		}
-#pragma unroll
-		for (int q = 0; q < 3; ++q) {
-			const int i = i0 + q * kResolveThreads;
-			if (i < nE) sE[i] = ok[q] ? v[q] : 0u;
-		}
+	for (int q = 0; q < kEPer; ++q) {
+		const int i = tid + q * kResolveThreads;
+		if (i < nE) sE[i] = ev[q];
 	}
 	__syncthreads();
 	uint32_t* const col = sE + (size_t)(n > 0 ? r0 : 0) * ew + k + 1;   // LDS word of (row r0 - 1, column k); row j of the group is col[(j + 1) * ew]
