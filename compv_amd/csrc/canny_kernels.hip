@@ -115,7 +115,7 @@ __global__ __launch_bounds__(kResolveThreads) void canny_resolve_kernel(ResolveA
 	// this band?" needs the U words only, but nearly every band of a real frame passes it, and two memory latencies one after the other per workgroup
 	// cost 1.6 us per launch (round 6: 59 -> 54 us for the three rounds of a 32 x 4K step).
 	const int nE = (rows + 2) * ew;
-	constexpr int kEPer = (66 * 66 + kResolveThreads - 1) / kResolveThreads;   // 9: (kBandH + 2) x (kBandWords + 2) words over the workgroup
+	constexpr int kEPer = ((kBandH + 2) * (kBandWords + 2) + kResolveThreads - 1) / kResolveThreads;   // 9: (kBandH + 2) x (kBandWords + 2) words over the workgroup
 	uint32_t ev[kEPer];
 #pragma unroll
 	for (int q = 0; q < kEPer; ++q) {

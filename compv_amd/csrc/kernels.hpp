@@ -9,7 +9,10 @@
 namespace compvhip {
 
 // ---- Canny ------------------------------------------------------------------------------------------------
-constexpr int kBandH = 64;            // rows per resolve band
+#ifndef COMPVHIP_BAND_H
+#define COMPVHIP_BAND_H 64
+#endif
+constexpr int kBandH = COMPVHIP_BAND_H;            // rows per resolve band
 constexpr int kBandWords = 64;        // 32-px words per resolve chunk (2048 columns): 0.056 ms per step at 4K, 0.075 ms with 128
 constexpr int kResolveThreads = 512;
 // Per-frame counters that many workgroups hit with atomics (Sobel gmax, the pixel sum of the mean thresholds) sit one per 128-byte line: the
