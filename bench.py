@@ -969,14 +969,16 @@ def kht_figure(capi, ctx, torch, lane, blocks, W, H, F):
             sm = ctx.houghkht_stage_ms()            # link, subdivide, statistics, prune, vote + peaks, sort + sweep
             gpu_ms = float(sm[1] + sm[2] + sm[4])
             traffic = None
-            tj = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r05", "kht_traffic.json")
-            if os.path.exists(tj):
+            prof = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles")
+            have = sorted(d for d in os.listdir(prof) if os.path.exists(os.path.join(prof, d, "kht_traffic.json")))
+            tj = os.path.join(prof, have[-1], "kht_traffic.json") if have else ""
+            if tj:
                 tdat = json.load(open(tj))
                 traffic = tdat.get("hbm_bytes_per_call") if tdat.get("so_sha256") == so_sha256() else None
             roof = {"bound": "hbm", "algorithmic_bytes_per_frame": alg, "gpu_stage_ms_single_frame": round(gpu_ms, 4),
                     "achieved": round(alg / (gpu_ms * 1e-3) / 1e9, 2) if gpu_ms > 0 else None, "peak": 8000.0, "unit": "GB/s",
                     "frac": round(alg / (gpu_ms * 1e-3) / 1e9 / 8000.0, 5) if gpu_ms > 0 else None, "traffic": traffic,
-                    "note": "the KHT is latency-bound, not bandwidth-bound: its GPU stages move a few MB per frame (profiles/r05/kht_pmc*); W*H + (T+2)(rhoN+2)*4 bytes per frame "
+                    "note": "the KHT is latency-bound, not bandwidth-bound: its GPU stages move a few MB per frame (profiles/r0*/kht_pmc*); W*H + (T+2)(rhoN+2)*4 bytes per frame "
                             "over the wall time of the subdivision + statistics + voting/peaks stages of one single-frame call (uploads, kernels, downloads, synchronisations)"}
     except Exception as e:  # reporting only
         roof = {"error": str(e)}
