@@ -135,6 +135,10 @@ struct compvhip_plan {
 	// sorts a range predicted from the totals of the plan's last steps (0 = none seen yet: the whole capacity) -- compvhip_plan_wait compares with the step's
 	// real total and replays the step when the prediction was too small.
 	unsigned int recentTotals[8] = {}; int recentN = 0;
+	// speculative hysteresis rounds of a step: what the plan's last 8 asynchronous steps needed (the first round that changed nothing, inclusive), at least 2, at
+	// most kSpecRounds; a step that needs more is replayed by compvhip_plan_wait and teaches the plan
+	int specRounds = kSpecRounds; unsigned char recentRounds[8] = {}; int recentRoundsN = 0;
+	int* hRounds = nullptr;                      // pinned host: the first 4 round flags of the asynchronous steps, 4 ints per ticket
 	int roundsUsed = 0;
 	int maxRounds = kMaxRounds; // flag slots in use (COMPVHIP_RESOLVE_WRAP lowers it: tests of the slot reuse)
 	bool countersFresh = false; // the step's memset already zeroed the edge/line counts (no second fill in front of the SHT stage)
@@ -173,7 +177,7 @@ struct compvhip_plan {
 	double khtStageMs[6] = {}; double khtWallMs = 0.0; int khtThreads = 0;
 	// asynchronous steps (compvhip_plan_pipeline_async / compvhip_plan_wait)
 	// seq: enqueue order; replay: an EARLIER step of the plan was replayed after this one ran -- its outputs may have been overwritten
-	struct AsyncStep { bool used = false; bool replay = false; uint64_t seq = 0; hipEvent_t done = nullptr; hipStream_t stream = nullptr; StepParams sp; size_t sortN = 0; } steps[kAsyncDepth];
+	struct AsyncStep { bool used = false; bool replay = false; uint64_t seq = 0; hipEvent_t done = nullptr; hipStream_t stream = nullptr; StepParams sp; size_t sortN = 0; int rounds = 0; } steps[kAsyncDepth];
 	uint64_t stepSeq = 0;
 	// timing
 	int timing = 0; // 0 off, 1 every kernel, 2 canny_tile + sht_vote, 3 sht_vote only, 4 canny_tile only
@@ -976,6 +980,7 @@ int compvhip_plan_create(compvhip_ctx* ctx, size_t W, size_t H, size_t S, size_t
 		if (dmalloc(ctx, &p->sums, frames * kFrameSlot) != hipSuccess) { rc = COMPVHIP_E_OUT_OF_MEMORY; break; }
 		if (hipHostMalloc(reinterpret_cast<void**>(&p->hFlags), sizeof(int) * 2 * (kAsyncDepth + 1)) != hipSuccess) { rc = COMPVHIP_E_OUT_OF_MEMORY; break; }
 		p->hTotals = reinterpret_cast<unsigned int*>(p->hFlags + kAsyncDepth + 1);
+		if (hipHostMalloc(reinterpret_cast<void**>(&p->hRounds), sizeof(int) * 4 * kAsyncDepth) != hipSuccess) { rc = COMPVHIP_E_OUT_OF_MEMORY; break; }
 	} while (0);
 	if (rc) { compvhip_plan_destroy(p); return fail(ctx, rc, "plan allocation"); }
 	*out = p;
@@ -993,6 +998,7 @@ void compvhip_plan_destroy(compvhip_plan* p)
 	dfree(ctx, p->dirty);
 	dfree(ctx, p->ebits); dfree(ctx, p->ubits); dfree(ctx, p->counters); dfree(ctx, p->thrDev); dfree(ctx, p->sums); dfree(ctx, p->tmpOut);
 	if (p->hFlags) (void)hipHostFree(p->hFlags);
+	if (p->hRounds) (void)hipHostFree(p->hRounds);
 	dfree(ctx, p->hist); dfree(ctx, p->otsu); dfree(ctx, p->blurTmp); dfree(ctx, p->grayTmp);
 	for (KhtBatchState* b : p->khtBatch) khtBatchFree(ctx, b);
 	p->khtBatch.clear();
@@ -1049,7 +1055,7 @@ static int planCannyImpl(compvhip_plan* p, const uint8_t* d_in, float tLow, floa
 	if (p->W < static_cast<size_t>(ksize) || p->H < static_cast<size_t>(ksize)) return fail(ctx, COMPVHIP_E_INVALID_PARAMETER, "image smaller than the kernel"); // compv_math_convlt.h:100
 	rc = enqueueCanny(p, d_in, out, lo, hi, ksize, type, tLow, tHigh, st);
 	if (rc) return rc;
-	rc = enqueueResolve(p, p->patchOut, kSpecRounds, st);
+	rc = enqueueResolve(p, p->patchOut, waitConverged ? kSpecRounds : p->specRounds, st);
 	if (rc) return rc;
 	if (waitConverged) {
 		for (;;) {
@@ -1359,9 +1365,11 @@ static int runStepAsync(compvhip_plan* p, const StepParams& sp, hipStream_t st, 
 	rc = enqueueStepTail(p, sp, st, sortN);
 	if (rc) return rc;
 	HIPCHK(ctx, hipMemcpyAsync(p->hFlags + 1 + slot, p->flags + (p->roundsUsed - 1), sizeof(int), hipMemcpyDeviceToHost, st));
+	static_assert(kMaxRounds >= 4, "the round flags compvhip_plan_wait learns from");
+	HIPCHK(ctx, hipMemcpyAsync(p->hRounds + 4 * slot, p->flags, sizeof(int) * 4, hipMemcpyDeviceToHost, st));
 	HIPCHK(ctx, hipMemcpyAsync(p->hTotals + 1 + slot, p->lineTotal, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
 	HIPCHK(ctx, hipEventRecord(stp.done, st));
-	stp.used = true; stp.replay = false; stp.seq = ++p->stepSeq; stp.stream = st; stp.sp = sp; stp.sortN = sortN;
+	stp.used = true; stp.replay = false; stp.seq = ++p->stepSeq; stp.stream = st; stp.sp = sp; stp.sortN = sortN; stp.rounds = p->roundsUsed;
 	*ticket = slot;
 	return COMPVHIP_OK;
 }
@@ -1422,6 +1430,18 @@ int compvhip_plan_wait(compvhip_plan* p, int ticket)
 	p->recentTotals[p->recentN++ & 7] = total;
 	if (p->recentN >= 16) p->recentN -= 8;   // the ring index keeps counting, "entries seen" saturates at 8
 	const bool sorted = static_cast<size_t>(total) <= stp.sortN;   // the predicted range covered every line of the step
+	{
+		// rounds this step needed = the first round that changed nothing, inclusive (more than were enqueued: one more than that, at least)
+		const int* rf = p->hRounds + 4 * ticket;
+		int needed = std::min(stp.rounds, 4) + 1;
+		for (int i = 0; i < std::min(stp.rounds, 4); ++i) if (rf[i] == 0) { needed = i + 1; break; }
+		p->recentRounds[p->recentRoundsN++ & 7] = static_cast<unsigned char>(std::min(needed, 255));
+		if (p->recentRoundsN >= 16) p->recentRoundsN -= 8;
+		int m = 2;
+		for (int i = 0; i < std::min(p->recentRoundsN, 8); ++i) m = std::max<int>(m, p->recentRounds[i]);
+		p->specRounds = (p->recentRoundsN >= 4) ? std::min(m, kSpecRounds) : kSpecRounds;   // a few steps first, then as many as they needed
+		if (getenv("COMPVHIP_TRACE_ROUNDS")) fprintf(stderr, "plan %p ticket %d: rounds enqueued %d, flags %d %d %d %d, needed %d -> next %d\n", (void*)p, ticket, stp.rounds, rf[0], rf[1], rf[2], rf[3], needed, p->specRounds);
+	}
 	if (p->hFlags[1 + ticket] == 0 && sorted && !stp.replay) return COMPVHIP_OK; // the speculative rounds reached the fixed point and the sort covered the lines (the usual case)
 	// Rare: the hysteresis of this step needed more rounds than were enqueued (or it produced more lines than the sorted range held), and a later step may
 	// already have reused the plan's masks.  Let the stream drain and run the step again, synchronously, from its (unmodified) input.  The replay writes this

@@ -267,6 +267,9 @@ COMPVHIP_API int compvhip_plan_pipeline(compvhip_plan* plan, const uint8_t* d_in
  * when it is waited for, in enqueue order, so after compvhip_plan_wait(t) the buffers of step t always hold step t's results.  Wait for the tickets
  * of a plan in the order they were issued.  Results of step t are only guaranteed to still be there until the next step that shares its buffers
  * starts -- give steps their own buffers to read them later.
+ * Speculative rounds: a step enqueues as many hysteresis rounds as the plan's last 8 asynchronous steps needed (the first round that changed nothing,
+ * inclusive): 3 for a new plan, 2 once four steps have needed no more (the benchmark's frames: round 0 does the work, round 1 confirms), never more than 3; a
+ * step that needs more is the replay described above, and the plan enqueues 3 again for the steps after it.
  * A second replay cause exists only on the library-sort fallback (max(W, H) > 4095, or more than 32 chunks of 4096 lines per frame): there the step
  * sorts a PREDICTED range of the line keys -- the largest line total of the plan's last 8 steps + 1/16 + 4096 -- and compvhip_plan_wait replays the
  * step when its real total exceeded the prediction.  Content whose line count jumps from step to step therefore replays often on such plans, and each

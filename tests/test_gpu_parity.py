@@ -1161,6 +1161,41 @@ def test_plan_wide_frames_use_the_library_sort_sized_by_the_lines(hip_ctx, oracl
         plan.close()
 
 
+def test_async_speculative_rounds_adapt_and_recover(hip_ctx, oracle):
+    """Round 6: a plan enqueues as many speculative hysteresis rounds as its recent asynchronous steps needed (2 once four easy steps have been seen, never
+    more than 3).  Six easy steps teach it 2; then a frame whose weak chains cross a dozen bands needs far more -- compvhip_plan_wait must replay it and return
+    the reference's edge map --, and an easy step after it is right again."""
+    import torch
+    from compv_amd import capi
+    W, H, n, cap = 1104, 700, 1, 4096
+    serp = np.full((H, W), 100, np.uint8)
+    for k, yy in enumerate(range(20, H - 20, 12)):
+        serp[yy:yy + 3, 15:W - 15] = 112
+        xs = W - 30 if (k % 2 == 0) else 15
+        serp[yy:yy + 15, xs:xs + 3] = 112
+    serp[18:26, 10:20] = 255
+    easy = [synth_frame(W, H, 40 + i) for i in range(7)]
+    seq = [(e, 59.0, 119.0) for e in easy[:6]] + [(serp, 10.0, 200.0), (easy[6], 59.0, 119.0)]
+    dev = torch.device("cuda:0")
+    plan = capi.Plan(hip_ctx, W, H, W, n, 1.0)
+    st = torch.cuda.Stream(device=dev)
+    try:
+        for i, (img, tl, th) in enumerate(seq):
+            d_in = torch.from_numpy(img[None]).to(dev)
+            d_e = torch.empty((n, H, W), dtype=torch.uint8, device=dev)
+            d_l = torch.zeros((n, cap, 5), dtype=torch.int32, device=dev); d_c = torch.zeros(n, dtype=torch.int32, device=dev)
+            torch.cuda.synchronize()
+            t = plan.pipeline_async(d_in.data_ptr(), tl, th, 40, 0, d_e.data_ptr(), d_l.data_ptr(), cap, d_c.data_ptr(), st.cuda_stream)
+            plan.wait(t)
+            st.synchronize()
+            rc, e = oracle.canny(img, tl, th)
+            got = d_e.cpu().numpy()[0]
+            assert (got == e).all(), (i, int((got != e).sum()))
+            assert int(d_c.cpu().numpy()[0]) == len(oracle.sht(e, 1.0, 40)), i
+    finally:
+        plan.close()
+
+
 def test_async_replay_with_shared_output_buffers(hip_ctx, oracle):
     """compvhip_plan_wait's replay rule (include/compv_hip.h): steps in flight may SHARE their output buffers; when an earlier step is replayed
     (its hysteresis needed more rounds than were enqueued), the later steps are replayed too when they are waited for, so after wait(t) the
