@@ -138,7 +138,8 @@ struct compvhip_plan {
 	// speculative hysteresis rounds of a step: what the plan's last 8 asynchronous steps needed (the first round that changed nothing, inclusive), at least 2, at
 	// most kSpecRounds; a step that needs more is replayed by compvhip_plan_wait and teaches the plan
 	int specRounds = kSpecRounds; unsigned char recentRounds[8] = {}; int recentRoundsN = 0;
-	int* hRounds = nullptr;                      // pinned host: the first 4 round flags of the asynchronous steps, 4 ints per ticket
+	int* hRoundsDev = nullptr; int* stepHostSlot = nullptr;   // hRounds as the device sees it / the slot of the asynchronous step being enqueued (nullptr otherwise)
+	int* hRounds = nullptr;                      // pinned host, per ticket: [0] the step's line total (the last int of its counter slot ... see runStepAsync), [kFrameSlot .. +3] its first 4 round flags
 	int roundsUsed = 0;
 	int maxRounds = kMaxRounds; // flag slots in use (COMPVHIP_RESOLVE_WRAP lowers it: tests of the slot reuse)
 	bool countersFresh = false; // the step's memset already zeroed the edge/line counts (no second fill in front of the SHT stage)
@@ -592,7 +593,7 @@ ShtArgs shtArgs(compvhip_plan* p, int threshold)
 	ShtArgs a;
 	a.ebits = p->ebits; a.edges = p->edges; a.edgeCounts = p->edgeCounts; a.acc = p->acc;
 	a.sinQ = p->sinQ; a.cosQ = p->cosQ; a.lineKeys = p->keysA; a.lineVals = p->valsA; a.lineCounts = p->lineCounts;
-	a.frameTotals = p->frameTotals; a.lineTotal = p->lineTotal; a.sortN = 0;
+	a.frameTotals = p->frameTotals; a.lineTotal = p->lineTotal; a.sortN = 0; a.outCounts = nullptr; a.stepFlags = nullptr; a.hostStep = nullptr;
 	a.nmsRange = p->nmsRange; a.blockCounts = p->blockCounts; a.lineBlocks = p->lineBlocks; a.nmsFlags = p->nmsFlags; a.nmsRows = static_cast<int>(sht_nms_rows(static_cast<int>(p->R))); a.nmsGroups = sht_nms_groups(static_cast<int>(p->T));
 	a.bitsFrameStride = p->bitsFrameStride; a.edgeCap = p->edgeCap; a.accFrameStride = p->accFrameStride; a.lineCap = p->lineCap;
 	a.W = static_cast<int>(p->W); a.H = static_cast<int>(p->H); a.wb = p->wb;
@@ -618,6 +619,7 @@ int enqueueCanny(compvhip_plan* p, const uint8_t* d_in, uint8_t* d_out, int tLow
 {
 	compvhip_ctx* ctx = p->ctx;
 	CannyArgs a;
+	a.zero = nullptr; a.nZero = 0;
 	a.in = d_in; a.out = d_out; a.ebits = p->ebits; a.ubits = p->ubits; a.thrDev = (thrMode != COMPVHIP_CANNY_THRESHOLD_COMPARE_TO_GRADIENT) ? p->thrDev : nullptr;
 	a.inFrameStride = p->S * p->H; a.outFrameStride = p->S * p->H; a.bitsFrameStride = p->bitsFrameStride;
 	a.W = static_cast<int>(p->W); a.H = static_cast<int>(p->H); a.S = static_cast<int>(p->S); a.So = static_cast<int>(p->S);
@@ -635,8 +637,9 @@ int enqueueCanny(compvhip_plan* p, const uint8_t* d_in, uint8_t* d_out, int tLow
 		Stamp s(p, st, "canny_mean_thresholds");
 		HIPCHK(ctx, launch_mean_thresholds(d_in, a.W, a.H, a.S, a.inFrameStride, static_cast<int>(p->frames), fLow, fHigh, p->sums, p->thrDev, st));
 	}
-	// ONE fill per step: edge counts, line counts and the hysteresis round flags live in one allocation
-	HIPCHK(ctx, hipMemsetAsync(p->counters, 0, sizeof(int) * (p->nCounts + kMaxRounds), st));
+	// ONE fill per step -- edge counts, line counts and the hysteresis round flags live in one allocation --, done by the first workgroups of the tile kernel
+	// (round 6: the hipMemsetAsync it replaces was a launch of its own on the lane's chain)
+	a.zero = p->counters; a.nZero = static_cast<int>(p->nCounts + kMaxRounds);
 	p->countersFresh = true;
 	p->roundsUsed = 0;
 	{
@@ -980,7 +983,8 @@ int compvhip_plan_create(compvhip_ctx* ctx, size_t W, size_t H, size_t S, size_t
 		if (dmalloc(ctx, &p->sums, frames * kFrameSlot) != hipSuccess) { rc = COMPVHIP_E_OUT_OF_MEMORY; break; }
 		if (hipHostMalloc(reinterpret_cast<void**>(&p->hFlags), sizeof(int) * 2 * (kAsyncDepth + 1)) != hipSuccess) { rc = COMPVHIP_E_OUT_OF_MEMORY; break; }
 		p->hTotals = reinterpret_cast<unsigned int*>(p->hFlags + kAsyncDepth + 1);
-		if (hipHostMalloc(reinterpret_cast<void**>(&p->hRounds), sizeof(int) * 4 * kAsyncDepth) != hipSuccess) { rc = COMPVHIP_E_OUT_OF_MEMORY; break; }
+		if (hipHostMalloc(reinterpret_cast<void**>(&p->hRounds), sizeof(int) * (kFrameSlot + 4) * kAsyncDepth, hipHostMallocMapped) != hipSuccess) { rc = COMPVHIP_E_OUT_OF_MEMORY; break; }
+		if (hipHostGetDevicePointer(reinterpret_cast<void**>(&p->hRoundsDev), p->hRounds, 0) != hipSuccess) { rc = COMPVHIP_E_HIP; break; }
 	} while (0);
 	if (rc) { compvhip_plan_destroy(p); return fail(ctx, rc, "plan allocation"); }
 	*out = p;
@@ -1193,6 +1197,8 @@ static int planShtImpl(compvhip_plan* p, const uint8_t* d_edges, int threshold, 
 		p->bitsValid = false; // U masks no longer match
 	}
 	ShtArgs a = shtArgs(p, threshold);
+	a.outCounts = d_counts;   // written by sht_lines_kernel together with the plan's own counts (was a device copy behind the sort)
+	a.hostStep = p->stepHostSlot; a.stepFlags = p->flags;   // asynchronous steps: line total + round flags straight into the ticket's pinned slot
 	const size_t capAll = p->lineCap * p->frames;
 	const bool deviceSort = p->deviceSort && !pairsOnly;   // every size read on the device: nothing to predict, nothing to pad
 	if (sortN != kSortExact) sortN = std::min(sortN, capAll);
@@ -1205,7 +1211,6 @@ static int planShtImpl(compvhip_plan* p, const uint8_t* d_edges, int threshold, 
 	{ Stamp s(p, st, "sht_lines_kernel"); HIPCHK(ctx, launch_sht_lines(a, frames, st)); }
 	// pairsOnly (the host entry point): stop at the (key, cell) pairs in emission order -- the caller orders them itself (referenceLineOrder)
 	if (pairsOnly) {
-		if (d_counts) HIPCHK(ctx, hipMemcpyAsync(d_counts, p->lineCounts, sizeof(int32_t) * frames, hipMemcpyDeviceToDevice, st));
 		return COMPVHIP_OK;
 	}
 	if (deviceSort) {
@@ -1215,7 +1220,6 @@ static int planShtImpl(compvhip_plan* p, const uint8_t* d_edges, int threshold, 
 			q.sortedKeys = p->keysB; q.sortedVals = p->valsB; q.chunkHist = p->chunkHist; q.strengthStart = p->strengthStart; q.chunks = p->sortChunks;
 			HIPCHK(ctx, launch_sht_sort_lines(a, q, frames, p->thetaStep, maxLines, d_lines, lineCap, st));
 		}
-		if (d_counts) HIPCHK(ctx, hipMemcpyAsync(d_counts, p->lineCounts, sizeof(int32_t) * frames, hipMemcpyDeviceToDevice, st));
 		return COMPVHIP_OK;
 	}
 	// Invariant of the library-sort fallback: nothing reads keysB / valsB beyond lineTotal (the decode kernel stops at the clamped per-frame counts), so the
@@ -1236,7 +1240,6 @@ static int planShtImpl(compvhip_plan* p, const uint8_t* d_edges, int threshold, 
 		HIPCHK(ctx, launch_sht_decode(p->keysB, p->valsB, p->lineCounts, p->lineCap, frames, static_cast<int>(p->T), static_cast<int>(p->W + p->H), p->thetaStep, maxLines,
 		                              p->strengthBits, d_lines, lineCap, st));
 	}
-	if (d_counts) HIPCHK(ctx, hipMemcpyAsync(d_counts, p->lineCounts, sizeof(int32_t) * frames, hipMemcpyDeviceToDevice, st));
 	return COMPVHIP_OK;
 }
 
@@ -1362,12 +1365,15 @@ static int runStepAsync(compvhip_plan* p, const StepParams& sp, hipStream_t st, 
 	}
 	if (p->deviceSort) sortN = kSortAll;   // sized on the device: no prediction to check
 	sortN = std::min(sortN, p->lineCap * p->frames);
+	// What compvhip_plan_wait needs -- the step's line total and its first four round flags -- is written by sht_lines_kernel straight into the ticket's pinned,
+	// device-mapped slot: no copy behind the step's kernels (rounds 2-5: three device-to-host copies, a device copy of the counts and a fill per step -- 30 us
+	// of stream operations between the last kernel of a step and the first of the next on a lane, 5 now)
+	static_assert(kMaxRounds >= 4 && kSpecRounds <= 4, "the round flags compvhip_plan_wait looks at");
+	if (p->roundsUsed > 4) return fail(ctx, COMPVHIP_E_INVALID_STATE, "more speculative rounds than flags the step reports");
+	p->stepHostSlot = p->hRoundsDev + (kFrameSlot + 4) * slot;
 	rc = enqueueStepTail(p, sp, st, sortN);
+	p->stepHostSlot = nullptr;
 	if (rc) return rc;
-	HIPCHK(ctx, hipMemcpyAsync(p->hFlags + 1 + slot, p->flags + (p->roundsUsed - 1), sizeof(int), hipMemcpyDeviceToHost, st));
-	static_assert(kMaxRounds >= 4, "the round flags compvhip_plan_wait learns from");
-	HIPCHK(ctx, hipMemcpyAsync(p->hRounds + 4 * slot, p->flags, sizeof(int) * 4, hipMemcpyDeviceToHost, st));
-	HIPCHK(ctx, hipMemcpyAsync(p->hTotals + 1 + slot, p->lineTotal, sizeof(unsigned int), hipMemcpyDeviceToHost, st));
 	HIPCHK(ctx, hipEventRecord(stp.done, st));
 	stp.used = true; stp.replay = false; stp.seq = ++p->stepSeq; stp.stream = st; stp.sp = sp; stp.sortN = sortN; stp.rounds = p->roundsUsed;
 	*ticket = slot;
@@ -1426,13 +1432,14 @@ int compvhip_plan_wait(compvhip_plan* p, int ticket)
 	HIPCHK(ctx, hipSetDevice(ctx->device));
 	HIPCHK(ctx, hipEventSynchronize(stp.done));
 	stp.used = false;
-	const unsigned int total = p->hTotals[1 + ticket];
+	const int* stepOut = p->hRounds + (kFrameSlot + 4) * ticket;   // what the step's one device-to-host copy brought: line total, then (kFrameSlot ints on) the round flags
+	const unsigned int total = static_cast<unsigned int>(stepOut[0]);
 	p->recentTotals[p->recentN++ & 7] = total;
 	if (p->recentN >= 16) p->recentN -= 8;   // the ring index keeps counting, "entries seen" saturates at 8
 	const bool sorted = static_cast<size_t>(total) <= stp.sortN;   // the predicted range covered every line of the step
 	{
 		// rounds this step needed = the first round that changed nothing, inclusive (more than were enqueued: one more than that, at least)
-		const int* rf = p->hRounds + 4 * ticket;
+		const int* rf = stepOut + kFrameSlot;
 		int needed = std::min(stp.rounds, 4) + 1;
 		for (int i = 0; i < std::min(stp.rounds, 4); ++i) if (rf[i] == 0) { needed = i + 1; break; }
 		p->recentRounds[p->recentRoundsN++ & 7] = static_cast<unsigned char>(std::min(needed, 255));
@@ -1442,7 +1449,8 @@ int compvhip_plan_wait(compvhip_plan* p, int ticket)
 		p->specRounds = (p->recentRoundsN >= 4) ? std::min(m, kSpecRounds) : kSpecRounds;   // a few steps first, then as many as they needed
 		if (getenv("COMPVHIP_TRACE_ROUNDS")) fprintf(stderr, "plan %p ticket %d: rounds enqueued %d, flags %d %d %d %d, needed %d -> next %d\n", (void*)p, ticket, stp.rounds, rf[0], rf[1], rf[2], rf[3], needed, p->specRounds);
 	}
-	if (p->hFlags[1 + ticket] == 0 && sorted && !stp.replay) return COMPVHIP_OK; // the speculative rounds reached the fixed point and the sort covered the lines (the usual case)
+	const int lastFlag = stepOut[kFrameSlot + std::max(0, std::min(stp.rounds, 4) - 1)];   // the flag of the step's last speculative round
+	if (lastFlag == 0 && sorted && !stp.replay) return COMPVHIP_OK; // the speculative rounds reached the fixed point and the sort covered the lines (the usual case)
 	// Rare: the hysteresis of this step needed more rounds than were enqueued (or it produced more lines than the sorted range held), and a later step may
 	// already have reused the plan's masks.  Let the stream drain and run the step again, synchronously, from its (unmodified) input.  The replay writes this
 	// step's output buffers AFTER the later steps of the plan ran: if they share those buffers (a caller that only consumes the newest

@@ -137,6 +137,8 @@ __global__ __launch_bounds__(WAVES * 64, (KS == 3 ? 8 : 7)) void canny_swar_tile
 
 	const int lane = threadIdx.x & 63;
 	const int wave = WAVES == 1 ? 0 : __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+	// the step's counters (consumed from the first hysteresis round on; the previous step's readers are behind us on the stream): 64 per workgroup
+	if (a.zero) for (int i = (int)blockIdx.x * (WAVES * 64) + (int)threadIdx.x; i < a.nZero; i += (int)gridDim.x * (WAVES * 64)) a.zero[i] = 0;   // (one trip, in the first workgroups, on any real launch)
 	int tileX, group;
 	if (!xcd_tile_map(blockIdx.x, a.tilesX, a.groups, tileX, group)) return;
 	const int frame = group / a.blockRows;

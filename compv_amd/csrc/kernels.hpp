@@ -34,6 +34,8 @@ struct CannyArgs {
 	int simdEnd, cStart;      // quirk Q3 coverage: [1,simdEnd) U [cStart,W-1)
 	int blockRows, groups;    // filled by the launcher: workgroup rows per frame, row groups in the launch (XCD-aware map)
 	int ksize;                // Sobel kernel size of the gradient: 3 or 5
+	int* zero; int nZero;     // counters the STEP needs cleared before its next kernel (edge / line / tile / block counts, round flags): the first nZero / 64 workgroups
+	                          // of the tile kernel clear 64 each -- a hipMemsetAsync per step was one more launch on the lane's chain (nullptr: nothing to clear)
 };
 
 struct ResolveArgs {
@@ -117,6 +119,10 @@ struct ShtArgs {
 	const int2* nmsRange;     // [nmsGroups] accumulator rows [x, y) the windows of the group's columns (+ one either side) can reach, widened by one row
 	int nmsGroups;            // groups of 8 theta columns
 	int* lineCounts;          // per frame
+	const int* stepFlags;     // asynchronous steps: the hysteresis round flags of this step (device) ...
+	int* hostStep;            // ... and where the host wants them: a device-mapped PINNED HOST slot, [0] = the line total, [kFrameSlot .. + 3] = the first four round flags;
+	                          // written by one wave of sht_lines_kernel (nullptr: not an asynchronous step) -- a device-to-host copy per step was one more operation on the lane's chain
+	int32_t* outCounts;       // the caller's per-frame line counts (device, may be nullptr): written with lineCounts by sht_lines_kernel -- a device copy per step was one more launch
 	int* frameTotals;         // [frames * kFrameSlot] NMS survivors per frame, one counter per 128-byte line (sht_nms_kernel adds its row blocks, zeroed per step)
 	unsigned int* lineTotal;  // sum over the frames of min(survivors, lineCap) = the key slots in use (written by sht_lines_kernel)
 	size_t sortN;             // key slots the sort will cover: sht_lines_kernel zeroes [lineTotal, sortN) (0: nothing to pad -- the sort is sized after the fact)

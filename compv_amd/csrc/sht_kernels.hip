@@ -348,7 +348,12 @@ __global__ __launch_bounds__(kLnRows) void sht_lines_kernel(ShtArgs a)
 	// last: every real key carries a strength > 0).  (Left to one block alone, the zeroing is 24 us on the critical path of a frame with few lines.)
 	if (blk == 0 && lane == 0) {
 		a.lineCounts[frame] = (int)min(count, 0x7fffffffu);
+		if (a.outCounts) a.outCounts[frame] = (int32_t)min(count, 0x7fffffffu);
 		if (frame == 0) *a.lineTotal = grand;
+	}
+	if (a.hostStep && blk == 0 && frame == 0 && lane < 4) {   // what compvhip_plan_wait looks at, straight into its pinned slot (visible to the host when the step's event has fired)
+		if (lane == 0) a.hostStep[0] = (int)grand;
+		a.hostStep[kFrameSlot + lane] = a.stepFlags[lane];
 	}
 	if ((size_t)grand < a.sortN) {
 		const size_t nb = (size_t)a.frames * (size_t)nblk, bi = (size_t)frame * (size_t)nblk + (size_t)blk;
