@@ -431,6 +431,8 @@ def main():
     ap.add_argument("--no-extras", action="store_true", help="skip the host_api / kht objects")
     ap.add_argument("--no-verify", action="store_true", help="experiment only: skip the golden check of all frames (the JSON line says so)")
     ap.add_argument("--no-kernel-events", action="store_true", help="experiment: no per-kernel HIP events in the timed steps")
+    ap.add_argument("--event-every", type=int, default=8,
+                    help="HIP events around the dominant kernel on every N-th step of a lane in the timed region (1 = every step: ~1 %% slower, the events are stream operations)")
     ap.add_argument("--reps", type=int, default=3, help="repetitions of the timed K-step loop; the MEDIAN repetition is reported")
     ap.add_argument("--inflight", type=int, default=2,
                     help="batches in flight: N plans (own buffers) on N HIP streams take the steps in turn, so the latency-bound kernels of one "
@@ -525,6 +527,7 @@ def main():
                 sharding.gather_lines(dist if dist_on else None, q["counts"], q["lines"][:, :TOPK].contiguous())
 
     step_no = [0]
+    sample_every, sample_mode = [1], [0]   # set once the dominant kernel is known
 
     def run_steps(k):
         """k steps.  Default: each step is enqueued with compvhip_plan_pipeline_async and waited for while the NEXT one is already
@@ -544,6 +547,10 @@ def main():
                 # the previous step on that lane has been waited for (a replayed step re-reads its input; the gather reads its results)
                 while len(pend) >= len(lanes):
                     finish(*pend.pop(0))
+            if sample_every[0] > 1:
+                # HIP events ride on every `sample_every`-th step of the timed region only (per lane: every lane is sampled): an event pair is two more
+                # operations on the lane's stream, ~6 us each -- around the dominant kernel of EVERY step they cost the headline ~1 %
+                q["plan"].set_timing(sample_mode[0] if (step_no[0] // len(lanes)) % sample_every[0] == 0 else 0)
             pend.append((q, enqueue(q, step_no[0])))
             step_no[0] += 1
             if len(pend) > max(1, min(args.depth, 3)) * len(lanes):   # the library keeps at most 4 steps of a plan in flight
@@ -576,6 +583,8 @@ def main():
     timed_mode = TIMING_MODES.get(dominant, 2)
     for q in lanes:
         q["plan"].set_timing(0 if args.no_kernel_events else timed_mode)
+    if not args.no_kernel_events and not args.sync_steps:
+        sample_every[0], sample_mode[0] = max(1, args.event_every), timed_mode
     per_kernel = {}
 
     def collect(dst, plans=None):
@@ -604,6 +613,7 @@ def main():
 
     # second pass, untimed: ONE batch at a time on ONE stream with HIP events around every launch -- the per-kernel durations a kernel
     # has when it owns the GPU (in the timed region two batches are in flight and kernels of different batches share the CUs)
+    sample_every[0] = 1
     for q in lanes:
         q["plan"].set_timing(0)
     breakdown = {}
@@ -731,6 +741,8 @@ def main():
                                       "kernels (ms_per_launch_timed_region, frac_timed_region)" % (breakdown[dom][1], len(lanes)))
                 roofline["ms_per_launch_timed_region"] = tr["ms_per_launch"]
                 roofline["frac_timed_region"] = tr["frac"]
+                roofline["timed_region_launches_sampled"] = int(per_kernel[dom][1]) if dom in per_kernel else 0
+                roofline["timed_region_sampling"] = "HIP events around this kernel on every %d-th step of each lane (--event-every)" % max(1, args.event_every)
             else:
                 roofline = roof(dom, alg.get(dom, F * W * H * 1.0))
                 roofline["timing"] = "HIP events on the launch stream around this kernel in every timed step"
