@@ -742,18 +742,35 @@ public:
 		if (pool_.empty()) { for (size_t i = 0; i < n; ++i) fn(i); return; }
 		std::shared_ptr<Job> job = std::make_shared<Job>(&fn, n, tag);
 		{
-			// later stages first (S > K > L > P): a group that is nearly through leaves before the next one starts, and the short K items never queue behind 3 ms links
+			// by stage priority (prio()), then by arrival
 			std::lock_guard<std::mutex> g(m_);
 			auto it = jobs_.begin();
 			while (it != jobs_.end() && prio((*it)->tag) >= prio(tag)) ++it;
 			jobs_.insert(it, job);
 		}
 		cv_.notify_all();
+		if (tag == 'K') {
+			// The prune items are short (0.2 ms) and gate their group's second GPU stage: when they are posted every worker is usually in the middle of a 3 ms
+			// link of another group, and the group -- and, 4 ms later, the workers -- would wait for one to come free.  The posting controller works along.
+			for (;;) {
+				size_t i;
+				{
+					std::lock_guard<std::mutex> g(m_);
+					if (job->next >= job->n) break;
+					i = job->next++;
+					if (job->next >= job->n) jobs_.erase(std::remove(jobs_.begin(), jobs_.end(), job), jobs_.end());
+				}
+				fn(i);
+				job->left.fetch_sub(1);
+			}
+		}
 		std::unique_lock<std::mutex> lk(m_);
 		done_.wait(lk, [&] { return job->left.load() == 0; });   // every item has RETURNED: fn may go out of scope
 	}
 private:
-	static int prio(char tag) { return tag == 'S' ? 3 : tag == 'K' ? 2 : tag == 'L' ? 1 : 0; }
+	// the stage with the longest way to go first: a frame that is not linked yet still needs 3 ms of link + two GPU stages + 2 ms of sweep, a sweep is the end of its frame
+	// and fills whatever gap is left (sweeps before links: 17.8 ms per 32 x 4K batch on 16 workers against 14.4)
+	static int prio(char tag) { return tag == 'K' ? 3 : (tag == 'L' || tag == 'P') ? 2 : 1; }
 	void loop()
 	{
 		for (;;) {

@@ -306,8 +306,8 @@ COMPVHIP_API int compvhip_plan_pipeline_ex(compvhip_plan* plan, const uint8_t* d
  * frames are independent, so they go through the stages in groups of 8: inside a group the host stages (linking, prune / Gmin, sort + sweep) are
  * parallel loops over its frames and every GPU stage is ONE launch over the strings / clusters / kernels / vote maps of all its frames; up to eight
  * groups are in flight, each with its own stream and a controller thread that only enqueues, SLEEPS on its GPU stages (blocking-sync events) and
- * posts its group's host stages to the hostThreads workers all groups share -- so while one group is on the GPU the workers link / sweep the frames of
- * the others.  hostThreads = 0: min(32, hardware threads / 2, the CPUs this process may really use: affinity mask and cgroup CPU quota).  COMPVHIP_E_OUT_OF_BOUND when a frame has more
+ * posts its group's host stages to the hostThreads workers all groups share (it works along on the short prune items only) -- so while one group is on the
+ * GPU the workers link / sweep the frames of the others.  hostThreads = 0: min(32, hardware threads / 2, the CPUs this process may really use: affinity mask and cgroup CPU quota).  COMPVHIP_E_OUT_OF_BOUND when a frame has more
  * than cap lines (counts[f] tells); on any other failure the error text names the frame.  clusterMinSize must be >= 2 (for 1 the reference's
  * cluster subdivision does not terminate: a defined deviation, also of compvhip_houghkht_u8 / compvhip_houghkht_kernels_u8).
  * compvhip_plan_houghkht_stage_ms: the six stage clocks of the last call summed over its frames (compvhip_houghkht_stage_ms order), the wall
