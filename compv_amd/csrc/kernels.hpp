@@ -13,7 +13,10 @@ namespace compvhip {
 #define COMPVHIP_BAND_H 64
 #endif
 constexpr int kBandH = COMPVHIP_BAND_H;            // rows per resolve band
-constexpr int kBandWords = 64;        // 32-px words per resolve chunk (2048 columns): 0.056 ms per step at 4K, 0.075 ms with 128
+#ifndef COMPVHIP_BAND_WORDS
+#define COMPVHIP_BAND_WORDS 64
+#endif
+constexpr int kBandWords = COMPVHIP_BAND_WORDS;        // 32-px words per resolve chunk (2048 columns): 0.056 ms per step at 4K, 0.075 ms with 128
 constexpr int kResolveThreads = 512;
 // Per-frame counters that many workgroups hit with atomics (Sobel gmax, the pixel sum of the mean thresholds) sit one per 128-byte line: the
 // L2 serialises the atomics of a line, and the counters of 32 frames side by side are ONE line.
