@@ -107,6 +107,23 @@ def test_bare_bench_gpus_2_starts_two_ranks_itself():
     assert res["dist_backend"] == "gloo" and res["value"] > 0
 
 
+@pytest.mark.gpu
+def test_bare_bench_refuses_more_gpus_than_visible():
+    """A bare `python bench.py --gpus N` with N > the GPUs of the node: the ranks it starts itself name the missing GPU and the launch ends non-zero in seconds,
+    with no JSON line (on a node that has the GPUs the same command is a normal run)."""
+    import subprocess
+    import sys
+    import torch
+    want = torch.cuda.device_count() + 1
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(want), "--steps", "2", "--warmup", "1", "--reps", "1", "--frames-per-gpu", "2", "--batches", "2",
+           "--width", "1280", "--height", "720", "--no-cpu-baseline", "--no-extras"]
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert r.returncode != 0
+    assert ("wants cuda:%d but this node shows %d GPU" % (want - 1, want - 1)) in r.stderr, r.stderr[-2000:]
+    assert not [l for l in r.stdout.splitlines() if l.startswith("{")]
+
+
 MGB = os.path.join(ROOT, "integration", "_build", "multi_gpu_batch")
 
 
