@@ -1032,6 +1032,7 @@ def kht_figure(capi, ctx, torch, lane, blocks, W, H, F):
             "roofline": roof,
             "cpu_baseline": cpu,
             "host_threads": stages.get("threads"),
+            "host_cpu_budget": capi.host_cpu_budget() if hasattr(capi, "host_cpu_budget") else None,   # what the default worker count is sized by (compvhip_host_cpu_budget)
             "host_share": stages.get("host_share"), "stages_ms_per_frame": stages.get("stages"),
             "note": "compvhip_plan_houghkht on the device edge maps of one batch: groups of 8 frames, host stages (linking, prune, sort + sweep) as parallel loops over a group's frames, "
                     "every GPU stage (subdivision, statistics, voting, peaks) ONE launch per group, up to 4 groups in flight; stages_ms_per_frame: host stages = thread time per frame, "

@@ -40,7 +40,7 @@ EXPORTS = [
     "compvhip_plan_pipeline_async", "compvhip_plan_wait", "compvhip_houghsht_to_cartesian", "compvhip_houghkht_to_cartesian",
     "compvhip_houghkht_kernels_u8", "compvhip_houghkht_stage_ms", "compvhip_convlt1_8u16s16s", "compvhip_convlt1_16s16s16s",
     "compvhip_plan_pipeline_ex", "compvhip_plan_houghkht", "compvhip_plan_houghkht_stage_ms", "compvhip_houghkht_link_u8",
-    "compvhip_houghkht_dims",
+    "compvhip_houghkht_dims", "compvhip_host_cpu_budget",
 ]
 
 
@@ -410,6 +410,13 @@ def houghkht_link(edges, min_size=10):
     if rc:
         raise CompvHipError(rc, "compvhip_houghkht_link_u8")
     return xy[:npts.value].copy(), ends[:nstr.value].copy()
+
+
+def host_cpu_budget():
+    """CPUs this process may really use at once: min(hardware threads, affinity mask, cgroup quota) (compvhip_host_cpu_budget)."""
+    lib = load()
+    lib.compvhip_host_cpu_budget.restype = C.c_int
+    return int(lib.compvhip_host_cpu_budget())
 
 
 def houghsht_vote_grid(W, H, theta_deg=1.0, frames=1):

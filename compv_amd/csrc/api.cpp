@@ -938,6 +938,11 @@ int compvhip_houghsht_vote_grid(size_t W, size_t H, float thetaDeg, size_t frame
 	return COMPVHIP_OK;
 }
 
+int compvhip_host_cpu_budget(void)
+{
+	return static_cast<int>(std::min<size_t>(hostCpuBudget(), 0x7fffffff));
+}
+
 int compvhip_houghsht_dims(size_t W, size_t H, float thetaDeg, size_t* R, size_t* T, float* step)
 {
 	if (!R || !T) return COMPVHIP_E_INVALID_PARAMETER;

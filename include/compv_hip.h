@@ -202,6 +202,10 @@ COMPVHIP_API int compvhip_houghkht_dims(size_t W, size_t H, float rho, float the
  * (acc_gather, houghsht.cxx:350-481, runs as one workgroup per frame, tile and 64 theta bins).  Host arithmetic only: what
  * compvhip_plan_create would choose, for tests and capacity planning.  COMPVHIP_E_NOT_IMPLEMENTED when no grid fits. */
 COMPVHIP_API int compvhip_houghsht_vote_grid(size_t W, size_t H, float thetaDeg, size_t frames, int* nx, int* ny, int* windowRows);
+/* The CPUs this process may really use at once: min(hardware threads, affinity mask, cgroup CPU quota) -- what compvhip_plan_houghkht sizes its default
+ * worker pool by (hostThreads = 0), and what the reference's CompVBase::init(-1) (base/compv_base.cxx:62: one thread per logical CPU) does not look at: a
+ * container may show 256 logical CPUs and own 16.  Host arithmetic only; always >= 1. */
+COMPVHIP_API int compvhip_host_cpu_budget(void);
 
 /* ---- device-resident batched pipeline (frames already in HBM) ---------------------------------------------- */
 

@@ -61,6 +61,32 @@ def test_vote_grid_helper():
     assert grid(640, 480, 1, 0.0)[0] == capi.E_INVALID_PARAMETER
 
 
+def test_host_cpu_budget_is_what_the_host_grants():
+    """compvhip_host_cpu_budget = min(hardware threads, affinity mask, cgroup CPU quota): the default worker count of compvhip_plan_houghkht."""
+    from compv_amd import capi
+    n = capi.host_cpu_budget()
+    want = os.cpu_count() or 1
+    try:
+        want = min(want, len(os.sched_getaffinity(0)))
+    except AttributeError:
+        pass
+    for path in ("/sys/fs/cgroup/cpu.max",):
+        try:
+            q = open(path).read().split()
+            if q[0] != "max":
+                want = min(want, max(1, int(q[0]) // int(q[1])))
+        except (OSError, ValueError, IndexError):
+            pass
+    try:
+        quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+        period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+        if quota > 0 and period > 0 and not os.path.exists("/sys/fs/cgroup/cpu.max"):
+            want = min(want, max(1, quota // period))
+    except (OSError, ValueError):
+        pass
+    assert n == want and n >= 1
+
+
 def test_no_gpu_means_loud_failure():
     from compv_amd import capi
     lib = capi.load()
